@@ -1,0 +1,56 @@
+// Shared device helpers for libavsep_gfx950 (gfx950 / CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "avsep.h"
+
+#define AVSEP_LAUNCH_CHECK()                                   \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) return AVSEP_ERR_LAUNCH;            \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == AVSEP_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == AVSEP_ACT_LRELU02) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+// derivative of act at pre-activation value v
+__device__ __forceinline__ float act_grad(float v, int act) {
+  if (act == AVSEP_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  if (act == AVSEP_ACT_LRELU02) return v > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+// sum over the 64 lanes of a wave (all lanes get the result)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum within each 32-lane half of the wave
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (id % 8 equal under
+// round-robin dispatch) receive CONSECUTIVE logical ids, so tiles that re-read the same
+// operand sit behind one L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  int q = nblocks >> 3, r = nblocks & 7, x = bid & 7, s = bid >> 3;
+  int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + s;
+}

@@ -1,0 +1,560 @@
+// Implicit-GEMM convolution (forward / data-gradient / weight-gradient) on the exact-f32
+// MFMA (v_mfma_f32_32x32x2_f32) for gfx950.  NCHW fp32.  See include/avsep.h.
+//
+// GEMM view (D[M][N], N on the lanes so global stores are coalesced):
+//   fwd   : D[co][pix]   = sum_k  Wp[k][co]      * X(k, pix)        k = (ci,kh,kw)
+//   dgrad : D[ci][pixin] = sum_k' Wd[k'][ci]     * dY(k', pixin)    k' = (tap,co), one launch
+//           slice (blockIdx.y) per input-pixel parity class so strided convs waste no MFMA work
+//   wgrad : D[co][k]     = sum_pix dY[co][pix]   * X(k, pix)        split over pixel chunks
+// X(k,pix) is the *virtual* conv input: two-source channel concat, per-channel affine (folded
+// BatchNorm), activation and optional bilinear x2 upsample are applied while gathering.
+// Both operands are staged global -> registers -> LDS (K-major, double buffered, one barrier
+// per K-tile); each wave owns a (BM/WM)x(BN/WN) block of 32x32 MFMA tiles.
+#include "common.h"
+
+enum { M_FWD = 0, M_DGRAD = 1, M_WGRAD = 2 };
+
+struct CArgs {
+  int N, Cin, H, W, Cout, Ho, Wo, KH, KW, stride, pad, dil;
+  int C0, C1, act0, act1, up2x;
+  int Hs, Ws;  // source spatial size (H/2, W/2 when up2x)
+  float rh, rw;
+  const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
+  const float* wp;
+  int wp_ld;
+  const float* dy;
+  float* out;
+  const float* bias;
+  double* stats;
+  int M, Ncols, K;
+  int gridM;
+  int chunk, P;  // wgrad: pixels per split, total pixels
+};
+
+__device__ __forceinline__ float load_src(const CArgs& a, long long nb0, long long nb1, int ci, int off) {
+  float v;
+  if (ci < a.C0) {
+    v = a.x0[nb0 + (long long)ci * (a.Hs * a.Ws) + off];
+    if (a.sc0) v = fmaf(v, a.sc0[ci], a.sh0[ci]);
+    v = act_apply(v, a.act0);
+  } else {
+    int c1 = ci - a.C0;
+    v = a.x1[nb1 + (long long)c1 * (a.Hs * a.Ws) + off];
+    if (a.sc1) v = fmaf(v, a.sc1[c1], a.sh1[c1]);
+    v = act_apply(v, a.act1);
+  }
+  return v;
+}
+
+// value of the virtual input at (ci, hi, wi), 0<=hi<H, 0<=wi<W
+__device__ __forceinline__ float load_virtual(const CArgs& a, long long nb0, long long nb1, int ci, int hi,
+                                              int wi) {
+  if (!a.up2x) return load_src(a, nb0, nb1, ci, hi * a.Ws + wi);
+  // nn.Upsample(scale_factor=2, bilinear, align_corners=True): src = dst*(in-1)/(out-1)
+  float fh = a.rh * (float)hi, fw = a.rw * (float)wi;
+  int h0 = (int)fh, w0 = (int)fw;
+  int h1 = h0 + (h0 < a.Hs - 1), w1 = w0 + (w0 < a.Ws - 1);
+  float lh = fh - (float)h0, lw = fw - (float)w0;
+  float v00 = load_src(a, nb0, nb1, ci, h0 * a.Ws + w0), v01 = load_src(a, nb0, nb1, ci, h0 * a.Ws + w1);
+  float v10 = load_src(a, nb0, nb1, ci, h1 * a.Ws + w0), v11 = load_src(a, nb0, nb1, ci, h1 * a.Ws + w1);
+  return (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+}
+
+template <int MODE, int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LDA = BM + ((MODE == M_WGRAD) ? 1 : 4);
+  constexpr int LDB = BN + ((MODE == M_WGRAD) ? 1 : 0);
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+  __shared__ float Bs[2][BK][LDB];
+  __shared__ int s_tab[(MODE == M_WGRAD) ? BN : 24];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int HoWo = a.Ho * a.Wo, KHW = a.KH * a.KW, HW = a.H * a.W;
+  const long long srcHW = (long long)a.Hs * a.Ws;
+
+  int M = a.M, Ncols = a.Ncols, K = a.K;
+  int ph = 0, pw = 0, Hc = 0, Wc = 0, ntw = 1;
+  if (MODE == M_DGRAD) {
+    const int s = a.stride;
+    ph = blockIdx.y / s;
+    pw = blockIdx.y % s;
+    Hc = (a.H > ph) ? (a.H - ph + s - 1) / s : 0;
+    Wc = (a.W > pw) ? (a.W - pw + s - 1) / s : 0;
+    if (tid == 0) {
+      int nh = 0, nw = 0;
+      for (int kh = 0; kh < a.KH; ++kh) {
+        int t = ph + a.pad - kh * a.dil;
+        if (((t % s) + s) % s == 0) s_tab[2 + nh++] = kh;
+      }
+      for (int kw = 0; kw < a.KW; ++kw) {
+        int t = pw + a.pad - kw * a.dil;
+        if (((t % s) + s) % s == 0) s_tab[12 + nw++] = kw;
+      }
+      s_tab[0] = nh;
+      s_tab[1] = nw;
+    }
+    __syncthreads();
+    ntw = s_tab[1];
+    Ncols = a.N * Hc * Wc;
+    K = s_tab[0] * ntw * a.Cout;
+  }
+  const int t_lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = (t_lin / a.gridM) * BN, m0 = (t_lin % a.gridM) * BM;
+  if (MODE == M_DGRAD && n0 >= Ncols) return;  // block-uniform
+
+  int p_begin = 0, p_end = 0, nK;
+  if (MODE == M_WGRAD) {
+    p_begin = blockIdx.y * a.chunk;
+    p_end = min(a.P, p_begin + a.chunk);
+    nK = (p_end - p_begin + BK - 1) / BK;
+    // per-column (k) decode table: ci | dh<<16 | dw<<24
+    for (int c = tid; c < BN; c += 256) {
+      int k = n0 + c, v = -1;
+      if (k < Ncols) {
+        int ci = k / KHW, r = k % KHW;
+        v = ci | ((r / a.KW) * a.dil << 16) | ((r % a.KW) * a.dil << 24);
+      }
+      s_tab[c] = v;
+    }
+    __syncthreads();
+  } else {
+    nK = (K + BK - 1) / BK;
+  }
+
+  // ---------------- per-thread loader state ----------------
+  // fwd/dgrad: thread owns one column (bcol) and BROWS consecutive k rows
+  constexpr int BGROUPS = 256 / BN, BROWS = (MODE == M_WGRAD) ? 1 : BK / BGROUPS;
+  constexpr int A4 = BM / 4, AV = (MODE == M_WGRAD) ? 1 : (BK * A4) / 256;
+  constexpr int PG = 256 / BK, AE = BM / PG, BE = BN / PG;  // wgrad
+  const int bcol = tid % BN, brow0 = (tid / BN) * BROWS;
+  bool cvalid = false;
+  long long nb0 = 0, nb1 = 0, nbdy = 0;
+  int hi0 = 0, wi0 = 0;
+  if (MODE == M_FWD) {
+    int j = n0 + bcol;
+    cvalid = j < Ncols;
+    int jj = cvalid ? j : 0;
+    int n = jj / HoWo, hw = jj % HoWo;
+    hi0 = (hw / a.Wo) * a.stride - a.pad;
+    wi0 = (hw % a.Wo) * a.stride - a.pad;
+    nb0 = (long long)n * a.C0 * srcHW;
+    nb1 = (long long)n * a.C1 * srcHW;
+  } else if (MODE == M_DGRAD) {
+    int q = n0 + bcol;
+    cvalid = q < Ncols;
+    int qq = cvalid ? q : 0;
+    int n = qq / (Hc * Wc), r = qq % (Hc * Wc);
+    hi0 = (r / Wc) * a.stride + ph + a.pad;  // hi + pad
+    wi0 = (r % Wc) * a.stride + pw + a.pad;
+    nbdy = (long long)n * a.Cout * HoWo;
+  }
+
+  float breg[(MODE == M_WGRAD) ? BE : BROWS];
+  float4 areg4[AV];
+  float areg[(MODE == M_WGRAD) ? AE : 1];
+
+  auto load_tile = [&](int kt) {
+    if (MODE == M_FWD) {
+#pragma unroll
+      for (int e = 0; e < AV; ++e) {
+        int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
+        areg4[e] = *reinterpret_cast<const float4*>(a.wp + (long long)(kt * BK + row) * a.wp_ld + m0 + c4 * 4);
+      }
+      int k = kt * BK + brow0;
+      int ci = k / KHW, r = k % KHW, kh = r / a.KW, kw = r % a.KW;
+#pragma unroll
+      for (int e = 0; e < BROWS; ++e) {
+        float v = 0.f;
+        if (cvalid && k + e < K) {
+          int hi = hi0 + kh * a.dil, wi = wi0 + kw * a.dil;
+          if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+            v = load_virtual(a, nb0, nb1, ci, hi, wi);
+        }
+        breg[e] = v;
+        if (++kw == a.KW) {
+          kw = 0;
+          if (++kh == a.KH) { kh = 0; ++ci; }
+        }
+      }
+    } else if (MODE == M_DGRAD) {
+#pragma unroll
+      for (int e = 0; e < AV; ++e) {
+        int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
+        int k = kt * BK + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) {
+          int co = k % a.Cout, t = k / a.Cout;
+          int kh = s_tab[2 + t / ntw], kw = s_tab[12 + t % ntw];
+          v = *reinterpret_cast<const float4*>(a.wp + (long long)((kh * a.KW + kw) * a.Cout + co) * a.wp_ld + m0 +
+                                               c4 * 4);
+        }
+        areg4[e] = v;
+      }
+      int k = kt * BK + brow0;
+      int co = k % a.Cout, t = k / a.Cout;
+#pragma unroll
+      for (int e = 0; e < BROWS; ++e) {
+        float v = 0.f;
+        if (cvalid && k + e < K) {
+          int kh = s_tab[2 + t / ntw], kw = s_tab[12 + t % ntw];
+          int th = hi0 - kh * a.dil, tw = wi0 - kw * a.dil;
+          if (th >= 0 && tw >= 0) {
+            int ho = th / a.stride, wo = tw / a.stride;
+            if (ho < a.Ho && wo < a.Wo) v = a.dy[nbdy + (long long)co * HoWo + ho * a.Wo + wo];
+          }
+        }
+        breg[e] = v;
+        if (++co == a.Cout) { co = 0; ++t; }
+      }
+    } else {  // WGRAD: thread owns one pixel row (p_local) and AE/BE strided columns
+      int p = p_begin + kt * BK + (tid % BK);
+      bool pv = p < p_end;
+      int pp = pv ? p : 0;
+      int n = pp / HoWo, hw = pp % HoWo;
+      int hb = (hw / a.Wo) * a.stride - a.pad, wb = (hw % a.Wo) * a.stride - a.pad;
+      long long b0 = (long long)n * a.C0 * srcHW, b1 = (long long)n * a.C1 * srcHW;
+      long long bdy = (long long)n * a.Cout * HoWo + hw;
+      const int grp = tid / BK;
+#pragma unroll
+      for (int e = 0; e < AE; ++e) {
+        int co = m0 + grp + PG * e;
+        areg[e] = (pv && co < M) ? a.dy[bdy + (long long)co * HoWo] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < BE; ++e) {
+        int tab = s_tab[grp + PG * e];
+        float v = 0.f;
+        if (pv && tab >= 0) {
+          int ci = tab & 0xffff, hi = hb + ((tab >> 16) & 0xff), wi = wb + ((tab >> 24) & 0xff);
+          if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) v = load_virtual(a, b0, b1, ci, hi, wi);
+        }
+        breg[e] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    if (MODE != M_WGRAD) {
+#pragma unroll
+      for (int e = 0; e < AV; ++e) {
+        int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
+        *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = areg4[e];
+      }
+#pragma unroll
+      for (int e = 0; e < BROWS; ++e) Bs[buf][brow0 + e][bcol] = breg[e];
+    } else {
+      const int pl = tid % BK, grp = tid / BK;
+#pragma unroll
+      for (int e = 0; e < AE; ++e) As[buf][pl][grp + PG * e] = areg[e];
+#pragma unroll
+      for (int e = 0; e < BE; ++e) Bs[buf][pl][grp + PG * e] = breg[e];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nK > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  const int li = lane & 31, lk = lane >> 5;
+  for (int kt = 0; kt < nK; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nK) load_tile(kt + 1);
+#pragma unroll
+    for (int k2 = 0; k2 < BK / 2; ++k2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = As[buf][2 * k2 + lk][wm * WTM + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][2 * k2 + lk][wn * WTN + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nK) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  long long cbase[TN];
+  bool cok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int col = n0 + wn * WTN + j * 32 + li;
+    cok[j] = col < Ncols;
+    int cc = cok[j] ? col : 0;
+    if (MODE == M_FWD) {
+      int n = cc / HoWo, hw = cc % HoWo;
+      cbase[j] = (long long)n * a.Cout * HoWo + hw;
+    } else if (MODE == M_DGRAD) {
+      int n = cc / (Hc * Wc), r = cc % (Hc * Wc);
+      cbase[j] = (long long)n * a.Cin * HW + ((r / Wc) * a.stride + ph) * a.W + (r % Wc) * a.stride + pw;
+    } else {
+      cbase[j] = (long long)blockIdx.y * M * Ncols + cc;
+    }
+  }
+  const long long rstride = (MODE == M_FWD) ? HoWo : (MODE == M_DGRAD ? HW : Ncols);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      bool rok = row < M;
+      float bias = (MODE == M_FWD && a.bias && rok) ? a.bias[row] : 0.f;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float v = acc[i][j][r] + bias;
+        if (rok && cok[j]) {
+          a.out[cbase[j] + (long long)row * rstride] = v;
+          s += v;
+          q += v * v;
+        }
+      }
+      if (MODE == M_FWD && a.stats) {
+        s = half_sum(s);
+        q = half_sum(q);
+        if (li == 0 && rok) {
+          atomicAdd(&a.stats[row], (double)s);
+          atomicAdd(&a.stats[M + row], (double)q);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// small helper kernels
+// ---------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH,
+                                    int KW, int rows, int ld, int mode) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)rows * ld;
+  if (i >= total) return;
+  int row = (int)(i / ld), col = (int)(i % ld);
+  int KHW = KH * KW;
+  float v = 0.f;
+  if (mode == 0) {  // row = k = (ci,kh,kw), col = co
+    if (row < Cin * KHW && col < Cout) v = w[(long long)col * Cin * KHW + row];
+  } else {  // row = tap*Cout + co, col = ci
+    if (row < KHW * Cout && col < Cin) {
+      int tap = row / Cout, co = row % Cout;
+      v = w[((long long)co * Cin + col) * KHW + tap];
+    }
+  }
+  out[i] = v;
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n, int S) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < S; ++z) s += ws[(long long)z * n + i];
+  out[i] = s;
+}
+
+// dbias[c] = sum over n,hw of dy[n,c,hw]; one block per channel
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int N, int C, int HW,
+                                                          float* __restrict__ out) {
+  int c = blockIdx.x;
+  double s = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* p = x + ((long long)n * C + c) * HW;
+    float t = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) t += p[i];
+    s += (double)t;
+  }
+  __shared__ double sh[4];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int check_desc(const avsep_conv_desc* d, bool fwd_only = false) {
+  if (!d || !d->x0) return AVSEP_ERR_ARG;
+  if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return AVSEP_ERR_ARG;
+  if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0) return AVSEP_ERR_ARG;
+  // the dgrad tap tables and the wgrad column table hold at most 8 taps per axis / 8-bit offsets
+  if (!fwd_only && (d->KH > 8 || d->KW > 8 || (d->KH - 1) * d->dil > 255 || (d->KW - 1) * d->dil > 255 ||
+                    d->Cin > 65535))
+    return AVSEP_ERR_ARG;
+  if (d->C0 <= 0 || d->C0 > d->Cin || (d->C0 < d->Cin && !d->x1)) return AVSEP_ERR_ARG;
+  int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  if (ho != d->Ho || wo != d->Wo) return AVSEP_ERR_ARG;
+  if (d->up2x && ((d->H & 1) || (d->W & 1))) return AVSEP_ERR_ARG;
+  if ((d->scale0 == nullptr) != (d->shift0 == nullptr)) return AVSEP_ERR_ARG;
+  if ((d->scale1 == nullptr) != (d->shift1 == nullptr)) return AVSEP_ERR_ARG;
+  return AVSEP_OK;
+}
+
+static CArgs make_args(const avsep_conv_desc* d) {
+  CArgs a{};
+  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = d->up2x;
+  a.Hs = d->up2x ? d->H / 2 : d->H;
+  a.Ws = d->up2x ? d->W / 2 : d->W;
+  a.rh = (d->up2x && d->H > 1) ? (float)(a.Hs - 1) / (float)(d->H - 1) : 0.f;
+  a.rw = (d->up2x && d->W > 1) ? (float)(a.Ws - 1) / (float)(d->W - 1) : 0.f;
+  a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
+  return a;
+}
+
+static inline int packed_rows(const avsep_conv_desc* d, int mode) {
+  return mode == 0 ? roundup(d->Cin * d->KH * d->KW, 32) : roundup(d->KH * d->KW * d->Cout, 32);
+}
+static inline int packed_ld(const avsep_conv_desc* d, int mode) { return roundup(mode == 0 ? d->Cout : d->Cin, 128); }
+
+extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
+  if (!d || (mode != 0 && mode != 1)) return 0;
+  return (size_t)packed_rows(d, mode) * packed_ld(d, mode);
+}
+
+extern "C" int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w, float* packed, int mode,
+                                       avsep_stream_t stream) {
+  if (!d || !w || !packed || (mode != 0 && mode != 1)) return AVSEP_ERR_ARG;
+  int rows = packed_rows(d, mode), ld = packed_ld(d, mode);
+  long long total = (long long)rows * ld;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed,
+                     d->Cout, d->Cin, d->KH, d->KW, rows, ld, mode);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// big tiles when they still fill the chip, else 64x64
+static inline bool use_big(int M, long long ncols) {
+  return M > 64 && (long long)cdiv(M, 128) * cdiv(ncols, 128) >= 320;
+}
+
+extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed, const float* bias, float* y,
+                                double* stats, avsep_stream_t stream) {
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  if (!w_packed || !y) return AVSEP_ERR_ARG;
+  CArgs a = make_args(d);
+  a.wp = w_packed; a.wp_ld = packed_ld(d, 0); a.out = y; a.bias = bias; a.stats = stats;
+  a.M = d->Cout; a.K = d->Cin * d->KH * d->KW;
+  long long ncols = (long long)d->N * d->Ho * d->Wo;
+  if (ncols > 0x7fffffffLL) return AVSEP_ERR_ARG;
+  a.Ncols = (int)ncols;
+  hipStream_t st = (hipStream_t)stream;
+  if (use_big(a.M, ncols)) {
+    a.gridM = cdiv(a.M, 128);
+    hipLaunchKernelGGL((igemm_kernel<M_FWD, 128, 128, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 128)), dim3(256), 0, st, a);
+  } else {
+    a.gridM = cdiv(a.M, 64);
+    hipLaunchKernelGGL((igemm_kernel<M_FWD, 64, 64, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 64)), dim3(256), 0, st, a);
+  }
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packed_dgrad, const float* dy, float* dx,
+                                  avsep_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
+  CArgs a = make_args(d);
+  a.wp = w_packed_dgrad; a.wp_ld = packed_ld(d, 1); a.dy = dy; a.out = dx;
+  a.M = d->Cin;
+  const int s = d->stride;
+  long long ncols = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);  // largest parity class
+  if ((long long)d->N * d->H * d->W > 0x7fffffffLL) return AVSEP_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (use_big(a.M, ncols * s * s)) {
+    a.gridM = cdiv(a.M, 128);
+    hipLaunchKernelGGL((igemm_kernel<M_DGRAD, 128, 128, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 128), s * s), dim3(256), 0,
+                       st, a);
+  } else {
+    a.gridM = cdiv(a.M, 64);
+    hipLaunchKernelGGL((igemm_kernel<M_DGRAD, 64, 64, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 64), s * s), dim3(256), 0, st,
+                       a);
+  }
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+struct WgradPlan {
+  bool big;
+  int splits, chunk, tiles;
+};
+static WgradPlan wgrad_plan(const avsep_conv_desc* d) {
+  WgradPlan p;
+  int M = d->Cout, Kc = d->Cin * d->KH * d->KW;
+  long long P = (long long)d->N * d->Ho * d->Wo;
+  p.big = M > 64 && Kc > 64;
+  int bm = p.big ? 128 : 64;
+  p.tiles = cdiv(M, bm) * cdiv(Kc, bm);
+  int want = cdiv(1024, p.tiles);                       // aim for ~1024 workgroups
+  long long maxs = (P + 255) / 256;                      // at least 256 pixels per split
+  int splits = (int)((want < maxs) ? want : maxs);
+  if (splits < 1) splits = 1;
+  long long chunk = (P + splits - 1) / splits;
+  chunk = (chunk + 31) / 32 * 32;
+  p.chunk = (int)chunk;
+  p.splits = (int)((P + chunk - 1) / chunk);
+  return p;
+}
+
+extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  WgradPlan p = wgrad_plan(d);
+  if (p.splits <= 1) return 0;
+  return (size_t)p.splits * d->Cout * d->Cin * d->KH * d->KW * sizeof(float);
+}
+
+extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias, void* workspace,
+                                  size_t workspace_bytes, avsep_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!dy || !dw) return AVSEP_ERR_ARG;
+  WgradPlan p = wgrad_plan(d);
+  size_t need = avsep_conv2d_wgrad_workspace_bytes(d);
+  if (need > workspace_bytes || (need && !workspace)) return AVSEP_ERR_WORKSPACE;
+  CArgs a = make_args(d);
+  a.dy = dy;
+  a.M = d->Cout; a.Ncols = d->Cin * d->KH * d->KW; a.K = 0;
+  long long P = (long long)d->N * d->Ho * d->Wo;
+  if (P > 0x7fffffffLL) return AVSEP_ERR_ARG;
+  a.P = (int)P; a.chunk = p.chunk;
+  a.out = (p.splits > 1) ? (float*)workspace : dw;
+  hipStream_t st = (hipStream_t)stream;
+  if (p.big) {
+    a.gridM = cdiv(a.M, 128);
+    hipLaunchKernelGGL((igemm_kernel<M_WGRAD, 128, 128, 32, 2, 2>), dim3(a.gridM * cdiv(a.Ncols, 128), p.splits), dim3(256),
+                       0, st, a);
+  } else {
+    a.gridM = cdiv(a.M, 64);
+    hipLaunchKernelGGL((igemm_kernel<M_WGRAD, 64, 64, 32, 2, 2>), dim3(a.gridM * cdiv(a.Ncols, 64), p.splits), dim3(256), 0,
+                       st, a);
+  }
+  AVSEP_LAUNCH_CHECK();
+  if (p.splits > 1) {
+    long long n = (long long)a.M * a.Ncols;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, dw, n, p.splits);
+    AVSEP_LAUNCH_CHECK();
+  }
+  if (dbias) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(d->Cout), dim3(256), 0, st, dy, d->N, d->Cout, d->Ho * d->Wo, dbias);
+    AVSEP_LAUNCH_CHECK();
+  }
+  return AVSEP_OK;
+}

@@ -1,0 +1,381 @@
+// Bottleneck audio-visual fusion (models/fusion_net.py): one workgroup per sample.
+// The whole CoLoc block (global max-pool -> 4 similarity maps -> per-map max -> best of the two
+// permutations -> match loss terms -> attended / selected visual vectors) is one launch forward and
+// one launch backward, replacing ~25 tiny ATen launches.  gfx950, wave64.
+#include "common.h"
+
+#define FUS_EPS 1e-8f
+
+struct FusArgs {
+  const float *x, *v0, *v1;
+  int B, Dc, FT, HW, kind, att;
+};
+
+// argmax (first index on ties) of s[0..n) by one wave; result valid in all lanes
+__device__ __forceinline__ void wave_argmax(const float* s, int n, int lane, float& best, int& arg) {
+  best = -INFINITY;
+  arg = 0x7fffffff;
+  for (int i = lane; i < n; i += 64) {
+    float v = s[i];
+    if (v > best) { best = v; arg = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob = __shfl_xor(best, o, 64);
+    int oa = __shfl_xor(arg, o, 64);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+  }
+}
+
+// maps m[k][c][hw] (k = audio block, c = visual map) into s_m; v norms into s_nv (cos); a norms into s_na
+__device__ void fusion_maps(const FusArgs& a, int b, const float* s_a, float* s_m, float* s_nv, float* s_na,
+                            float* s_red) {
+  const int tid = threadIdx.x, Dc = a.Dc, HW = a.HW;
+  const float inv_sqrt = 1.f / sqrtf((float)Dc);
+  if (a.att == 0) {  // norms of the two audio blocks
+    float q0 = 0.f, q1 = 0.f;
+    for (int d = tid; d < Dc; d += 256) { q0 += s_a[d] * s_a[d]; q1 += s_a[Dc + d] * s_a[Dc + d]; }
+    q0 = wave_sum(q0);
+    q1 = wave_sum(q1);
+    if ((tid & 63) == 0) { s_red[tid >> 6] = q0; s_red[4 + (tid >> 6)] = q1; }
+    __syncthreads();
+    if (tid == 0) {
+      s_na[0] = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+      s_na[1] = sqrtf(s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+    }
+    __syncthreads();
+  }
+  for (int hw = tid; hw < HW; hw += 256) {
+    for (int c = 0; c < 2; ++c) {
+      const float* vp = (c == 0 ? a.v0 : a.v1) + (long long)b * Dc * HW + hw;
+      float d0 = 0.f, d1 = 0.f, nv = 0.f;
+      for (int d = 0; d < Dc; ++d) {
+        float vv = vp[(long long)d * HW];
+        d0 = fmaf(s_a[d], vv, d0);
+        d1 = fmaf(s_a[Dc + d], vv, d1);
+        nv = fmaf(vv, vv, nv);
+      }
+      float m0, m1;
+      if (a.att == 1) {
+        m0 = 1.f / (1.f + expf(-d0 * inv_sqrt));
+        m1 = 1.f / (1.f + expf(-d1 * inv_sqrt));
+      } else {
+        nv = sqrtf(nv);
+        float dn = fmaxf(nv, FUS_EPS);
+        m0 = d0 / (fmaxf(s_na[0], FUS_EPS) * dn);
+        m1 = d1 / (fmaxf(s_na[1], FUS_EPS) * dn);
+        s_nv[c * HW + hw] = nv;
+      }
+      s_m[(0 * 2 + c) * HW + hw] = m0;
+      s_m[(1 * 2 + c) * HW + hw] = m1;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void fusion_av_fwd_kernel(FusArgs a, float* __restrict__ a_pool, int* __restrict__ pool_idx,
+                                                            float* __restrict__ feat, int* __restrict__ sel_idx,
+                                                            float* __restrict__ att_maps, float* __restrict__ match_part,
+                                                            int* __restrict__ best_out) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Dc = a.Dc, D = 2 * a.Dc, HW = a.HW, FT = a.FT;
+  float* s_a = sm;                 // [2*Dc]
+  float* s_m = s_a + D;            // [4*HW]
+  float* s_nv = s_m + 4 * HW;      // [2*HW]
+  float* s_red = s_nv + 2 * HW;    // [16]
+  float* s_na = s_red + 16;        // [2]
+  float* s_mx = s_na + 2;          // [4] per-map max
+  int* s_arg = (int*)(s_mx + 4);   // [4]
+  int* s_best = s_arg + 4;         // [1]
+
+  // 1. global max-pool over F x T with argmax (first max wins)
+  for (int d = tid; d < D; d += 256) {
+    const float* p = a.x + ((long long)b * D + d) * FT;
+    float m = p[0];
+    int am = 0;
+    for (int i = 1; i < FT; ++i) {
+      float v = p[i];
+      if (v > m) { m = v; am = i; }
+    }
+    s_a[d] = m;
+    a_pool[(long long)b * D + d] = m;
+    pool_idx[(long long)b * D + d] = am;
+  }
+  __syncthreads();
+  // 2. similarity maps
+  fusion_maps(a, b, s_a, s_m, s_nv, s_na, s_red);
+  // 3. per-map max / argmax: wave w handles map (k = w>>1, c = w&1)
+  {
+    float mx;
+    int am;
+    wave_argmax(s_m + wave * HW, HW, lane, mx, am);
+    if (lane == 0) { s_mx[wave] = mx; s_arg[wave] = am; }
+  }
+  __syncthreads();
+  // 4. permutation scores: p=0 pairs (k=c), p=1 pairs (k=1-c)
+  if (tid == 0) {
+    float p0 = s_mx[0 * 2 + 0] + s_mx[1 * 2 + 1];
+    float p1 = s_mx[1 * 2 + 0] + s_mx[0 * 2 + 1];
+    int best = p1 > p0 ? 1 : 0;  // torch.sort(descending) keeps index 0 first on ties
+    s_best[0] = best;
+    best_out[b] = best;
+    match_part[b] = best ? (p0 - p1) : (p1 - p0);  // -best + rest
+  }
+  __syncthreads();
+  const int best = s_best[0];
+  // 5. attention maps of the winning permutation
+  for (int i = tid; i < 2 * HW; i += 256) {
+    int c = i / HW, hw = i % HW;
+    att_maps[((long long)b * 2 + c) * HW + hw] = s_m[((c ^ best) * 2 + c) * HW + hw];
+  }
+  // 6. attended (max-pool of v * att) or selected visual vectors
+  for (int i = tid; i < D; i += 256) {
+    int c = i / Dc, d = i % Dc;
+    const float* vp = (c == 0 ? a.v0 : a.v1) + ((long long)b * Dc + d) * HW;
+    const float* at = s_m + ((c ^ best) * 2 + c) * HW;
+    float f;
+    int arg;
+    if (a.kind == 0) {
+      f = vp[0] * at[0];
+      arg = 0;
+      for (int hw = 1; hw < HW; ++hw) {
+        float v = vp[hw] * at[hw];
+        if (v > f) { f = v; arg = hw; }
+      }
+    } else {
+      arg = s_arg[(c ^ best) * 2 + c];
+      f = vp[arg];
+    }
+    feat[(long long)b * D + i] = f;
+    sel_idx[(long long)b * D + i] = arg;
+  }
+}
+
+__global__ __launch_bounds__(256) void fusion_av_bwd_kernel(FusArgs a, const float* __restrict__ a_pool,
+                                                            const int* __restrict__ pool_idx,
+                                                            const int* __restrict__ sel_idx,
+                                                            const int* __restrict__ best_in,
+                                                            const float* __restrict__ dfeat,
+                                                            const float* __restrict__ dmaps,
+                                                            const float* __restrict__ dmatch_ptr, float dmatch_scale,
+                                                            float* __restrict__ dx, float* __restrict__ dv0,
+                                                            float* __restrict__ dv1) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Dc = a.Dc, D = 2 * a.Dc, HW = a.HW, FT = a.FT;
+  float* s_a = sm;
+  float* s_m = s_a + D;
+  float* s_nv = s_m + 4 * HW;
+  float* s_red = s_nv + 2 * HW;
+  float* s_na = s_red + 16;
+  float* s_mx = s_na + 2;
+  int* s_arg = (int*)(s_mx + 4);
+  float* s_E = (float*)(s_arg + 4) + 4;  // [4*HW] gradient wrt maps m[k][c][hw]
+  float* s_S = s_E + 4 * HW;             // [2] cos: sum E*m per audio block
+
+  for (int d = tid; d < D; d += 256) s_a[d] = a_pool[(long long)b * D + d];
+  for (int i = tid; i < 4 * HW; i += 256) s_E[i] = 0.f;
+  __syncthreads();
+  fusion_maps(a, b, s_a, s_m, s_nv, s_na, s_red);
+  {
+    float mx;
+    int am;
+    wave_argmax(s_m + wave * HW, HW, lane, mx, am);
+    if (lane == 0) s_arg[wave] = am;
+  }
+  __syncthreads();
+  const int best = best_in[b];
+  const float dmatch = (dmatch_ptr ? dmatch_ptr[0] : 1.f) * dmatch_scale;
+  // match loss: -score(best) + score(other); score_p = sum_c max_hw m[k=c^p][c]
+  if (tid < 4) {
+    int k = tid >> 1, c = tid & 1, p = k ^ c;
+    atomicAdd(&s_E[tid * HW + s_arg[tid]], (p == best ? -1.f : 1.f) * dmatch);
+  }
+  if (dmaps)
+    for (int i = tid; i < 2 * HW; i += 256) {
+      int c = i / HW, hw = i % HW;
+      atomicAdd(&s_E[((c ^ best) * 2 + c) * HW + hw], dmaps[((long long)b * 2 + c) * HW + hw]);
+    }
+  if (a.kind == 0)  // attended vector: f = v[d,h*] * att[c][h*]
+    for (int i = tid; i < D; i += 256) {
+      int c = i / Dc, d = i % Dc, h = sel_idx[(long long)b * D + i];
+      float vv = (c == 0 ? a.v0 : a.v1)[((long long)b * Dc + d) * HW + h];
+      atomicAdd(&s_E[((c ^ best) * 2 + c) * HW + h], dfeat[(long long)b * D + i] * vv);
+    }
+  __syncthreads();
+  const float inv_sqrt = 1.f / sqrtf((float)Dc);
+  if (a.att == 1) {  // through the sigmoid: G = E * m(1-m)/sqrt(Dc)
+    for (int i = tid; i < 4 * HW; i += 256) {
+      float m = s_m[i];
+      s_E[i] *= m * (1.f - m) * inv_sqrt;
+    }
+  } else {  // cos: S_k = sum_{c,hw} E*m
+    float q0 = 0.f, q1 = 0.f;
+    for (int i = tid; i < 2 * HW; i += 256) { q0 += s_E[i] * s_m[i]; q1 += s_E[2 * HW + i] * s_m[2 * HW + i]; }
+    q0 = wave_sum(q0);
+    q1 = wave_sum(q1);
+    if ((tid & 63) == 0) { s_red[tid >> 6] = q0; s_red[4 + (tid >> 6)] = q1; }
+    __syncthreads();
+    if (tid == 0) {
+      s_S[0] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+      s_S[1] = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    }
+  }
+  __syncthreads();
+  // gradient to the audio vectors -> scattered to the arg-max position of the global max-pool
+  for (int i = tid; i < D; i += 256) {
+    int k = i / Dc, d = i % Dc;
+    float g = 0.f;
+    for (int c = 0; c < 2; ++c) {
+      const float* vp = (c == 0 ? a.v0 : a.v1) + ((long long)b * Dc + d) * HW;
+      const float* E = s_E + (k * 2 + c) * HW;
+      if (a.att == 1) {
+        for (int hw = 0; hw < HW; ++hw) g = fmaf(E[hw], vp[hw], g);
+      } else {
+        const float* nv = s_nv + c * HW;
+        for (int hw = 0; hw < HW; ++hw) g = fmaf(E[hw] / fmaxf(nv[hw], FUS_EPS), vp[hw], g);
+      }
+    }
+    if (a.att == 0) {
+      float na = s_na[k], nac = fmaxf(na, FUS_EPS);
+      g = g / nac;
+      if (na > FUS_EPS) g -= s_S[k] * s_a[i] / (na * na);
+    }
+    if (dx) {
+      long long o = ((long long)b * D + i) * FT + pool_idx[(long long)b * D + i];
+      dx[o] += g;
+    }
+  }
+  // gradient to the visual maps (every element written)
+  for (int c = 0; c < 2; ++c) {
+    float* dv = c == 0 ? dv0 : dv1;
+    if (!dv) continue;
+    const float* vsrc = (c == 0 ? a.v0 : a.v1) + (long long)b * Dc * HW;
+    const float* E0 = s_E + (0 * 2 + c) * HW;
+    const float* E1 = s_E + (1 * 2 + c) * HW;
+    const float* at = s_m + ((c ^ best) * 2 + c) * HW;
+    const int where = s_arg[(c ^ best) * 2 + c];
+    for (int i = tid; i < Dc * HW; i += 256) {
+      int d = i / HW, hw = i % HW;
+      float g;
+      if (a.att == 1) {
+        g = E0[hw] * s_a[d] + E1[hw] * s_a[Dc + d];
+      } else {
+        float nv = s_nv[c * HW + hw], nvc = fmaxf(nv, FUS_EPS);
+        float na0 = fmaxf(s_na[0], FUS_EPS), na1 = fmaxf(s_na[1], FUS_EPS);
+        g = (E0[hw] * s_a[d] / na0 + E1[hw] * s_a[Dc + d] / na1) / nvc;
+        if (nv > FUS_EPS)
+          g -= (E0[hw] * s_m[(0 * 2 + c) * HW + hw] + E1[hw] * s_m[(1 * 2 + c) * HW + hw]) * vsrc[i] / (nv * nv);
+      }
+      int sel = sel_idx[(long long)b * D + c * Dc + d];
+      if (a.kind == 0) {
+        if (hw == sel) g += dfeat[(long long)b * D + c * Dc + d] * at[hw];
+      } else {
+        if (hw == where) g += dfeat[(long long)b * D + c * Dc + d];
+      }
+      dv[(long long)b * Dc * HW + i] = g;
+    }
+  }
+}
+
+static size_t fusion_smem(int Dc, int HW) { return (size_t)(2 * Dc + 4 * HW + 2 * HW + 16 + 2 + 4 + 4 + 4 + 4 * HW + 2) * 4; }
+
+extern "C" int avsep_fusion_av_fwd(const float* x, const float* v0, const float* v1, int32_t B, int32_t Dc, int32_t FT,
+                                   int32_t HW, int32_t kind, int32_t att, float* a_pool, int32_t* pool_idx, float* feat,
+                                   int32_t* sel_idx, float* att_maps, float* match_part, int32_t* best,
+                                   avsep_stream_t stream) {
+  if (!x || !v0 || !v1 || !a_pool || !pool_idx || !feat || !sel_idx || !att_maps || !match_part || !best)
+    return AVSEP_ERR_ARG;
+  if (B <= 0 || Dc <= 0 || FT <= 0 || HW <= 0 || (att != 0 && att != 1)) return AVSEP_ERR_ARG;
+  if (kind != 0 && kind != 1) return AVSEP_ERR_ARG;  // MixVis (kind 2) is not built yet
+  size_t smem = fusion_smem(Dc, HW);
+  if (smem > 160 * 1024) return AVSEP_ERR_ARG;
+  FusArgs a{x, v0, v1, B, Dc, FT, HW, kind, att};
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)fusion_av_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(fusion_av_fwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, a, a_pool, pool_idx, feat, sel_idx,
+                     att_maps, match_part, best);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+extern "C" int avsep_fusion_av_bwd(const float* x, const float* v0, const float* v1, int32_t B, int32_t Dc, int32_t FT,
+                                   int32_t HW, int32_t kind, int32_t att, const float* a_pool, const int32_t* pool_idx,
+                                   const int32_t* sel_idx, const float* att_maps, const int32_t* best, const float* dfeat,
+                                   const float* dmaps, const float* dmatch, float dmatch_scale, float* dx_accum, float* dv0, float* dv1,
+                                   avsep_stream_t stream) {
+  (void)att_maps;
+  if (!x || !v0 || !v1 || !a_pool || !pool_idx || !sel_idx || !best || !dfeat) return AVSEP_ERR_ARG;
+  if (B <= 0 || Dc <= 0 || FT <= 0 || HW <= 0 || (att != 0 && att != 1)) return AVSEP_ERR_ARG;
+  if (kind != 0 && kind != 1) return AVSEP_ERR_ARG;
+  size_t smem = fusion_smem(Dc, HW);
+  if (smem > 160 * 1024) return AVSEP_ERR_ARG;
+  FusArgs a{x, v0, v1, B, Dc, FT, HW, kind, att};
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)fusion_av_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(fusion_av_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, a, a_pool, pool_idx, sel_idx, best,
+                     dfeat, dmaps, dmatch, dmatch_scale, dx_accum, dv0, dv1);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// audio-only branch: swapped global-max-pooled blocks (fusion_net.py:93-104)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fusion_ao_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ draws,
+                                                            int all_zero, int Dc, int FT, float* __restrict__ feat,
+                                                            int* __restrict__ pool_idx) {
+  const int b = blockIdx.x, D = 2 * Dc;
+  extern __shared__ float s_a[];
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float* p = x + ((long long)b * D + d) * FT;
+    float m = p[0];
+    int am = 0;
+    for (int i = 1; i < FT; ++i)
+      if (p[i] > m) { m = p[i]; am = i; }
+    s_a[d] = m;
+    pool_idx[(long long)b * D + d] = am;
+  }
+  __syncthreads();
+  const int draw = draws[b];
+  for (int i = threadIdx.x; i < D; i += 256) {
+    int slot = i / Dc, d = i % Dc;
+    int src = all_zero ? 1 : (draw ? slot : 1 - slot);  // gather index = one_hot(draw)[slot]
+    feat[(long long)b * D + i] = s_a[src * Dc + d];
+  }
+}
+
+__global__ __launch_bounds__(256) void fusion_ao_bwd_kernel(const uint8_t* __restrict__ draws, int all_zero, int Dc, int FT,
+                                                            const int* __restrict__ pool_idx,
+                                                            const float* __restrict__ dfeat, float* __restrict__ dx) {
+  const int b = blockIdx.x, D = 2 * Dc;
+  const int draw = draws[b];
+  for (int i = threadIdx.x; i < D; i += 256) {  // i indexes the SOURCE block element
+    int blk = i / Dc, d = i % Dc;
+    float g = 0.f;
+    for (int slot = 0; slot < 2; ++slot) {
+      int src = all_zero ? 1 : (draw ? slot : 1 - slot);
+      if (src == blk) g += dfeat[(long long)b * D + slot * Dc + d];
+    }
+    dx[((long long)b * D + i) * FT + pool_idx[(long long)b * D + i]] += g;
+  }
+}
+
+extern "C" int avsep_fusion_ao_fwd(const float* x, const uint8_t* draws, int32_t all_zero, int32_t B, int32_t Dc,
+                                   int32_t FT, float* feat, int32_t* pool_idx, avsep_stream_t stream) {
+  if (!x || !draws || !feat || !pool_idx || B <= 0 || Dc <= 0 || FT <= 0 || Dc > 8192) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(fusion_ao_fwd_kernel, dim3(B), dim3(256), 2 * Dc * sizeof(float), (hipStream_t)stream, x, draws, all_zero,
+                     Dc, FT, feat, pool_idx);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+extern "C" int avsep_fusion_ao_bwd(const uint8_t* draws, int32_t all_zero, int32_t B, int32_t Dc, int32_t FT,
+                                   const int32_t* pool_idx, const float* dfeat, float* dx_accum, avsep_stream_t stream) {
+  if (!draws || !pool_idx || !dfeat || !dx_accum || B <= 0 || Dc <= 0 || FT <= 0) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(fusion_ao_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, draws, all_zero, Dc, FT, pool_idx,
+                     dfeat, dx_accum);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}

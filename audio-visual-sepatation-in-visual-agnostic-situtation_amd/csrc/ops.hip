@@ -1,0 +1,794 @@
+// HBM-bound kernels of the train step: BatchNorm pieces, decoder glue (ReLU + bilinear x2 and
+// its transpose), prepare (log-frequency warp + masks + weights), fused mask loss, SGD, pooling.
+// gfx950 only.  See include/avsep.h for the contract of every entry point.
+#include "common.h"
+
+// ============================================================================
+// BatchNorm pieces
+// ============================================================================
+// grid (C, chunks): block reduces one channel over a slice of (n,hw)
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int N, int C, int HW,
+                                                            double* __restrict__ stats) {
+  const int c = blockIdx.x;
+  const long long total = (long long)N * HW;
+  const long long per = (total + gridDim.y - 1) / gridDim.y;
+  const long long beg = per * blockIdx.y, end = min(total, beg + per);
+  float s = 0.f, q = 0.f;
+  double ds = 0.0, dq = 0.0;
+  int cnt = 0;
+  for (long long i = beg + threadIdx.x; i < end; i += 256) {
+    int n = (int)(i / HW), hw = (int)(i % HW);
+    float v = x[((long long)n * C + c) * HW + hw];
+    s += v;
+    q += v * v;
+    if (++cnt == 64) { ds += s; dq += q; s = q = 0.f; cnt = 0; }
+  }
+  ds += s;
+  dq += q;
+  ds = wave_sum_d(ds);
+  dq = wave_sum_d(dq);
+  __shared__ double sh[8];
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = ds; sh[4 + (threadIdx.x >> 6)] = dq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[c], sh[0] + sh[1] + sh[2] + sh[3]);
+    atomicAdd(&stats[C + c], sh[4] + sh[5] + sh[6] + sh[7]);
+  }
+}
+
+extern "C" int avsep_channel_stats(const float* x, int32_t N, int32_t C, int32_t HW, double* stats,
+                                   avsep_stream_t stream) {
+  if (!x || !stats || N <= 0 || C <= 0 || HW <= 0) return AVSEP_ERR_ARG;
+  long long total = (long long)N * HW;
+  int chunks = (int)min((long long)cdiv(2048, C), (total + 4095) / 4096);
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(channel_stats_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, stats);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, int C, int training, float* scale, float* shift,
+                                   float* mean_o, float* invstd_o) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (training) {
+    mean = stats[c] / count;
+    var = stats[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (running_mean) {
+      double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  float sc = g * invstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  if (mean_o) mean_o[c] = (float)mean;
+  if (invstd_o) invstd_o[c] = invstd;
+}
+
+extern "C" int avsep_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, int32_t C,
+                                 int32_t training, float* scale, float* shift, float* mean, float* invstd,
+                                 avsep_stream_t stream) {
+  if (C <= 0 || !scale || !shift) return AVSEP_ERR_ARG;
+  if (training ? !stats : (!running_mean || !running_var)) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, count, gamma,
+                     beta, running_mean, running_var, momentum, eps, C, training, scale, shift, mean, invstd);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ bstats, double count, const float* __restrict__ gamma,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd, int C,
+                                     float* dgamma, float* dbeta, float* pqr) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = bstats[c], s2 = bstats[C + c];
+  double g = gamma ? gamma[c] : 1.0, is = invstd[c], mu = mean[c];
+  double p = g * is;
+  double q = -p * is * s2 / count;
+  double r = -p * s1 / count - q * mu;
+  if (dgamma) dgamma[c] = (float)s2;
+  if (dbeta) dbeta[c] = (float)s1;
+  pqr[c] = (float)p;
+  pqr[C + c] = (float)q;
+  pqr[2 * C + c] = (float)r;
+}
+
+extern "C" int avsep_bn_bwd_coeffs(const double* bstats, double count, const float* gamma, const float* mean,
+                                   const float* invstd, int32_t C, float* dgamma, float* dbeta, float* pqr,
+                                   avsep_stream_t stream) {
+  if (!bstats || !mean || !invstd || !pqr || C <= 0) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, bstats, count, gamma,
+                     mean, invstd, C, dgamma, dbeta, pqr);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// grid (chunks over hw, C, N) — float4 when HW % 4 == 0
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                           const float* __restrict__ pqr, int C, int HW,
+                                                           float* __restrict__ dy) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float p = pqr[c], q = pqr[C + c], r = pqr[2 * C + c];
+  const long long base = ((long long)n * C + c) * HW;
+  if ((HW & 3) == 0) {
+    const float4* dz4 = reinterpret_cast<const float4*>(dz + base);
+    const float4* y4 = reinterpret_cast<const float4*>(y + base);
+    float4* o4 = reinterpret_cast<float4*>(dy + base);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += gridDim.x * 256) {
+      float4 a = dz4[i], b = y4[i], o;
+      o.x = fmaf(p, a.x, fmaf(q, b.x, r));
+      o.y = fmaf(p, a.y, fmaf(q, b.y, r));
+      o.z = fmaf(p, a.z, fmaf(q, b.z, r));
+      o.w = fmaf(p, a.w, fmaf(q, b.w, r));
+      o4[i] = o;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256)
+      dy[base + i] = fmaf(p, dz[base + i], fmaf(q, y[base + i], r));
+  }
+}
+
+extern "C" int avsep_bn_bwd_apply(const float* dz, const float* y, const float* pqr, int32_t N, int32_t C, int32_t HW,
+                                  float* dy, avsep_stream_t stream) {
+  if (!dz || !y || !pqr || !dy || N <= 0 || C <= 0 || HW <= 0) return AVSEP_ERR_ARG;
+  if (C > 65535 || N > 65535) return AVSEP_ERR_ARG;
+  int gx = min(cdiv(HW, 1024), 64);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, dz, y, pqr, C, HW, dy);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ res, int act, int C, int HW,
+                                                         float* __restrict__ z) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+  const long long base = ((long long)n * C + c) * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float v = fmaf(y[base + i], sc, sh);
+    if (res) v += res[base + i];
+    z[base + i] = act_apply(v, act);
+  }
+}
+
+extern "C" int avsep_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
+                                int32_t act, int32_t N, int32_t C, int32_t HW, float* z, avsep_stream_t stream) {
+  if (!y || !z || N <= 0 || C <= 0 || HW <= 0 || C > 65535 || N > 65535) return AVSEP_ERR_ARG;
+  int gx = min(cdiv(HW, 256), 64);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, y, scale, shift, residual, act,
+                     C, HW, z);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// grid (C, chunks)
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ res,
+                                                             const float* __restrict__ add,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int act, int N, int C,
+                                                             int HW, float* __restrict__ out, double* bstats) {
+  const int c = blockIdx.x;
+  const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+  const float mu = mean ? mean[c] : 0.f, is = invstd ? invstd[c] : 1.f;
+  const long long total = (long long)N * HW;
+  const long long per = (total + gridDim.y - 1) / gridDim.y;
+  const long long beg = per * blockIdx.y, end = min(total, beg + per);
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = beg + threadIdx.x; i < end; i += 256) {
+    int n = (int)(i / HW), hw = (int)(i % HW);
+    long long o = ((long long)n * C + c) * HW + hw;
+    float yv = y[o];
+    float pre = fmaf(yv, sc, sh);
+    if (res) pre += res[o];
+    float g = act_grad(pre, act) * dz[o];
+    if (add) g += add[o];
+    out[o] = g;
+    s1 += g;
+    s2 += g * (yv - mu) * is;
+  }
+  if (bstats) {
+    double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+    __shared__ double sh2[8];
+    if ((threadIdx.x & 63) == 0) { sh2[threadIdx.x >> 6] = d1; sh2[4 + (threadIdx.x >> 6)] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&bstats[c], sh2[0] + sh2[1] + sh2[2] + sh2[3]);
+      atomicAdd(&bstats[C + c], sh2[4] + sh2[5] + sh2[6] + sh2[7]);
+    }
+  }
+}
+
+extern "C" int avsep_affine_act_bwd(const float* dz, const float* y, const float* scale, const float* shift,
+                                    const float* residual, const float* add, const float* mean, const float* invstd,
+                                    int32_t act, int32_t N, int32_t C, int32_t HW, float* dz_pre, double* bstats,
+                                    avsep_stream_t stream) {
+  if (!dz || !y || !dz_pre || N <= 0 || C <= 0 || HW <= 0) return AVSEP_ERR_ARG;
+  if (bstats && (!mean || !invstd)) return AVSEP_ERR_ARG;
+  long long total = (long long)N * HW;
+  int chunks = (int)min((long long)cdiv(2048, C), (total + 2047) / 2048);
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(affine_act_bwd_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, y, scale, shift,
+                     residual, add, mean, invstd, act, N, C, HW, dz_pre, bstats);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// ============================================================================
+// decoder glue: out = up2x(relu(cat(T0(x0), T1(x1))))   and transpose
+// ============================================================================
+struct CatArgs {
+  int N, C0, C1, H, W, b0, b1;
+  const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
+  float rh, rw;
+};
+__device__ __forceinline__ float cat_relu_val(const CatArgs& a, int n, int c, int h, int w) {
+  float v;
+  if (c < a.C0) {
+    v = a.b0 ? a.x0[(long long)n * a.C0 + c] : a.x0[(((long long)n * a.C0 + c) * a.H + h) * a.W + w];
+    if (a.sc0) v = fmaf(v, a.sc0[c], a.sh0[c]);
+  } else {
+    int c1 = c - a.C0;
+    v = a.b1 ? a.x1[(long long)n * a.C1 + c1] : a.x1[(((long long)n * a.C1 + c1) * a.H + h) * a.W + w];
+    if (a.sc1) v = fmaf(v, a.sc1[c1], a.sh1[c1]);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void relu_up2x_fwd_kernel(CatArgs a, float* __restrict__ out) {
+  const int Ho = 2 * a.H, Wo = 2 * a.W, C = a.C0 + a.C1;
+  const long long total = (long long)a.N * C * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int wo = (int)(i % Wo);
+    long long t = i / Wo;
+    int ho = (int)(t % Ho);
+    t /= Ho;
+    int c = (int)(t % C), n = (int)(t / C);
+    float fh = a.rh * (float)ho, fw = a.rw * (float)wo;
+    int h0 = (int)fh, w0 = (int)fw;
+    int h1 = h0 + (h0 < a.H - 1), w1 = w0 + (w0 < a.W - 1);
+    float lh = fh - (float)h0, lw = fw - (float)w0;
+    float v00 = fmaxf(cat_relu_val(a, n, c, h0, w0), 0.f), v01 = fmaxf(cat_relu_val(a, n, c, h0, w1), 0.f);
+    float v10 = fmaxf(cat_relu_val(a, n, c, h1, w0), 0.f), v11 = fmaxf(cat_relu_val(a, n, c, h1, w1), 0.f);
+    out[i] = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+  }
+}
+
+static CatArgs make_cat(const avsep_cat_desc* d) {
+  CatArgs a{};
+  a.N = d->N; a.C0 = d->C0; a.C1 = d->C1; a.H = d->H; a.W = d->W; a.b0 = d->bcast0; a.b1 = d->bcast1;
+  a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
+  a.rh = (float)(d->H - 1) / (float)(2 * d->H - 1);
+  a.rw = (float)(d->W - 1) / (float)(2 * d->W - 1);
+  return a;
+}
+static int check_cat(const avsep_cat_desc* d) {
+  if (!d || d->N <= 0 || d->C0 <= 0 || d->C1 < 0 || d->H <= 0 || d->W <= 0 || !d->x0) return AVSEP_ERR_ARG;
+  if (d->C1 > 0 && !d->x1) return AVSEP_ERR_ARG;
+  return AVSEP_OK;
+}
+
+extern "C" int avsep_relu_up2x_fwd(const avsep_cat_desc* d, float* out, avsep_stream_t stream) {
+  int rc = check_cat(d);
+  if (rc || !out) return AVSEP_ERR_ARG;
+  CatArgs a = make_cat(d);
+  long long total = (long long)d->N * (d->C0 + d->C1) * 4 * d->H * d->W;
+  int blocks = (int)min((total + 255) / 256, (long long)65536);
+  hipLaunchKernelGGL(relu_up2x_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, out);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// transpose-gather of the bilinear weights for one low-res position along one axis
+__device__ __forceinline__ int up2x_taps(int h, int Hin, float r, int* idx, float* wt) {
+  int cnt = 0;
+  int lo = max(0, 2 * h - 3), hi = min(2 * Hin - 1, 2 * h + 4);
+  for (int ho = lo; ho <= hi; ++ho) {
+    float f = r * (float)ho;
+    int h0 = (int)f;
+    int h1 = h0 + (h0 < Hin - 1);
+    float l = f - (float)h0;
+    float w = (h0 == h ? 1.f - l : 0.f) + (h1 == h ? l : 0.f);
+    if (w != 0.f) { idx[cnt] = ho; wt[cnt] = w; ++cnt; }
+  }
+  return cnt;
+}
+
+// grid (C0+C1, chunks); a block reduces the BN-backward sums of its channel
+__global__ __launch_bounds__(256) void relu_up2x_bwd_kernel(CatArgs a, const float* __restrict__ dout,
+                                                            float* __restrict__ g0, float* __restrict__ g1,
+                                                            const float* __restrict__ mean1,
+                                                            const float* __restrict__ invstd1, double* bstats1,
+                                                            int acc0) {
+  const int C = a.C0 + a.C1, c = blockIdx.x;
+  const int Ho = 2 * a.H, Wo = 2 * a.W, HW = a.H * a.W;
+  const bool first = c < a.C0;
+  const int cs = first ? c : c - a.C0, Cs = first ? a.C0 : a.C1;
+  const bool bc = first ? a.b0 : a.b1;
+  float* g = first ? g0 : g1;
+  float s1 = 0.f, s2 = 0.f;
+  const float mu = (!first && mean1) ? mean1[cs] : 0.f, is = (!first && invstd1) ? invstd1[cs] : 1.f;
+  if (g) {
+    if (bc) {  // one thread per sample: sum over the whole low-res map
+      for (int n = blockIdx.y * 256 + threadIdx.x; n < a.N; n += gridDim.y * 256) {
+        float v = cat_relu_val(a, n, c, 0, 0), tot = 0.f;
+        if (v > 0.f) {
+          const float* p = dout + ((long long)n * C + c) * Ho * Wo;
+          for (int i = 0; i < Ho * Wo; ++i) tot += p[i];  // bilinear weights of a constant map sum to 1 per output
+        }
+        long long o = (long long)n * Cs + cs;
+        g[o] = (acc0 && first) ? g[o] + tot : tot;
+      }
+    } else {
+      const long long total = (long long)a.N * HW;
+      const long long per = (total + gridDim.y - 1) / gridDim.y;
+      const long long beg = per * blockIdx.y, end = min(total, beg + per);
+      for (long long i = beg + threadIdx.x; i < end; i += 256) {
+        int n = (int)(i / HW), hw = (int)(i % HW), h = hw / a.W, w = hw % a.W;
+        float pre = cat_relu_val(a, n, c, h, w);
+        float tot = 0.f;
+        if (pre > 0.f) {
+          int ih[8], iw[8];
+          float wh[8], ww[8];
+          int nh = up2x_taps(h, a.H, a.rh, ih, wh), nw = up2x_taps(w, a.W, a.rw, iw, ww);
+          const float* p = dout + ((long long)n * C + c) * Ho * Wo;
+          for (int y = 0; y < nh; ++y) {
+            float row = 0.f;
+            for (int x = 0; x < nw; ++x) row += ww[x] * p[ih[y] * Wo + iw[x]];
+            tot += wh[y] * row;
+          }
+        }
+        long long o = ((long long)n * Cs + cs) * HW + hw;
+        g[o] = (acc0 && first) ? g[o] + tot : tot;
+        if (!first && bstats1) {
+          float yv = a.x1[o];
+          s1 += tot;
+          s2 += tot * (yv - mu) * is;
+        }
+      }
+    }
+  }
+  if (!first && bstats1) {
+    double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+    __shared__ double sh2[8];
+    if ((threadIdx.x & 63) == 0) { sh2[threadIdx.x >> 6] = d1; sh2[4 + (threadIdx.x >> 6)] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&bstats1[cs], sh2[0] + sh2[1] + sh2[2] + sh2[3]);
+      atomicAdd(&bstats1[a.C1 + cs], sh2[4] + sh2[5] + sh2[6] + sh2[7]);
+    }
+  }
+}
+
+extern "C" int avsep_relu_up2x_bwd(const avsep_cat_desc* d, const float* dout, float* g0, float* g1,
+                                   const float* mean1, const float* invstd1, double* bstats1, int32_t acc0,
+                                   avsep_stream_t stream) {
+  int rc = check_cat(d);
+  if (rc || !dout) return AVSEP_ERR_ARG;
+  if (bstats1 && (!mean1 || !invstd1 || d->bcast1 || !g1)) return AVSEP_ERR_ARG;
+  CatArgs a = make_cat(d);
+  int C = d->C0 + d->C1;
+  long long total = (long long)d->N * d->H * d->W;
+  int chunks = (int)min((long long)cdiv(4096, C), (total + 511) / 512);
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(relu_up2x_bwd_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, a, dout, g0, g1, mean1,
+                     invstd1, bstats1, acc0);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// ============================================================================
+// prepare: eps + log-frequency warp + weight + GT masks + log   (main.py:51-95)
+// ============================================================================
+// numpy.linspace(-1, 1, n)[i] in float64
+__device__ __forceinline__ double linspace_pm1(int i, int n) {
+  if (n == 1) return -1.0;
+  if (i == n - 1) return 1.0;
+  return -1.0 + (double)i * (2.0 / (double)(n - 1));
+}
+// y coordinate of utils.py:warpgrid in float64, cast to fp32 like grid.astype(np.float32)
+__device__ __forceinline__ float warp_gy(int f, int Fout, int warp) {
+  double yv = linspace_pm1(f, Fout);
+  double gy = warp ? (pow(21.0, (yv + 1.0) / 2.0) - 11.0) / 10.0 : log(yv * 10.0 + 11.0) / log(21.0) * 2.0 - 1.0;
+  return (float)gy;
+}
+
+struct Bilin {
+  int y0, x0;
+  float wnw, wne, wsw, wse;
+};
+// F.grid_sample(bilinear, zeros, align_corners=False) coordinates for one output location
+__device__ __forceinline__ Bilin grid_bilin(float gx, float gy, int Hin, int Win) {
+  float ix = ((gx + 1.f) * (float)Win - 1.f) / 2.f;
+  float iy = ((gy + 1.f) * (float)Hin - 1.f) / 2.f;
+  float fx = floorf(ix), fy = floorf(iy);
+  Bilin b;
+  b.x0 = (int)fx;
+  b.y0 = (int)fy;
+  float ex = fx + 1.f - ix, ey = fy + 1.f - iy;  // distance to the east / south neighbour
+  float wx = ix - fx, wy = iy - fy;
+  b.wnw = ex * ey;
+  b.wne = wx * ey;
+  b.wsw = ex * wy;
+  b.wse = wx * wy;
+  return b;
+}
+__device__ __forceinline__ float sample_bilin(const float* __restrict__ p, const Bilin& b, int Hin, int Win,
+                                              float eps) {
+  float v = 0.f;
+  bool y0 = (unsigned)b.y0 < (unsigned)Hin, y1 = (unsigned)(b.y0 + 1) < (unsigned)Hin;
+  bool x0 = (unsigned)b.x0 < (unsigned)Win, x1 = (unsigned)(b.x0 + 1) < (unsigned)Win;
+  if (y0 && x0) v += (p[b.y0 * Win + b.x0] + eps) * b.wnw;
+  if (y0 && x1) v += (p[b.y0 * Win + b.x0 + 1] + eps) * b.wne;
+  if (y1 && x0) v += (p[(b.y0 + 1) * Win + b.x0] + eps) * b.wsw;
+  if (y1 && x1) v += (p[(b.y0 + 1) * Win + b.x0 + 1] + eps) * b.wse;
+  return v;
+}
+
+// grid (Fout, B), block over t
+__global__ __launch_bounds__(256) void prepare_kernel(const float* __restrict__ mag_mix, const float* __restrict__ mags,
+                                                      int S, int B, int Fin, int T, int Fout, int warp, int weighted,
+                                                      int binary, float* __restrict__ mix_w, float* __restrict__ mags_w,
+                                                      float* __restrict__ logm, float* __restrict__ weight,
+                                                      float* __restrict__ gt) {
+  const int f = blockIdx.x, b = blockIdx.y;
+  __shared__ float s_gy;
+  if (warp && threadIdx.x == 0) s_gy = warp_gy(f, Fout, 1);
+  __syncthreads();
+  const long long in_b = (long long)b * Fin * T, out_row = ((long long)b * Fout + f) * T;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    float mix, src[4];
+    if (warp) {
+      Bilin bl = grid_bilin((float)linspace_pm1(t, T), s_gy, Fin, T);
+      mix = sample_bilin(mag_mix + in_b, bl, Fin, T, 1e-10f);
+      for (int s = 0; s < S; ++s) src[s] = sample_bilin(mags + (long long)s * B * Fin * T + in_b, bl, Fin, T, 0.f);
+    } else {
+      mix = mag_mix[in_b + (long long)f * T + t] + 1e-10f;
+      for (int s = 0; s < S; ++s) src[s] = mags[(long long)s * B * Fin * T + in_b + (long long)f * T + t];
+    }
+    mix_w[out_row + t] = mix;
+    logm[out_row + t] = logf(mix);
+    weight[out_row + t] = weighted ? fminf(fmaxf(log1pf(mix), 1e-3f), 10.f) : 1.f;
+    for (int s = 0; s < S; ++s) {
+      long long o = (long long)s * B * Fout * T + out_row + t;
+      mags_w[o] = src[s];
+      gt[o] = binary ? (src[s] > 0.5f * mix ? 1.f : 0.f) : fminf(fmaxf(src[s] / mix, 0.f), 5.f);
+    }
+  }
+}
+
+extern "C" int avsep_prepare(const float* mag_mix, const float* mags, int32_t S, int32_t B, int32_t Fin, int32_t T,
+                             int32_t Fout, int32_t warp, int32_t weighted, int32_t binary, float* mag_mix_w,
+                             float* mags_w, float* log_mag_mix, float* weight, float* gt, avsep_stream_t stream) {
+  if (!mag_mix || !mags || !mag_mix_w || !mags_w || !log_mag_mix || !weight || !gt) return AVSEP_ERR_ARG;
+  if (S < 1 || S > 4 || B <= 0 || Fin <= 0 || T <= 0 || Fout <= 0 || B > 65535) return AVSEP_ERR_ARG;
+  if (!warp && Fout != Fin) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(prepare_kernel, dim3(Fout, B), dim3(256), 0, (hipStream_t)stream, mag_mix, mags, S, B, Fin, T, Fout,
+                     warp, weighted, binary, mag_mix_w, mags_w, log_mag_mix, weight, gt);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, int Hin, int Win, int Hout, int Wout,
+                                                   int warp, float* __restrict__ y) {
+  const int f = blockIdx.x, bc = blockIdx.y;
+  __shared__ float s_gy;
+  if (threadIdx.x == 0) s_gy = warp_gy(f, Hout, warp);
+  __syncthreads();
+  const float* p = x + (long long)bc * Hin * Win;
+  for (int t = threadIdx.x; t < Wout; t += 256) {
+    Bilin bl = grid_bilin((float)linspace_pm1(t, Wout), s_gy, Hin, Win);
+    y[((long long)bc * Hout + f) * Wout + t] = sample_bilin(p, bl, Hin, Win, 0.f);
+  }
+}
+
+extern "C" int avsep_warp(const float* x, int32_t BC, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t warp,
+                          float* y, avsep_stream_t stream) {
+  if (!x || !y || BC <= 0 || BC > 65535 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(warp_kernel, dim3(Hout, BC), dim3(256), 0, (hipStream_t)stream, x, Hin, Win, Hout, Wout, warp, y);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// ============================================================================
+// mask loss (activation + weighted BCE/L1/L2 + PIT matrix)
+// ============================================================================
+#define MAXS 4
+__device__ __forceinline__ void activate_vec(const float* l, float* p, int S, int act) {
+  if (act == AVSEP_ACT_SOFTMAX2) {
+    float m = l[0];
+    for (int s = 1; s < S; ++s) m = fmaxf(m, l[s]);
+    float z = 0.f;
+    for (int s = 0; s < S; ++s) { p[s] = expf(l[s] - m); z += p[s]; }
+    for (int s = 0; s < S; ++s) p[s] /= z;
+    return;
+  }
+  for (int s = 0; s < S; ++s) {
+    float v = l[s];
+    if (act == AVSEP_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    else if (act == AVSEP_ACT_TANH) v = tanhf(v);
+    else if (act == AVSEP_ACT_RELU) v = fmaxf(v, 0.f);
+    p[s] = v;
+  }
+}
+__device__ __forceinline__ float loss_elem(float p, float t, int loss) {
+  if (loss == 0) return -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(logf(1.f - p), -100.f));
+  float d = p - t;
+  return loss == 1 ? fabsf(d) : d * d;
+}
+__device__ __forceinline__ float loss_grad(float p, float t, int loss) {  // d loss / d p
+  if (loss == 0) return (p - t) / fmaxf((1.f - p) * p, 1e-12f);
+  float d = p - t;
+  return loss == 1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+}
+
+// grid (chunks, B)
+__global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ gt,
+                                                            const float* __restrict__ weight, long long wts, int B,
+                                                            int S, int FT, int act, int loss,
+                                                            float* __restrict__ pred, double* __restrict__ sums) {
+  const int b = blockIdx.y;
+  float acc[MAXS * MAXS];
+  for (int i = 0; i < MAXS * MAXS; ++i) acc[i] = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < FT; i += gridDim.x * 256) {
+    float l[MAXS], p[MAXS], t[MAXS];
+    for (int s = 0; s < S; ++s) {
+      l[s] = logits[((long long)b * S + s) * FT + i];
+      t[s] = gt[((long long)s * B + b) * FT + i];
+    }
+    activate_vec(l, p, S, act);
+    for (int s = 0; s < S; ++s) pred[((long long)b * S + s) * FT + i] = p[s];
+    for (int ti = 0; ti < S; ++ti) {
+      float w = weight ? weight[ti * wts + (long long)b * FT + i] : 1.f;
+      for (int pj = 0; pj < S; ++pj) acc[ti * MAXS + pj] += w * loss_elem(p[pj], t[ti], loss);
+    }
+  }
+  __shared__ double sh[4][MAXS * MAXS];
+  for (int k = 0; k < S * S; ++k) {
+    int ti = k / S, pj = k % S;
+    double d = wave_sum_d((double)acc[ti * MAXS + pj]);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x < S * S)
+    atomicAdd(&sums[(long long)b * S * S + threadIdx.x],
+              sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+extern "C" int avsep_mask_loss_fwd(const float* logits, const float* gt, const float* weight, int64_t w_target_stride,
+                                   int32_t B, int32_t S, int32_t FT, int32_t act, int32_t loss, float* pred,
+                                   double* sums, avsep_stream_t stream) {
+  if (!logits || !gt || !pred || !sums || B <= 0 || B > 65535 || S < 1 || S > MAXS || FT <= 0) return AVSEP_ERR_ARG;
+  if (loss < 0 || loss > 2) return AVSEP_ERR_ARG;
+  int gx = min(cdiv(FT, 1024), 64);
+  hipLaunchKernelGGL(mask_loss_fwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, logits, gt, weight,
+                     (long long)w_target_stride, B, S, FT, act, loss, pred, sums);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+__global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ gt,
+                                                            const float* __restrict__ weight, long long wts,
+                                                            const float* __restrict__ coef, int B, int S, int FT, int act,
+                                                            int loss, float* __restrict__ dlogits) {
+  const int b = blockIdx.y;
+  float cf[MAXS * MAXS];
+  for (int k = 0; k < S * S; ++k) cf[(k / S) * MAXS + (k % S)] = coef[(long long)b * S * S + k];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < FT; i += gridDim.x * 256) {
+    float l[MAXS], p[MAXS], t[MAXS], g[MAXS];
+    for (int s = 0; s < S; ++s) {
+      l[s] = logits[((long long)b * S + s) * FT + i];
+      t[s] = gt[((long long)s * B + b) * FT + i];
+    }
+    activate_vec(l, p, S, act);
+    float w[MAXS];
+    for (int ti = 0; ti < S; ++ti) w[ti] = weight ? weight[ti * wts + (long long)b * FT + i] : 1.f;
+    for (int pj = 0; pj < S; ++pj) {
+      float s = 0.f;
+      for (int ti = 0; ti < S; ++ti) {
+        float c = cf[ti * MAXS + pj];
+        if (c != 0.f) s += c * w[ti] * loss_grad(p[pj], t[ti], loss);
+      }
+      g[pj] = s;  // d total / d pred_j
+    }
+    if (act == AVSEP_ACT_SOFTMAX2) {
+      float dot = 0.f;
+      for (int s = 0; s < S; ++s) dot += g[s] * p[s];
+      for (int s = 0; s < S; ++s) dlogits[((long long)b * S + s) * FT + i] = p[s] * (g[s] - dot);
+    } else {
+      for (int s = 0; s < S; ++s) {
+        float d = 1.f;
+        if (act == AVSEP_ACT_SIGMOID) d = p[s] * (1.f - p[s]);
+        else if (act == AVSEP_ACT_TANH) d = 1.f - p[s] * p[s];
+        else if (act == AVSEP_ACT_RELU) d = l[s] > 0.f ? 1.f : 0.f;
+        dlogits[((long long)b * S + s) * FT + i] = g[s] * d;
+      }
+    }
+  }
+}
+
+extern "C" int avsep_mask_loss_bwd(const float* logits, const float* gt, const float* weight, int64_t w_target_stride,
+                                   const float* coef, int32_t B, int32_t S, int32_t FT, int32_t act, int32_t loss,
+                                   float* dlogits, avsep_stream_t stream) {
+  if (!logits || !gt || !coef || !dlogits || B <= 0 || B > 65535 || S < 1 || S > MAXS || FT <= 0) return AVSEP_ERR_ARG;
+  if (loss < 0 || loss > 2) return AVSEP_ERR_ARG;
+  int gx = min(cdiv(FT, 1024), 64);
+  hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, logits, gt, weight,
+                     (long long)w_target_stride, coef, B, S, FT, act, loss, dlogits);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// ============================================================================
+// pooling, temporal mean, SGD, synthesizer
+// ============================================================================
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int NC, int H, int W, int Ho, int Wo,
+                                                          float* __restrict__ y, int* __restrict__ idx) {
+  const long long total = (long long)NC * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho);
+    long long nc = i / ((long long)Wo * Ho);
+    const float* p = x + nc * H * W;
+    float best = -INFINITY;
+    int bi = -1;
+    for (int kh = 0; kh < 3; ++kh) {
+      int h = ho * 2 - 1 + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        int w = wo * 2 - 1 + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float v = p[h * W + w];
+        if (v > best || bi < 0) { best = v; bi = h * W + w; }
+      }
+    }
+    y[i] = best;
+    if (idx) idx[i] = bi;
+  }
+}
+extern "C" int avsep_maxpool3x3s2_fwd(const float* x, int32_t NC, int32_t H, int32_t W, float* y, int32_t* idx,
+                                      avsep_stream_t stream) {
+  if (!x || !y || NC <= 0 || H <= 0 || W <= 0) return AVSEP_ERR_ARG;
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  long long total = (long long)NC * Ho * Wo;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((int)min((total + 255) / 256, (long long)65536)), dim3(256), 0,
+                     (hipStream_t)stream, x, NC, H, W, Ho, Wo, y, idx);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// gather form: each input pixel collects from the <=4 windows that contain it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, int NC,
+                                                          int H, int W, int Ho, int Wo, float* __restrict__ dx) {
+  const long long total = (long long)NC * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int w = (int)(i % W), h = (int)((i / W) % H);
+    long long nc = i / ((long long)W * H);
+    int self = h * W + w;
+    float s = 0.f;
+    // window ho covers input rows 2ho-1..2ho+1  =>  h/2 <= ho <= (h+1)/2
+    for (int ho = h / 2; ho <= (h + 1) / 2 && ho < Ho; ++ho)
+      for (int wo = w / 2; wo <= (w + 1) / 2 && wo < Wo; ++wo) {
+        long long o = (nc * Ho + ho) * Wo + wo;
+        if (idx[o] == self) s += dy[o];
+      }
+    dx[i] = s;
+  }
+}
+extern "C" int avsep_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int32_t NC, int32_t H, int32_t W, float* dx,
+                                      avsep_stream_t stream) {
+  if (!dy || !idx || !dx || NC <= 0 || H <= 0 || W <= 0) return AVSEP_ERR_ARG;
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  long long total = (long long)NC * H * W;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((int)min((total + 255) / 256, (long long)65536)), dim3(256), 0,
+                     (hipStream_t)stream, dy, idx, NC, H, W, Ho, Wo, dx);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+__global__ __launch_bounds__(256) void temporal_mean_fwd_kernel(const float* __restrict__ x, int B, int T, long long CHW,
+                                                                float* __restrict__ y) {
+  const long long total = (long long)B * CHW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long b = i / CHW, r = i % CHW;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += x[(b * T + t) * CHW + r];
+    y[i] = s / (float)T;
+  }
+}
+extern "C" int avsep_temporal_mean_fwd(const float* x, int32_t B, int32_t T, int32_t CHW, float* y,
+                                       avsep_stream_t stream) {
+  if (!x || !y || B <= 0 || T <= 0 || CHW <= 0) return AVSEP_ERR_ARG;
+  long long total = (long long)B * CHW;
+  hipLaunchKernelGGL(temporal_mean_fwd_kernel, dim3((int)min((total + 255) / 256, (long long)65536)), dim3(256), 0,
+                     (hipStream_t)stream, x, B, T, (long long)CHW, y);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+__global__ __launch_bounds__(256) void temporal_mean_bwd_kernel(const float* __restrict__ dy, int B, int T, long long CHW,
+                                                                float* __restrict__ dx) {
+  const long long total = (long long)B * T * CHW;
+  const float inv = 1.f / (float)T;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long bt = i / CHW, r = i % CHW;
+    dx[i] = dy[(bt / T) * CHW + r] * inv;
+  }
+}
+extern "C" int avsep_temporal_mean_bwd(const float* dy, int32_t B, int32_t T, int32_t CHW, float* dx,
+                                       avsep_stream_t stream) {
+  if (!dy || !dx || B <= 0 || T <= 0 || CHW <= 0) return AVSEP_ERR_ARG;
+  long long total = (long long)B * T * CHW;
+  hipLaunchKernelGGL(temporal_mean_bwd_kernel, dim3((int)min((total + 255) / 256, (long long)65536)), dim3(256), 0,
+                     (hipStream_t)stream, dy, B, T, (long long)CHW, dx);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  size_t n, float lr, float mom, float wd, float gs, int first) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float pv = p[i];
+    float d = fmaf(wd, pv, g[i] * gs);
+    float b = first ? d : fmaf(mom, buf[i], d);
+    buf[i] = b;
+    p[i] = pv - lr * b;
+  }
+}
+extern "C" int avsep_sgd_momentum(float* p, const float* g, float* buf, size_t n, float lr, float momentum,
+                                  float weight_decay, float grad_scale, int32_t first, avsep_stream_t stream) {
+  if (!p || !g || !buf) return AVSEP_ERR_ARG;
+  if (n == 0) return AVSEP_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)min((n + 255) / 256, (size_t)16384)), dim3(256), 0, (hipStream_t)stream, p, g, buf,
+                     n, lr, momentum, weight_decay, grad_scale, first);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+__global__ __launch_bounds__(256) void innerprod_kernel(const float* __restrict__ img, const float* __restrict__ snd,
+                                                        const float* __restrict__ scale, const float* __restrict__ bias,
+                                                        int K, int HW, float* __restrict__ z) {
+  const int b = blockIdx.y;
+  extern __shared__ float s_w[];
+  for (int k = threadIdx.x; k < K; k += 256) s_w[k] = img[(long long)b * K + k] * (scale ? scale[k] : 1.f);
+  __syncthreads();
+  const float bs = bias ? bias[0] : 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(s_w[k], snd[((long long)b * K + k) * HW + i], s);
+    z[(long long)b * HW + i] = s + bs;
+  }
+}
+extern "C" int avsep_innerprod_fwd(const float* img, const float* snd, const float* scale, const float* bias, int32_t B,
+                                   int32_t K, int32_t HW, float* z, avsep_stream_t stream) {
+  if (!img || !snd || !z || B <= 0 || B > 65535 || K <= 0 || K > 8192 || HW <= 0) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(innerprod_kernel, dim3(min(cdiv(HW, 256), 256), B), dim3(256), K * sizeof(float), (hipStream_t)stream,
+                     img, snd, scale, bias, K, HW, z);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+extern "C" int avsep_version(void) { return 100; }
+extern "C" const char* avsep_arch(void) { return "gfx950"; }
+extern "C" const char* avsep_strerror(int code) {
+  switch (code) {
+    case AVSEP_OK: return "ok";
+    case AVSEP_ERR_ARG: return "invalid argument (shape, null pointer or unsupported geometry)";
+    case AVSEP_ERR_LAUNCH: return "kernel launch failed";
+    case AVSEP_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown error";
+  }
+}

@@ -1,0 +1,231 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of include/avsep.h).
+
+Only shape bookkeeping and output allocation happen here; all arithmetic is in
+libavsep_gfx950.so.  Tensors are dense fp32 NCHW on the current cuda device.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib
+from .lib import ConvDesc, CatDesc, call, ptr
+
+
+def _f32(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def out_size(h, k, s, p, d):
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+class Conv:
+    """Geometry + virtual-input description of one convolution call (avsep_conv_desc)."""
+
+    def __init__(self, x0, cout, k, stride, pad, dil=1, x1=None, sc0=None, sh0=None, act0=0,
+                 sc1=None, sh1=None, act1=0, up2x=False):
+        lib.require_gpu(x0)
+        N, C0, Hs, Ws = x0.shape
+        C1 = x1.shape[1] if x1 is not None else 0
+        H, W = (2 * Hs, 2 * Ws) if up2x else (Hs, Ws)
+        kh, kw = (k, k) if isinstance(k, int) else k
+        self.N, self.Cin, self.H, self.W, self.Cout = N, C0 + C1, H, W, cout
+        self.KH, self.KW = kh, kw
+        self.Ho, self.Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
+        self.keep = (x0, x1, sc0, sh0, sc1, sh1)
+        d = ConvDesc()
+        d.N, d.Cin, d.H, d.W, d.Cout, d.Ho, d.Wo = N, C0 + C1, H, W, cout, self.Ho, self.Wo
+        d.KH, d.KW, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
+        d.C0, d.act0, d.act1, d.up2x = C0, act0, act1, int(up2x)
+        d.x0, d.x1 = ptr(x0), ptr(x1)
+        d.scale0, d.shift0, d.scale1, d.shift1 = ptr(sc0), ptr(sh0), ptr(sc1), ptr(sh1)
+        self.d = d
+        self.ref = C.byref(d)
+        self.like = x0
+
+    def pack(self, w, mode):
+        n = lib.load().avsep_conv_packed_floats(self.ref, mode)
+        out = _f32((n,), w)
+        call("avsep_conv_pack_weights", self.ref, ptr(w), ptr(out), mode)
+        return out
+
+    def fwd(self, w_packed, bias=None, stats=None):
+        y = _f32((self.N, self.Cout, self.Ho, self.Wo), self.like)
+        call("avsep_conv2d_fwd", self.ref, ptr(w_packed), ptr(bias), ptr(y), ptr(stats))
+        return y
+
+    def dgrad(self, w_packed_d, dy):
+        dx = _f32((self.N, self.Cin, self.H, self.W), self.like)
+        call("avsep_conv2d_dgrad", self.ref, ptr(w_packed_d), ptr(dy), ptr(dx))
+        return dx
+
+    def wgrad(self, dy, want_bias=False):
+        dw = _f32((self.Cout, self.Cin, self.KH, self.KW), self.like)
+        db = _f32((self.Cout,), self.like) if want_bias else None
+        nbytes = lib.load().avsep_conv2d_wgrad_workspace_bytes(self.ref)
+        ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=self.like.device)
+        call("avsep_conv2d_wgrad", self.ref, ptr(dy), ptr(dw), ptr(db), ptr(ws), nbytes)
+        return dw, db
+
+
+def zeros_stats(c, like):
+    return torch.zeros((2 * c,), dtype=torch.float64, device=like.device)
+
+
+def channel_stats(x, stats):
+    N, Cc = x.shape[:2]
+    call("avsep_channel_stats", ptr(x), N, Cc, x.numel() // (N * Cc), ptr(stats))
+
+
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, like):
+    Cc = gamma.numel()
+    out = _f32((4, Cc), like)  # scale, shift, mean, invstd
+    call("avsep_bn_finalize", ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+         float(momentum), float(eps), Cc, int(training), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]))
+    return out
+
+
+def bn_bwd_coeffs(bstats, count, gamma, mean, invstd):
+    Cc = gamma.numel()
+    dgamma, dbeta, pqr = _f32((Cc,), gamma), _f32((Cc,), gamma), _f32((3, Cc), gamma)
+    call("avsep_bn_bwd_coeffs", ptr(bstats), float(count), ptr(gamma), ptr(mean), ptr(invstd), Cc,
+         ptr(dgamma), ptr(dbeta), ptr(pqr))
+    return dgamma, dbeta, pqr
+
+
+def bn_bwd_apply_(dz, y, pqr):
+    N, Cc = y.shape[:2]
+    call("avsep_bn_bwd_apply", ptr(dz), ptr(y), ptr(pqr), N, Cc, y.numel() // (N * Cc), ptr(dz))
+    return dz
+
+
+def affine_act(y, scale, shift, residual, act):
+    N, Cc = y.shape[:2]
+    z = torch.empty_like(y)
+    call("avsep_affine_act", ptr(y), ptr(scale), ptr(shift), ptr(residual), act, N, Cc,
+         y.numel() // (N * Cc), ptr(z))
+    return z
+
+
+def affine_act_bwd_(dz, y, scale, shift, residual, add, mean, invstd, act, bstats):
+    """In place on dz: dz <- act'(scale*y+shift[+res]) * dz (+ add); accumulates bstats."""
+    N, Cc = y.shape[:2]
+    call("avsep_affine_act_bwd", ptr(dz), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(add),
+         ptr(mean), ptr(invstd), act, N, Cc, y.numel() // (N * Cc), ptr(dz), ptr(bstats))
+    return dz
+
+
+class Cat:
+    def __init__(self, x0, x1, sc0=None, sh0=None, sc1=None, sh1=None, bcast0=False, hw=None):
+        N, C0 = x0.shape[:2]
+        C1 = x1.shape[1]
+        H, W = hw if hw is not None else x1.shape[2:]
+        self.shape = (N, C0, C1, H, W)
+        self.keep = (x0, x1, sc0, sh0, sc1, sh1)
+        d = CatDesc()
+        d.N, d.C0, d.C1, d.H, d.W, d.bcast0, d.bcast1 = N, C0, C1, H, W, int(bcast0), 0
+        d.x0, d.x1 = ptr(x0), ptr(x1)
+        d.scale0, d.shift0, d.scale1, d.shift1 = ptr(sc0), ptr(sh0), ptr(sc1), ptr(sh1)
+        self.d, self.ref, self.like, self.bcast0 = d, C.byref(d), x1, bcast0
+
+    def fwd(self):
+        N, C0, C1, H, W = self.shape
+        out = _f32((N, C0 + C1, 2 * H, 2 * W), self.like)
+        call("avsep_relu_up2x_fwd", self.ref, ptr(out))
+        return out
+
+    def bwd(self, dout, mean1=None, invstd1=None, bstats1=None):
+        N, C0, C1, H, W = self.shape
+        g0 = _f32((N, C0) if self.bcast0 else (N, C0, H, W), self.like)
+        g1 = _f32((N, C1, H, W), self.like)
+        call("avsep_relu_up2x_bwd", self.ref, ptr(dout), ptr(g0), ptr(g1), ptr(mean1), ptr(invstd1),
+             ptr(bstats1), 0)
+        return g0, g1
+
+
+def prepare(mag_mix, mags, log_freq, weighted, binary, fout=256):
+    """mag_mix [B,1,F,T]; mags [S,B,1,F,T] (one buffer).  Returns mix_w, mags_w, log, weight, gt."""
+    lib.require_gpu(mag_mix)
+    S, B, _, Fin, T = mags.shape
+    Fo = fout if log_freq else Fin
+    mix_w, logm, weight = (_f32((B, 1, Fo, T), mag_mix) for _ in range(3))
+    mags_w, gt = _f32((S, B, 1, Fo, T), mag_mix), _f32((S, B, 1, Fo, T), mag_mix)
+    call("avsep_prepare", ptr(mag_mix), ptr(mags), S, B, Fin, T, Fo, int(bool(log_freq)), int(bool(weighted)),
+         int(bool(binary)), ptr(mix_w), ptr(mags_w), ptr(logm), ptr(weight), ptr(gt))
+    return mix_w, mags_w, logm, weight, gt
+
+
+def warp(x, hout, wout, warp_flag):
+    B, Cc, Hin, Win = x.shape
+    y = _f32((B, Cc, hout, wout), x)
+    call("avsep_warp", ptr(x), B * Cc, Hin, Win, hout, wout, int(warp_flag), ptr(y))
+    return y
+
+
+def sgd_momentum_(p, g, buf, lr, momentum, weight_decay, grad_scale, first):
+    call("avsep_sgd_momentum", ptr(p), ptr(g), ptr(buf), p.numel(), float(lr), float(momentum),
+         float(weight_decay), float(grad_scale), int(first))
+
+
+def temporal_mean(x, B, T):
+    chw = x.numel() // (B * T)
+    y = _f32((B,) + tuple(x.shape[1:]), x)
+    call("avsep_temporal_mean_fwd", ptr(x), B, T, chw, ptr(y))
+    return y
+
+
+def temporal_mean_bwd(dy, B, T):
+    chw = dy.numel() // B
+    dx = _f32((B * T,) + tuple(dy.shape[1:]), dy)
+    call("avsep_temporal_mean_bwd", ptr(dy), B, T, chw, ptr(dx))
+    return dx
+
+
+def maxpool3x3s2(x):
+    N, Cc, H, W = x.shape
+    Ho, Wo = out_size(H, 3, 2, 1, 1), out_size(W, 3, 2, 1, 1)
+    y = _f32((N, Cc, Ho, Wo), x)
+    idx = torch.empty((N, Cc, Ho, Wo), dtype=torch.int32, device=x.device)
+    call("avsep_maxpool3x3s2_fwd", ptr(x), N * Cc, H, W, ptr(y), ptr(idx))
+    return y, idx
+
+
+def maxpool3x3s2_bwd(dy, idx, H, W):
+    N, Cc = dy.shape[:2]
+    dx = _f32((N, Cc, H, W), dy)
+    call("avsep_maxpool3x3s2_bwd", ptr(dy), ptr(idx), N * Cc, H, W, ptr(dx))
+    return dx
+
+
+class Stft:
+    """librosa-style STFT/iSTFT plan (bases built once on the device)."""
+
+    def __init__(self, device, n_fft=1022, hop=256, pad_mode="reflect"):
+        self.n_fft, self.hop, self.reflect = n_fft, hop, int(pad_mode == "reflect")
+        L = lib.load()
+        with torch.cuda.device(device):
+            self.fwd_basis = torch.empty((L.avsep_stft_basis_floats(n_fft, 0),), dtype=torch.float32, device=device)
+            self.inv_basis = torch.empty((L.avsep_stft_basis_floats(n_fft, 1),), dtype=torch.float32, device=device)
+            call("avsep_stft_basis", n_fft, ptr(self.fwd_basis), ptr(self.inv_basis))
+
+    def stft(self, wav, want_phase=True):
+        """wav [R,L] -> mag, phase [R, n_fft/2+1, 1+L//hop]."""
+        R, Ln = wav.shape
+        bins, frames = self.n_fft // 2 + 1, 1 + Ln // self.hop
+        nbytes = lib.load().avsep_stft_workspace_bytes(R, Ln, self.n_fft, self.hop)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=wav.device)
+        mag = _f32((R, bins, frames), wav)
+        phase = _f32((R, bins, frames), wav) if want_phase else None
+        call("avsep_stft_mag", ptr(wav), R, Ln, self.n_fft, self.hop, self.reflect, ptr(self.fwd_basis), ptr(mag),
+             ptr(phase), ptr(ws), nbytes)
+        return mag, phase
+
+    def istft(self, mag, phase):
+        R, bins, frames = mag.shape
+        out_len = self.hop * (frames - 1)
+        nbytes = lib.load().avsep_istft_workspace_bytes(R, self.n_fft, frames)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=mag.device)
+        wav = _f32((R, out_len), mag)
+        call("avsep_istft", ptr(mag), ptr(phase), R, self.n_fft, self.hop, frames, ptr(self.inv_basis), ptr(wav),
+             out_len, ptr(ws), nbytes)
+        return wav

@@ -1,0 +1,122 @@
+"""ctypes binding of libavsep_gfx950.so (the C ABI declared in include/avsep.h).
+
+There is deliberately no fallback: if the shared library is missing or a call
+returns an error, this raises.  PyTorch is used only for device memory and
+streams; every pointer handed over is ``tensor.data_ptr()``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavsep_gfx950.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SIGMOID, ACT_TANH, ACT_SOFTMAX2 = range(6)
+ACT_BY_NAME = {"no": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH,
+               "softmax": ACT_SOFTMAX2}
+LOSS_BY_NAME = {"bce": 0, "l1": 1, "l2": 2}
+
+
+class AvsepError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                "N Cin H W Cout Ho Wo KH KW stride pad dil C0 act0 act1 up2x".split()] + \
+               [(n, C.c_void_p) for n in "x0 x1 scale0 shift0 scale1 shift1".split()]
+
+
+class CatDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in "N C0 C1 H W bcast0 bcast1".split()] + \
+               [(n, C.c_void_p) for n in "x0 x1 scale0 shift0 scale1 shift1".split()]
+
+
+_P, _I, _F, _D, _Z = C.c_void_p, C.c_int32, C.c_float, C.c_double, C.c_size_t
+_CD, _KD = C.POINTER(ConvDesc), C.POINTER(CatDesc)
+
+# name -> (restype, argtypes); one entry per prototype in include/avsep.h
+SIGNATURES = {
+    "avsep_version": (C.c_int, []),
+    "avsep_arch": (C.c_char_p, []),
+    "avsep_strerror": (C.c_char_p, [C.c_int]),
+    "avsep_conv_packed_floats": (_Z, [_CD, C.c_int]),
+    "avsep_conv_pack_weights": (C.c_int, [_CD, _P, _P, C.c_int, _P]),
+    "avsep_conv2d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P]),
+    "avsep_conv2d_dgrad": (C.c_int, [_CD, _P, _P, _P, _P]),
+    "avsep_conv2d_wgrad_workspace_bytes": (_Z, [_CD]),
+    "avsep_conv2d_wgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
+    "avsep_channel_stats": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "avsep_bn_finalize": (C.c_int, [_P, _D, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P]),
+    "avsep_bn_bwd_coeffs": (C.c_int, [_P, _D, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "avsep_bn_bwd_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "avsep_affine_act": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "avsep_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_relu_up2x_fwd": (C.c_int, [_KD, _P, _P]),
+    "avsep_relu_up2x_bwd": (C.c_int, [_KD, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "avsep_prepare": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "avsep_warp": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "avsep_fusion_av_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "avsep_fusion_av_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F,
+                                      _P, _P, _P, _P]),
+    "avsep_fusion_ao_fwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_fusion_ao_bwd": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "avsep_mask_loss_fwd": (C.c_int, [_P, _P, _P, C.c_int64, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_mask_loss_bwd": (C.c_int, [_P, _P, _P, C.c_int64, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "avsep_stft_basis_floats": (_Z, [_I, _I]),
+    "avsep_stft_basis": (C.c_int, [_I, _P, _P, _P]),
+    "avsep_stft_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "avsep_stft_mag": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    "avsep_istft_workspace_bytes": (_Z, [_I, _I, _I]),
+    "avsep_istft": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
+    "avsep_maxpool3x3s2_fwd": (C.c_int, [_P, _I, _I, _I, _P, _P, _P]),
+    "avsep_maxpool3x3s2_bwd": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
+    "avsep_temporal_mean_fwd": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "avsep_temporal_mean_bwd": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "avsep_sgd_momentum": (C.c_int, [_P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
+    "avsep_innerprod_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises AvsepError when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AvsepError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the HIP path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_contiguous(), "avsep kernels take dense tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point on the current stream; raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise AvsepError(f"{name} failed: {lib.avsep_strerror(rc).decode()} ({rc})")
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise AvsepError("the HIP path needs tensors on an MI355X (cuda) device; there is no CPU fallback")

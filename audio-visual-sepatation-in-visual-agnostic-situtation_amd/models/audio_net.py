@@ -1,0 +1,295 @@
+"""Audio U-Net on the HIP kernels (drop-in for the reference's models/audio_net.py:10-203).
+
+Same constructor, same ``forward(x, v) -> (feat, (match_loss, att_maps))`` contract and the
+same ``state_dict`` key names (``bn0.*``, ``unet_block[.mid_forward]^k.down_forward.{0|1}.weight``,
+``...down_forward.2.*``, ``...up_forward.2.*``, ``...up_forward.3.*``).  The whole network is ONE
+autograd node: forward and backward are explicit launch sequences over libavsep_gfx950.so
+(implicit-GEMM convolutions with BatchNorm/LeakyReLU/ReLU/concat folded into their operand
+gathers and BN statistics into their epilogues), not a graph of torch operators.
+
+Reference quirks reproduced: the skip tensor is the LeakyReLU'd block
+input (in-place aliasing, audio_net.py:64,119-122) so the decoder sees ReLU(z); there is no
+BatchNorm after the innermost down conv nor around the outermost block; the fusion sits between
+the innermost down and up convs.
+"""
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from .. import lib
+from ..lib import ACT_LRELU02, ACT_NONE, ACT_RELU
+from . import fusion_net
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+class _Slots(nn.Module):
+    def put(self, idx, mod):
+        self.add_module(str(idx), mod)
+        return mod
+
+    def at(self, idx):
+        return getattr(self, str(idx))
+
+
+class Conv2dParams(nn.Module):
+    """Parameter holder (class name contains 'Conv' so the reference-style weights_init applies)."""
+
+    def __init__(self, cin, cout, k, bias):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        self.kernel_size, self.in_channels, self.out_channels = (k, k), cin, cout
+        # nn.Conv2d default init (kaiming_uniform a=sqrt(5)); ModelBuilder.weights_init overrides it
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if bias:
+            bound = 1.0 / (cin * k * k) ** 0.5
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class BatchNorm2dParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.num_features = c
+
+
+class _Level(nn.Module):
+    def __init__(self, outer_nc, inner_nc, in_nc, up_in_nc, kind, child):
+        super().__init__()
+        self.kind = kind
+        self.down_forward = _Slots()
+        if child is not None:
+            self.mid_forward = child
+        self.up_forward = _Slots()
+        self.down_conv = self.down_forward.put(0 if kind == "outer" else 1, Conv2dParams(in_nc, inner_nc, 4, False))
+        self.down_bn = self.down_forward.put(2, BatchNorm2dParams(inner_nc)) if kind == "mid" else None
+        self.up_conv = self.up_forward.put(2, Conv2dParams(up_in_nc, outer_nc, 3, kind == "outer"))
+        self.up_bn = self.up_forward.put(3, BatchNorm2dParams(outer_nc)) if kind != "outer" else None
+
+    # the aliases above are plain attributes, not extra registrations
+    def __setattr__(self, name, value):
+        if name in ("down_conv", "down_bn", "up_conv", "up_bn"):
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
+
+class Unet(nn.Module):
+    def __init__(self, fc_dim=64, num_downs=5, ngf=64, use_dropout=False, fusion_type="con_motion",
+                 att_type="cos", fuse_upsample=True):
+        super().__init__()
+        if use_dropout:
+            raise NotImplementedError("use_dropout is never enabled by the reference builders")
+        self.fusion = fusion_net.get_fusion_net(fusion_type)(att_type=att_type)
+        self.fusion_type, self.att_type = fusion_type, att_type
+        self.fuse_upsample = fuse_upsample
+        lvl = _Level(ngf * 8, ngf * 8, ngf * 8, ngf * 16, "inner", None)
+        for _ in range(num_downs - 5):
+            lvl = _Level(ngf * 8, ngf * 8, ngf * 8, ngf * 16, "mid", lvl)
+        lvl = _Level(ngf * 4, ngf * 8, ngf * 4, ngf * 16, "mid", lvl)
+        lvl = _Level(ngf * 2, ngf * 4, ngf * 2, ngf * 8, "mid", lvl)
+        lvl = _Level(ngf, ngf * 2, ngf, ngf * 4, "mid", lvl)
+        lvl = _Level(fc_dim, ngf, 1, ngf * 2, "outer", lvl)
+        self.bn0 = BatchNorm2dParams(1)
+        self.unet_block = lvl
+        self.ao_draws = None  # tests may pin the audio-only random swap
+
+    # the fusion module is parameter free and must not add state_dict keys
+    def __setattr__(self, name, value):
+        if name == "fusion":
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
+    def levels(self):
+        out, l = [], self.unet_block
+        while True:
+            out.append(l)
+            if l.kind == "inner":
+                return out
+            l = l.mid_forward
+
+    def param_list(self):
+        """Flat, fixed order of every trainable tensor (the argument order of the autograd node)."""
+        ps = [self.bn0.weight, self.bn0.bias]
+        for l in self.levels():
+            ps.append(l.down_conv.weight)
+            if l.down_bn is not None:
+                ps += [l.down_bn.weight, l.down_bn.bias]
+            ps.append(l.up_conv.weight)
+            if l.up_conv.bias is not None:
+                ps.append(l.up_conv.bias)
+            if l.up_bn is not None:
+                ps += [l.up_bn.weight, l.up_bn.bias]
+        return ps
+
+    def forward(self, x, v=None):
+        lib.require_gpu(x)
+        B = x.shape[0]
+        draws = None
+        if v is None:
+            draws = self.ao_draws if self.ao_draws is not None else (torch.rand(B) > 0.5)
+            vs = []
+        else:
+            vs = [t.contiguous().float() for t in v]
+        out = _UnetFn.apply(self, draws, len(vs), x.contiguous().float(), *vs, *self.param_list())
+        feat, match_loss, att_maps = out
+        if v is None:
+            return feat, (None, None)
+        return feat, (match_loss, att_maps)
+
+
+def _bn_run(bn, stats, count, training, like):
+    """scale/shift/mean/invstd rows for one BatchNorm; updates the running buffers in training."""
+    out = K.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                        BN_MOMENTUM, BN_EPS, training, like)
+    if training:
+        bn.num_batches_tracked += 1
+    return out
+
+
+class _UnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, draws, nv, x, *rest):
+        vs, training = list(rest[:nv]), net.training
+        lv = net.levels()
+        L = len(lv)
+        B, _, H, W = x.shape
+        S = {"x": x, "vs": vs, "lv": lv}
+
+        # bn0 over the whole tile (audio_net.py:37,41)
+        st0 = K.zeros_stats(1, x)
+        if training:
+            K.channel_stats(x, st0)
+        S["bn0"] = _bn_run(net.bn0, st0, B * H * W, training, x)
+
+        # ---- encoder: conv k4 s2 p1, input = LeakyReLU(BN(prev)) folded into the gather ----
+        src, aff, act = x, S["bn0"], ACT_NONE
+        S["dconv"], S["yd"], S["dbn"] = [], [], []
+        for i, l in enumerate(lv):
+            w = l.down_conv.weight.detach()
+            cv = K.Conv(src, w.shape[0], 4, 2, 1, sc0=aff[0] if aff is not None else None,
+                        sh0=aff[1] if aff is not None else None, act0=act)
+            st = K.zeros_stats(w.shape[0], x) if (l.down_bn is not None and training) else None
+            y = cv.fwd(cv.pack(w, 0), None, st)
+            bn = None
+            if l.down_bn is not None:
+                bn = _bn_run(l.down_bn, st, y.numel() // y.shape[1], training, x)
+            S["dconv"].append(cv); S["yd"].append(y); S["dbn"].append(bn)
+            src, aff, act = y, bn, ACT_LRELU02
+
+        # ---- bottleneck fusion (models/fusion_net.py) ----
+        ybot = S["yd"][-1]
+        fus = net.fusion.run_forward(ybot, vs, draws)
+        S["fus"] = fus
+        feat_vec = fus["feat"]                                   # [B, D] broadcast vectors
+
+        # ---- decoder: ReLU + bilinear x2 + conv k3 p1 over concat(skip, inner) ----
+        S["uconv"], S["yu"], S["ubn"], S["cat"], S["U"] = [None] * L, [None] * L, [None] * L, [None] * L, [None] * L
+        for i in range(L - 1, -1, -1):
+            l = lv[i]
+            w = l.up_conv.weight.detach()
+            if i == L - 1:
+                cat = K.Cat(feat_vec, ybot, bcast0=True)
+                fused = False
+            else:
+                dbn, ubn = S["dbn"][i], S["ubn"][i + 1]
+                cat = K.Cat(S["yd"][i], S["yu"][i + 1], sc0=dbn[0] if dbn is not None else None,
+                            sh0=dbn[1] if dbn is not None else None, sc1=ubn[0], sh1=ubn[1])
+                fused = net.fuse_upsample
+            if fused:   # upsample folded into the conv's operand gather: nothing materialised
+                cv = K.Conv(cat.keep[0], w.shape[0], 3, 1, 1, x1=cat.keep[1], sc0=cat.keep[2], sh0=cat.keep[3],
+                            act0=ACT_RELU, sc1=cat.keep[4], sh1=cat.keep[5], act1=ACT_RELU, up2x=True)
+            else:
+                U = cat.fwd()
+                S["U"][i] = U
+                cv = K.Conv(U, w.shape[0], 3, 1, 1)
+            st = K.zeros_stats(w.shape[0], x) if (l.up_bn is not None and training) else None
+            bias = l.up_conv.bias.detach() if l.up_conv.bias is not None else None
+            y = cv.fwd(cv.pack(w, 0), bias, st)
+            bn = _bn_run(l.up_bn, st, y.numel() // y.shape[1], training, x) if l.up_bn is not None else None
+            S["uconv"][i], S["yu"][i], S["ubn"][i], S["cat"][i] = cv, y, bn, cat
+
+        ctx.S, ctx.net, ctx.nv, ctx.training = S, net, nv, training
+        logits = S["yu"][0]
+        if nv:
+            match = fus["match_part"].mean()
+            att = fus["att_maps"]
+        else:
+            match = x.new_zeros(())
+            att = x.new_zeros(())
+        ctx.mark_non_differentiable(att)
+        return logits, match, att
+
+    @staticmethod
+    def backward(ctx, dlogits, dmatch, _datt):
+        S, net, nv = ctx.S, ctx.net, ctx.nv
+        if not ctx.training:
+            raise lib.AvsepError("backward through the U-Net needs train mode (batch statistics)")
+        lv = S["lv"]
+        L = len(lv)
+        x = S["x"]
+        grads = {}
+
+        def bn_back(bn_mod, bnrow, bstats, count):
+            dgamma, dbeta, pqr = K.bn_bwd_coeffs(bstats, count, bn_mod.weight.detach(), bnrow[2], bnrow[3])
+            grads[bn_mod.weight], grads[bn_mod.bias] = dgamma, dbeta
+            return pqr
+
+        # ---- decoder backward, outermost -> innermost ----
+        g = dlogits.contiguous()
+        Gd = [None] * L          # gradient reaching zd[i] through the skip path (already ReLU-masked)
+        dfeat = dbot = None
+        for i in range(L):
+            l, cv, cat = lv[i], S["uconv"][i], S["cat"][i]
+            w = l.up_conv.weight.detach()
+            dw, db = cv.wgrad(g, want_bias=l.up_conv.bias is not None)
+            grads[l.up_conv.weight] = dw
+            if db is not None:
+                grads[l.up_conv.bias] = db
+            dU = cv.dgrad(cv.pack(w, 1), g)                    # wrt the (virtual) upsampled input
+            if i == L - 1:
+                dfeat, dbot = cat.bwd(dU)
+            else:
+                ubn = S["ubn"][i + 1]
+                bst = K.zeros_stats(ubn.shape[1], x)
+                Gd[i], dz = cat.bwd(dU, mean1=ubn[2], invstd1=ubn[3], bstats1=bst)
+                yu = S["yu"][i + 1]
+                pqr = bn_back(lv[i + 1].up_bn, ubn, bst, yu.numel() // yu.shape[1])
+                g = K.bn_bwd_apply_(dz, yu, pqr)
+            del dU
+
+        # ---- fusion backward: adds into dbot, returns the visual-feature gradients ----
+        dvs = net.fusion.run_backward(S["yd"][-1], S["vs"], S["fus"], dfeat, dbot, None, dmatch if nv else None)
+
+        # ---- encoder backward, innermost -> outermost ----
+        g = dbot
+        for i in range(L - 1, -1, -1):
+            l, cv = lv[i], S["dconv"][i]
+            w = l.down_conv.weight.detach()
+            grads[l.down_conv.weight], _ = cv.wgrad(g)
+            dS = cv.dgrad(cv.pack(w, 1), g)                   # wrt act(BN(prev)) (or BN0(x) for i == 0)
+            if i > 0:
+                yprev, bn = S["yd"][i - 1], S["dbn"][i - 1]
+                bst = K.zeros_stats(yprev.shape[1], x) if bn is not None else None
+                K.affine_act_bwd_(dS, yprev, bn[0] if bn is not None else None, bn[1] if bn is not None else None,
+                                  None, Gd[i - 1], bn[2] if bn is not None else None,
+                                  bn[3] if bn is not None else None, ACT_LRELU02, bst)
+                if bn is not None:
+                    pqr = bn_back(lv[i - 1].down_bn, bn, bst, yprev.numel() // yprev.shape[1])
+                    g = K.bn_bwd_apply_(dS, yprev, pqr)
+                else:
+                    g = dS
+            else:
+                bn0 = S["bn0"]
+                bst = K.zeros_stats(1, x)
+                K.affine_act_bwd_(dS, x, None, None, None, None, bn0[2], bn0[3], ACT_NONE, bst)
+                bn_back(net.bn0, bn0, bst, x.numel())
+        ctx.S = None
+        plist = net.param_list()
+        return (None, None, None, None, *dvs, *[grads.get(p) for p in plist])

@@ -1,0 +1,141 @@
+"""Bottleneck audio-visual fusion on the HIP kernels (reference: models/fusion_net.py:7-311).
+
+``get_fusion_net(mtype)`` keeps the reference's switch (``hidsep`` -> CoLoc, ``CoLoc_Sel``,
+``MixVis``; anything else asserts).  Each class is parameter free.  ``run_forward`` /
+``run_backward`` are what the U-Net autograd node calls; ``forward(x, v_ls)`` is the standalone
+module interface ``(cat(tiles, x), (match_loss, att_maps))`` of the reference.
+"""
+import torch
+import torch.nn as nn
+
+from .. import lib
+from ..lib import call, ptr
+
+_KIND = {"hidsep": 0, "CoLoc_Sel": 1, "MixVis": 2}
+_ATT = {"cos": 0, "sig": 1}
+
+
+class _FusionBase(nn.Module):
+    kind_name = "hidsep"
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.att_type = kwargs.get("att_type", "cos")
+        if self.att_type not in _ATT:
+            raise ValueError(f"att_type {self.att_type!r}")
+        self.kind = _KIND[self.kind_name]
+        self.ao_draws = None
+
+    # ------------------------------------------------------------------ kernels
+    def run_forward(self, x, vs, draws):
+        """x [B,D,F,T] bottleneck; vs list of visual maps or [] for audio-only."""
+        B, D, Fq, T = x.shape
+        Dc, FT = D // 2, Fq * T
+        dev = x.device
+        out = {"feat": torch.empty((B, D), dtype=torch.float32, device=dev),
+               "pool_idx": torch.empty((B, D), dtype=torch.int32, device=dev)}
+        if not vs:
+            d8 = draws.to(torch.uint8)
+            all_zero = int(int(d8.max()) == 0)  # one_hot width quirk, fusion_net.py:96 (draws live on the host)
+            out["draws"], out["all_zero"] = d8.to(dev), all_zero
+            call("avsep_fusion_ao_fwd", ptr(x), ptr(out["draws"]), all_zero, B, Dc, FT, ptr(out["feat"]),
+                 ptr(out["pool_idx"]))
+            return out
+        if self.kind == 2:
+            raise lib.AvsepError("MixVis fusion is not built on the HIP path yet")
+        if len(vs) != 2:
+            raise AssertionError("CoLoc fusion takes one visual map per source (C = 2)")
+        H, W = vs[0].shape[-2:]
+        HW = H * W
+        if vs[0].shape[1] != Dc:
+            raise lib.AvsepError(f"visual channels {vs[0].shape[1]} != bottleneck/2 = {Dc}")
+        out.update(a_pool=torch.empty((B, D), dtype=torch.float32, device=dev),
+                   sel_idx=torch.empty((B, D), dtype=torch.int32, device=dev),
+                   att_maps=torch.empty((B, 2, H, W), dtype=torch.float32, device=dev),
+                   match_part=torch.empty((B,), dtype=torch.float32, device=dev),
+                   best=torch.empty((B,), dtype=torch.int32, device=dev), HW=HW)
+        call("avsep_fusion_av_fwd", ptr(x), ptr(vs[0]), ptr(vs[1]), B, Dc, FT, HW, self.kind, _ATT[self.att_type],
+             ptr(out["a_pool"]), ptr(out["pool_idx"]), ptr(out["feat"]), ptr(out["sel_idx"]), ptr(out["att_maps"]),
+             ptr(out["match_part"]), ptr(out["best"]))
+        return out
+
+    def run_backward(self, x, vs, fus, dfeat, dx_accum, _unused, dmatch):
+        """Adds the gradient wrt x into dx_accum; returns the visual-map gradients."""
+        B, D, Fq, T = x.shape
+        Dc, FT = D // 2, Fq * T
+        if not vs:
+            call("avsep_fusion_ao_bwd", ptr(fus["draws"]), fus["all_zero"], B, Dc, FT, ptr(fus["pool_idx"]),
+                 ptr(dfeat), ptr(dx_accum))
+            return []
+        dvs = [torch.empty_like(v) for v in vs]
+        dm = None
+        if dmatch is not None:
+            dm = dmatch.reshape(1).contiguous().float()
+        call("avsep_fusion_av_bwd", ptr(x), ptr(vs[0]), ptr(vs[1]), B, Dc, FT, fus["HW"], self.kind,
+             _ATT[self.att_type], ptr(fus["a_pool"]), ptr(fus["pool_idx"]), ptr(fus["sel_idx"]),
+             ptr(fus["att_maps"]), ptr(fus["best"]), ptr(dfeat), None, ptr(dm), 1.0 / B if dm is not None else 0.0,
+             ptr(dx_accum), ptr(dvs[0]), ptr(dvs[1]))
+        return dvs
+
+    # ------------------------------------------------------------------ module interface
+    def forward(self, x, v_ls, option=None):
+        if option is not None:
+            raise NotImplementedError("option='duet' is unreachable from Unet in the reference")
+        lib.require_gpu(x)
+        if v_ls is None:
+            B = x.shape[0]
+            draws = self.ao_draws if self.ao_draws is not None else (torch.rand(B) > 0.5)
+            y, _m = _FusionFn.apply(self, draws, 0, x.contiguous())
+            return y, (None, None)
+        vs = [v.contiguous().float() for v in v_ls]
+        y, match, att = _FusionFn.apply(self, None, len(vs), x.contiguous(), *vs)
+        return y, (match, att)
+
+
+class _FusionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, draws, nv, x, *vs):
+        vs = list(vs)
+        fus = mod.run_forward(x, vs, draws)
+        B, D, Fq, T = x.shape
+        tiles = fus["feat"].reshape(B, D, 1, 1).expand(B, D, Fq, T)
+        y = torch.cat([tiles, x], 1)
+        ctx.mod, ctx.fus, ctx.nv = mod, fus, nv
+        ctx.save_for_backward(x, *vs)
+        if not nv:
+            return y, x.new_zeros(())
+        ctx.mark_non_differentiable(fus["att_maps"])
+        return y, fus["match_part"].mean(), fus["att_maps"]
+
+    @staticmethod
+    def backward(ctx, dy, dmatch, *_):
+        x, *vs = ctx.saved_tensors
+        B, D = x.shape[:2]
+        dy = dy.contiguous()
+        dfeat = dy[:, :D].sum(dim=(2, 3)).contiguous()
+        dx = dy[:, D:].contiguous().clone()
+        dvs = ctx.mod.run_backward(x, list(vs), ctx.fus, dfeat, dx, None, dmatch if ctx.nv else None)
+        return (None, None, None, dx, *dvs)
+
+
+class CoLoc(_FusionBase):
+    kind_name = "hidsep"
+
+
+class CoLoc_Sel(_FusionBase):
+    kind_name = "CoLoc_Sel"
+
+
+class MixVis(_FusionBase):
+    kind_name = "MixVis"
+
+
+def get_fusion_net(mtype):
+    if mtype == "hidsep":
+        return CoLoc
+    elif mtype == "CoLoc_Sel":
+        return CoLoc_Sel
+    elif mtype == "MixVis":
+        return MixVis
+    else:
+        assert False

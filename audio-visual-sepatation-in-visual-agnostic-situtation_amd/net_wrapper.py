@@ -1,0 +1,238 @@
+"""Step definition: NetWrapper / create_optimizer / train_step — the host-side mirror of the
+reference's main.py:39-192 and :536-569, on the HIP path.
+
+``NetWrapper(nets, crit_ao, crit_av).forward(batch_data, args, use_vis, is_share=False)``
+returns ``(err, outputs)`` with the reference's dictionary keys.  The batch contract is the
+reference loader's (dataset/music.py:275-331): ``mag_mix [B,1,512,256]``, ``mags`` list of N,
+``frames`` list of N ``[B,3,T,224,224]``; alternatively ``audios``/``audio_mix`` waveforms can be
+given and the STFT runs on the GPU (``attach_stft``).
+"""
+import torch
+
+from . import kernels as K
+from . import lib
+from .lib import ACT_BY_NAME
+from .models import activate
+from .models.criterion import PitWrapper, best_permutations, mask_loss
+
+args = None  # module-global like main.py's `args`, used by train_step when none is passed
+
+
+class NetWrapper(torch.nn.Module):
+    def __init__(self, nets, crit_ao, crit_av):
+        super().__init__()
+        if len(nets) != 2:
+            raise NotImplementedError("the 3-net form (net_motion, --load_clips) is out of scope")
+        self.net_sound, self.net_frame = nets
+        self.load_clips = False
+        self.crit_ao = crit_ao
+        self.crit_av = crit_av
+        self.stft_plan = None
+
+    # ------------------------------------------------------------------ main.py:51-95
+    def prepare(self, batch_data, args, use_vis=True, is_share=False):
+        mag_mix = batch_data["mag_mix"]
+        lib.require_gpu(mag_mix)
+        N = args.num_mix
+        mags_in = torch.stack([m.float() for m in batch_data["mags"][:N]], 0).contiguous()
+        mix_w, mags_w, log_mag_mix, weights, gt = K.prepare(
+            mag_mix.float().contiguous(), mags_in, args.log_freq, args.weighted_loss, args.binary_mask)
+        mags = [mags_w[n] for n in range(N)]
+        for n in range(N):                       # the reference replaces the entries in place (:66)
+            batch_data["mags"][n] = mags[n]
+        gt_masks = [gt[n] for n in range(N)]
+        self._gt_stack = gt                      # [N,B,1,F,T], one buffer for the fused loss
+        if use_vis or args.fusion_type == "share" or is_share:
+            return batch_data["frames"], None, mags, mix_w, log_mag_mix, gt_masks, weights
+        return mags, mix_w, log_mag_mix, gt_masks, weights
+
+    # ------------------------------------------------------------------ main.py:97-111
+    def forward_ao(self, data, args):
+        mags, mag_mix, log_mag_mix, gt_masks, weight = data
+        feat_sound, *_ = self.net_sound(log_mag_mix, None)
+        act = ACT_BY_NAME.get(args.output_activation)
+        if act is None:
+            raise Exception("Unkown activation!")
+        B = feat_sound.shape[0]
+        pred, sums, FT = mask_loss(feat_sound, self._gt_stack, weight, act, "bce")   # PIT always uses BCE
+        mat = sums / FT                                                              # [B,2,2] target x prediction
+        perms = best_permutations(mat.detach().cpu().numpy())
+        idx = torch.tensor(perms, device=mat.device)
+        err = torch.gather(mat, 2, idx[:, :, None]).squeeze(-1).mean(-1).mean().to(torch.float32)
+        pred_last = pred.permute(0, 2, 3, 1)                                          # B x F x T x C
+        ordered = PitWrapper.reorder_tensor(pred_last, perms)
+        gt = torch.stack(gt_masks, dim=-1)[:, 0]
+        w2 = torch.stack([weight[:, 0]] * 2, dim=-1)
+        return err, {"pred_masks": [ordered[..., i].unsqueeze(1) for i in range(2)],
+                     "gt_masks": [gt[..., i].unsqueeze(1) for i in range(2)],
+                     "mag_mix": mag_mix, "mags": mags, "weight": w2}
+
+    # ------------------------------------------------------------------ main.py:113-148
+    def forward_av(self, data, args):
+        N = args.num_mix
+        frames, _, mags, mag_mix, log_mag_mix, gt_masks, weight = data
+        feat_frames = [activate(self.net_frame.forward_multiframe(frames[n], pool=args.not_pool_vis),
+                                args.img_activation) for n in range(N)]
+        kind = getattr(self.crit_av, "kind", "bce")
+        act = ACT_BY_NAME.get(args.output_activation)
+        if act is None:
+            raise Exception("Unkown activation!")
+        fused = args.output_activation != "softmax"   # softmax over the singleton channel is identically 1 (:132)
+        gt_nat = self._gt_stack
+        errs, match_loss = [], 0
+        # pass 1: visual features in reversed order against reversed targets; pass 2: natural order
+        for reverse in (True, False):
+            vis_in = feat_frames[::-1] if reverse else feat_frames
+            feat_sound, meta = self.net_sound(log_mag_mix, vis_in)
+            if fused:
+                gt = gt_nat.flip(0).contiguous() if reverse else gt_nat
+                pred, sums, FT = mask_loss(feat_sound, gt, weight, act, kind)
+                B, S = feat_sound.shape[:2]
+                err = (torch.diagonal(sums, dim1=1, dim2=2).sum() / (B * S * FT)).to(torch.float32)
+                pred_masks = [pred[:, n].unsqueeze(1) for n in range(N)]
+            else:
+                pred_masks = [activate(feat_sound[:, n].unsqueeze(1), args.output_activation) for n in range(N)]
+                err = self.crit_av(pred_masks, gt_masks[::-1] if reverse else gt_masks, weight)
+            errs.append(err.reshape(1))
+            match_loss = match_loss + meta[0]
+        err = ((errs[0] + errs[1]) / 2 + args.match_weight * match_loss).reshape(1)
+        return err, {"pred_masks": pred_masks, "gt_masks": gt_masks, "mag_mix": mag_mix, "mags": mags,
+                     "weight": weight, "match_loss": match_loss.reshape(1), "att_maps": meta[1],
+                     "logits": feat_sound}
+
+    # ------------------------------------------------------------------ main.py:150-160
+    def forward(self, batch_data, args, use_vis, is_share=False):
+        if "mag_mix" not in batch_data:
+            self.attach_stft(batch_data, args)
+        data = self.prepare(batch_data, args, use_vis, is_share)
+        if use_vis:
+            if args.fusion_type == "MixVis":
+                raise lib.AvsepError("forward_avmiximg (MixVis) is not built on the HIP path yet")
+            return self.forward_av(data, args)
+        return self.forward_ao(data, args)
+
+    # ------------------------------------------------------------------ dataset/base.py:142-147,174-189 on the GPU
+    def attach_stft(self, batch_data, args):
+        """mag_mix / mags / phase_mix from the waveforms in the batch (N+1 STFTs per mixture)."""
+        wavs = [batch_data["audio_mix"]] + list(batch_data["audios"][:args.num_mix])
+        B, Ln = wavs[0].shape
+        if self.stft_plan is None:
+            self.stft_plan = K.Stft(wavs[0].device, args.stft_frame, args.stft_hop,
+                                    getattr(args, "stft_pad_mode", "reflect"))
+        rows = torch.cat([w.float() for w in wavs], 0).contiguous()             # [(1+N)*B, L]
+        mag, phase = self.stft_plan.stft(rows, want_phase=True)
+        mag = mag.view(len(wavs), B, 1, *mag.shape[1:])
+        batch_data["mag_mix"] = mag[0]
+        batch_data["mags"] = [mag[1 + n] for n in range(args.num_mix)]
+        batch_data["phase_mix"] = phase.view(len(wavs), B, 1, *phase.shape[1:])[0]
+        return batch_data
+
+
+# ---------------------------------------------------------------------- main.py:536-555
+class FlatSGD:
+    """torch.optim.SGD semantics (momentum, weight decay, per-group lr; main.py:547) over flat
+    buffers: every parameter becomes a view into one fp32 parameter buffer and its .grad a view
+    into one gradient buffer, so zero_grad is one memset, the data-parallel all-reduce is ONE
+    RCCL call over xGMI (replacing DataParallel's broadcast + reduce, main.py:661) and the
+    update is one fused HIP launch per group."""
+
+    def __init__(self, groups, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1):
+        self.momentum, self.weight_decay = momentum, weight_decay
+        self.world_size, self.process_group = world_size, process_group
+        self.param_groups = []
+        params = []
+        for g in groups:
+            ps = [p for p in g["params"] if p.requires_grad]
+            self.param_groups.append({"params": ps, "lr": g["lr"]})
+            params += ps
+        if not params:
+            raise ValueError("no parameters")
+        dev = params[0].device
+        lib.require_gpu(params[0])
+        total = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_buf = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self._views = []
+        for g in self.param_groups:
+            g["range"] = [off, off]
+            for p in g["params"]:
+                n = p.numel()
+                self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[off:off + n].view_as(p.data)
+                gv = self.flat_grad[off:off + n].view_as(p.data)
+                p.grad = gv
+                self._views.append((p, gv))
+                off += n
+            g["range"][1] = off
+        self._first = True
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        for p, gv in self._views:
+            p.grad = gv
+
+    def _collect(self):
+        # a caller that ran module.zero_grad(set_to_none=True) (torch default, main.py:560) left
+        # autograd to allocate fresh .grad tensors: fold them back into the flat buffer
+        for p, gv in self._views:
+            if p.grad is None:
+                gv.zero_()
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+            p.grad = gv
+
+    def step(self):
+        self._collect()
+        scale = 1.0
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, group=self.process_group)   # RCCL sum over xGMI
+            scale = 1.0 / self.world_size
+        for g in self.param_groups:
+            a, b = g["range"]
+            if b > a:
+                K.sgd_momentum_(self.flat_param[a:b], self.flat_grad[a:b], self.flat_buf[a:b], g["lr"],
+                                self.momentum, self.weight_decay, scale, self._first)
+        self._first = False
+
+
+def create_optimizer(nets, args, process_group=None, world_size=1):
+    (net_sound, net_frame) = nets
+    groups = [{"params": list(net_sound.parameters()), "lr": args.lr_sound},
+              {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound}]
+    if not args.fix_vis:
+        groups.append({"params": list(net_frame.features.parameters()), "lr": args.lr_frame})
+    return FlatSGD(groups, momentum=args.beta1, weight_decay=args.weight_decay,
+                   process_group=process_group, world_size=world_size)
+
+
+def adjust_learning_rate(optimizer, args):
+    args.lr_sound *= 0.1
+    args.lr_frame *= 0.1
+    if hasattr(args, "lr_motion"):
+        args.lr_motion *= 0.1
+    for param_group in optimizer.param_groups:
+        param_group["lr"] *= 0.1
+
+
+def train_step_async(model, batch, optimizer, use_vis, step_args=None):
+    """One train step without any host synchronisation: returns device tensors (err, match_loss, outputs)."""
+    a = step_args if step_args is not None else args
+    torch.set_grad_enabled(True)
+    model.train()
+    optimizer.zero_grad()
+    err, outputs = model.forward(batch, a, use_vis)
+    err = err.mean()
+    err.backward()
+    optimizer.step()
+    match_loss = outputs["match_loss"].mean() if use_vis else None
+    return err.detach(), (match_loss.detach() if match_loss is not None else None), outputs
+
+
+def train_step(model, batch, optimizer, use_vis, step_args=None):
+    """main.py:557-569: zero_grad -> forward -> err.mean().backward() -> optimizer.step();
+    returns (err.item(), match_loss.item() or None) like the reference (one host sync)."""
+    err, match_loss, _ = train_step_async(model, batch, optimizer, use_vis, step_args)
+    return err.item(), (match_loss.item() if match_loss is not None else None)

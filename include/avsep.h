@@ -1,0 +1,245 @@
+/*
+ * avsep.h — C ABI of libavsep_gfx950.so: the MI355X (gfx950) kernels behind the
+ * mix-and-separate train step of abcqmars/audio-visual-sepatation-in-visual-agnostic-situtation.
+ *
+ * The reference has no native layer: every entry point below
+ * replaces a group of stock PyTorch operators at the cited reference call site,
+ * and is what a binding for the reference's Python would load with ctypes
+ * (INTEGRATION.md shows the stub).  Conventions:
+ *   - extern "C", plain pointers and sizes; no C++/torch types cross the boundary;
+ *   - every pointer is a DEVICE pointer unless the name says host; tensors are
+ *     dense fp32 NCHW unless stated; the caller owns all buffers incl. workspaces;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous;
+ *   - return value: 0 = ok, negative = error (avsep_strerror()).
+ *   - the library keeps no mutable global state; it is re-entrant per stream.
+ */
+#ifndef AVSEP_H
+#define AVSEP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVSEP_OK 0
+#define AVSEP_ERR_ARG (-1)     /* bad shape / null pointer / unsupported geometry */
+#define AVSEP_ERR_LAUNCH (-2)  /* hipGetLastError() after a launch */
+#define AVSEP_ERR_WORKSPACE (-3)
+
+#define AVSEP_ACT_NONE 0
+#define AVSEP_ACT_RELU 1
+#define AVSEP_ACT_LRELU02 2    /* LeakyReLU(0.2): models/audio_net.py:64 */
+#define AVSEP_ACT_SIGMOID 3
+#define AVSEP_ACT_TANH 4
+#define AVSEP_ACT_SOFTMAX2 5   /* softmax over a 2-channel dim (models/__init__.py:19-20) */
+
+typedef void* avsep_stream_t;
+
+int avsep_version(void);
+const char* avsep_arch(void);          /* "gfx950" */
+const char* avsep_strerror(int code);
+
+/* ---------------------------------------------------------------------------
+ * Convolution as implicit GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces nn.Conv2d forward/backward at models/audio_net.py:72-98,177-182 and the
+ * torchvision ResNet-18 convs wrapped by models/vision_net.py:84-92.
+ *
+ * The conv input is a virtual tensor: channel-concat of up to two sources (the U-Net
+ * skip concat, audio_net.py:122,203), each passed through an optional per-channel
+ * affine (a folded BatchNorm, audio_net.py:65-67) and activation (LeakyReLU / ReLU,
+ * audio_net.py:64,66) while it is gathered — none of those is materialised.
+ * With up2x != 0 the virtual input is additionally the bilinear x2 upsample
+ * (align_corners=True, audio_net.py:68-69) of that tensor; H,W are then the
+ * UPSAMPLED sizes and the sources are [N,C,H/2,W/2].
+ * ------------------------------------------------------------------------- */
+typedef struct avsep_conv_desc {
+  int32_t N, Cin, H, W;        /* virtual input  [N,Cin,H,W]   */
+  int32_t Cout, Ho, Wo;        /* output         [N,Cout,Ho,Wo] */
+  int32_t KH, KW, stride, pad, dil;
+  int32_t C0;                  /* channels from x0; Cin-C0 from x1 (0 => x1 unused) */
+  int32_t act0, act1;          /* AVSEP_ACT_NONE/RELU/LRELU02, applied after the affine */
+  int32_t up2x;
+  const float* x0;
+  const float* x1;
+  const float* scale0;         /* [C0] or NULL */
+  const float* shift0;
+  const float* scale1;         /* [Cin-C0] or NULL */
+  const float* shift1;
+} avsep_conv_desc;
+
+/* Weight repack, once per optimizer step.  w: OIHW [Cout,Cin,KH,KW].
+ * mode 0 -> forward operand  [Kpad][Mpad], k=(ci,kh,kw), Mpad=roundup(Cout,128), Kpad=roundup(K,32)
+ * mode 1 -> dgrad operand    [KH*KW*Cout (padded to 32)][roundup(Cin,128)]            */
+size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode);
+int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w, float* packed, int mode,
+                            avsep_stream_t stream);
+
+/* y = conv(virtual input) (+bias).  stats (optional, double[2*Cout], pre-zeroed):
+ * per-channel sum and sum of squares of y, for the following BatchNorm.          */
+int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed, const float* bias, float* y,
+                     double* stats, avsep_stream_t stream);
+/* dx = gradient w.r.t. the VIRTUAL input [N,Cin,H,W] (after affine/activation/upsample). */
+int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packed_dgrad, const float* dy,
+                       float* dx, avsep_stream_t stream);
+/* dw OIHW; dbias optional ([Cout]).  workspace from avsep_conv2d_wgrad_workspace_bytes(). */
+size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d);
+int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias,
+                       void* workspace, size_t workspace_bytes, avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * BatchNorm2d pieces (train-mode batch statistics; nn.BatchNorm2d at audio_net.py:37,65,67).
+ * ------------------------------------------------------------------------- */
+/* stats[2*C] += per-channel (sum, sumsq) of x [N,C,HW]. */
+int avsep_channel_stats(const float* x, int32_t N, int32_t C, int32_t HW, double* stats,
+                        avsep_stream_t stream);
+/* From (sum,sumsq) -> scale=gamma*invstd, shift=beta-mean*scale, mean, invstd; updates the
+ * running buffers (momentum, unbiased var) when training!=0; with training==0 uses them. */
+int avsep_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps,
+                      int32_t C, int32_t training, float* scale, float* shift, float* mean,
+                      float* invstd, avsep_stream_t stream);
+/* Backward of train-mode BN given dz (grad wrt BN output) sums: bstats[2*C] = (sum dz, sum dz*xhat).
+ * Writes dgamma,dbeta and the coefficients of dy = p*dz + q*y + r (p,q,r: [C] each).     */
+int avsep_bn_bwd_coeffs(const double* bstats, double count, const float* gamma, const float* mean,
+                        const float* invstd, int32_t C, float* dgamma, float* dbeta, float* pqr,
+                        avsep_stream_t stream);
+/* dy = p[c]*dz + q[c]*y + r[c]  (in place on dz allowed). */
+int avsep_bn_bwd_apply(const float* dz, const float* y, const float* pqr, int32_t N, int32_t C,
+                       int32_t HW, float* dy, avsep_stream_t stream);
+/* z = act(scale[c]*y + shift[c]); optional residual add before the activation. */
+int avsep_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
+                     int32_t act, int32_t N, int32_t C, int32_t HW, float* z, avsep_stream_t stream);
+/* Gradient through z = act(scale*y+shift [+res]):  dz_pre = act'(.)*dz (+ add);  also
+ * accumulates bstats (sum dz_pre, sum dz_pre*xhat) when bstats != NULL.                  */
+int avsep_affine_act_bwd(const float* dz, const float* y, const float* scale, const float* shift,
+                         const float* residual, const float* add, const float* mean,
+                         const float* invstd, int32_t act, int32_t N, int32_t C, int32_t HW,
+                         float* dz_pre, double* bstats, avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * U-Net decoder glue: ReLU + bilinear x2 (align_corners=True) of the concat
+ * (audio_net.py:66-69,122,203) and its transpose.
+ * Sources as in avsep_conv_desc; a source with bcast!=0 is a [N,C] vector tiled over HxW
+ * (the fusion output, fusion_net.py:70-72).
+ * ------------------------------------------------------------------------- */
+typedef struct avsep_cat_desc {
+  int32_t N, C0, C1, H, W;     /* low-res sizes; output is [N,C0+C1,2H,2W] */
+  int32_t bcast0, bcast1;
+  const float* x0;
+  const float* x1;
+  const float* scale0;
+  const float* shift0;
+  const float* scale1;
+  const float* shift1;
+} avsep_cat_desc;
+int avsep_relu_up2x_fwd(const avsep_cat_desc* d, float* out, avsep_stream_t stream);
+/* g0/g1: gradient wrt the pre-ReLU (post-affine) value of each source, masked by (value>0);
+ * for a bcast source the gradient is summed over HxW into [N,C].  bstats1 (optional):
+ * (sum g1, sum g1*xhat1) for the BN that produced source 1 (needs mean1/invstd1).
+ * acc0 != 0: g0 += instead of =.                                                         */
+int avsep_relu_up2x_bwd(const avsep_cat_desc* d, const float* dout, float* g0, float* g1,
+                        const float* mean1, const float* invstd1, double* bstats1, int32_t acc0,
+                        avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * prepare: +1e-10, log-frequency warp (grid_sample bilinear/zeros/align_corners=False on the
+ * utils.py:12-26 grid), loss weight, ground-truth masks, log  (main.py:51-95).
+ * mags: [S][B,1,Fin,T] contiguous as one buffer [S,B,Fin,T].  warp==0 -> Fout==Fin, no resample.
+ * Outputs [B,1,Fout,T]: mag_mix_w, log_mag_mix, weight; [S,B,Fout,T]: mags_w, gt.
+ * ------------------------------------------------------------------------- */
+int avsep_prepare(const float* mag_mix, const float* mags, int32_t S, int32_t B, int32_t Fin,
+                  int32_t T, int32_t Fout, int32_t warp, int32_t weighted, int32_t binary,
+                  float* mag_mix_w, float* mags_w, float* log_mag_mix, float* weight, float* gt,
+                  avsep_stream_t stream);
+/* grid_sample of [B,C,Hin,Win] on warpgrid(B,Hout,Wout,warp) — the un-warp of main.py:216-220
+ * (warp=0) and the generic resample. */
+int avsep_warp(const float* x, int32_t BC, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
+               int32_t warp, float* y, avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Bottleneck fusion (models/fusion_net.py).  x: [B,2*Dc,F,T] bottleneck; v: [C=2][B,Dc,H,W].
+ * kind: 0 hidsep/CoLoc, 1 CoLoc_Sel, 2 MixVis (v is then ONE map [B,Dc,H,W]);  att: 0 cos, 1 sig.
+ * Outputs: feat [B,2*Dc] (the two broadcast vectors), att_maps [B,2,H,W], match_part [B]
+ * (per-sample match-loss terms; the caller averages), best [B] (winning permutation),
+ * pool_idx [B,2*Dc] argmax of the global max-pool, sel_idx [B,2*Dc] argmax used for feat.
+ * bwd: dfeat [B,2*Dc]; dmaps optional [B,2,H,W]; the match-loss cotangent is the DEVICE scalar
+ * *dmatch (NULL = 1) times the host factor dmatch_scale (1/B for the batch mean); the gradient
+ * wrt x is ADDED into dx_accum [B,2*Dc,F,T]; dv0/dv1 [B,Dc,H,W] are overwritten.
+ * ------------------------------------------------------------------------- */
+int avsep_fusion_av_fwd(const float* x, const float* v0, const float* v1, int32_t B, int32_t Dc,
+                        int32_t FT, int32_t HW, int32_t kind, int32_t att, float* a_pool,
+                        int32_t* pool_idx, float* feat, int32_t* sel_idx, float* att_maps,
+                        float* match_part, int32_t* best, avsep_stream_t stream);
+int avsep_fusion_av_bwd(const float* x, const float* v0, const float* v1, int32_t B, int32_t Dc,
+                        int32_t FT, int32_t HW, int32_t kind, int32_t att, const float* a_pool,
+                        const int32_t* pool_idx, const int32_t* sel_idx, const float* att_maps,
+                        const int32_t* best, const float* dfeat, const float* dmaps,
+                        const float* dmatch, float dmatch_scale, float* dx_accum, float* dv0,
+                        float* dv1, avsep_stream_t stream);
+/* AO branch (fusion_net.py:93-104): feat = swapped global-max-pooled blocks. draws: uint8[B]. */
+int avsep_fusion_ao_fwd(const float* x, const uint8_t* draws, int32_t all_zero, int32_t B,
+                        int32_t Dc, int32_t FT, float* feat, int32_t* pool_idx,
+                        avsep_stream_t stream);
+int avsep_fusion_ao_bwd(const uint8_t* draws, int32_t all_zero, int32_t B, int32_t Dc, int32_t FT,
+                        const int32_t* pool_idx, const float* dfeat, float* dx_accum,
+                        avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Mask loss: activation + weighted BCE/L1/L2 (models/criterion.py:10-49) and the PIT loss
+ * matrix (criterion.py:138-178) in one pass.  logits [B,S,FT]; gt [S,B,FT]; weight [B,FT] shared by
+ * all targets (w_target_stride 0) or one map per target i at weight + i*w_target_stride.
+ * pred [B,S,FT] = activation(logits).  sums: double[B*S*S], sums[b,i,j] = sum_ft w*l(pred_j, gt_i).
+ * loss: 0 bce, 1 l1, 2 l2.
+ * bwd: dlogits[b,j,ft] = sum_i coef[b,i,j] * w * dl/dlogit(pred_j, gt_i).
+ * ------------------------------------------------------------------------- */
+int avsep_mask_loss_fwd(const float* logits, const float* gt, const float* weight,
+                        int64_t w_target_stride, int32_t B, int32_t S, int32_t FT, int32_t act,
+                        int32_t loss, float* pred, double* sums, avsep_stream_t stream);
+int avsep_mask_loss_bwd(const float* logits, const float* gt, const float* weight,
+                        int64_t w_target_stride, const float* coef, int32_t B, int32_t S, int32_t FT,
+                        int32_t act, int32_t loss, float* dlogits, avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * STFT / iSTFT (librosa semantics, dataset/base.py:142-147, utils.py:101-104): periodic Hann,
+ * center=True, DFT as GEMM on the f32 MFMA.  wav [R,L]; mag/phase [R,n_fft/2+1,frames].
+ * The bases (window folded in, cos then -sin) are conv operands built once by avsep_stft_basis
+ * into caller buffers of avsep_stft_basis_floats() floats; reflect=1 -> librosa<0.10 pad mode,
+ * 0 -> zeros (librosa>=0.10).  phase may be NULL.
+ * ------------------------------------------------------------------------- */
+size_t avsep_stft_basis_floats(int32_t n_fft, int32_t inverse);
+int avsep_stft_basis(int32_t n_fft, float* fwd_basis, float* inv_basis, avsep_stream_t stream);
+size_t avsep_stft_workspace_bytes(int32_t R, int32_t L, int32_t n_fft, int32_t hop);
+int avsep_stft_mag(const float* wav, int32_t R, int32_t L, int32_t n_fft, int32_t hop,
+                   int32_t reflect, const float* basis, float* mag, float* phase, void* workspace,
+                   size_t workspace_bytes, avsep_stream_t stream);
+size_t avsep_istft_workspace_bytes(int32_t R, int32_t n_fft, int32_t frames);
+int avsep_istft(const float* mag, const float* phase, int32_t R, int32_t n_fft, int32_t hop,
+                int32_t frames, const float* inv_basis, float* wav, int32_t out_len, void* workspace,
+                size_t workspace_bytes, avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Misc per-frame visual ops and the optimizer.
+ * ------------------------------------------------------------------------- */
+int avsep_maxpool3x3s2_fwd(const float* x, int32_t NC, int32_t H, int32_t W, float* y, int32_t* idx,
+                           avsep_stream_t stream);   /* nn.MaxPool2d(3,2,1), resnet stem */
+int avsep_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int32_t NC, int32_t H, int32_t W,
+                           float* dx, avsep_stream_t stream);
+/* y[b,c,hw] = mean_t x[b*T+t,c,hw]  (vision_net.py:134-135) and its transpose. */
+int avsep_temporal_mean_fwd(const float* x, int32_t B, int32_t T, int32_t CHW, float* y,
+                            avsep_stream_t stream);
+int avsep_temporal_mean_bwd(const float* dy, int32_t B, int32_t T, int32_t CHW, float* dx,
+                            avsep_stream_t stream);
+/* SGD with momentum + weight decay (torch.optim.SGD semantics, main.py:547):
+ * g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf.  grad_scale multiplies g first
+ * (1/world after the RCCL sum). */
+int avsep_sgd_momentum(float* p, const float* g, float* buf, size_t n, float lr, float momentum,
+                       float weight_decay, float grad_scale, int32_t first, avsep_stream_t stream);
+/* InnerProd / Bias synthesizer (models/synthesizer_net.py:12-19): z[b,hw] = sum_k img[b,k]*scale[k]*snd[b,k,hw] + bias */
+int avsep_innerprod_fwd(const float* img, const float* snd, const float* scale, const float* bias,
+                        int32_t B, int32_t K, int32_t HW, float* z, avsep_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVSEP_H */

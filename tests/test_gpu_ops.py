@@ -1,0 +1,264 @@
+"""-m gpu: every HIP entry point against plain PyTorch fp32 on the CPU (conv/BN/upsample are
+floating-point kernels, so the torch reference is kept beside the oracle; tolerances are stated
+per test: fp32 accumulation-order noise only)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _pkg():
+    import avsep_amd
+    return avsep_amd
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, dil
+    (2, 1, 32, 32, 64, 4, 2, 1, 1),        # U-Net d1 shape family
+    (2, 64, 16, 16, 128, 4, 2, 1, 1),
+    (3, 96, 8, 8, 40, 3, 1, 1, 1),         # ragged channel counts
+    (2, 160, 10, 6, 130, 3, 1, 1, 1),      # > one 128 tile in M, odd spatial
+    (2, 3, 30, 30, 64, 7, 2, 3, 1),        # resnet stem
+    (2, 32, 14, 14, 48, 3, 1, 2, 2),       # dilated
+    (2, 32, 15, 15, 48, 3, 2, 1, 1),       # 3x3 stride 2, odd size
+    (2, 32, 14, 14, 64, 1, 2, 0, 1),       # 1x1 stride 2 downsample
+    (4, 256, 4, 4, 256, 4, 2, 1, 1),       # deep, tiny spatial
+    (1, 20, 12, 12, 2, 3, 1, 1, 1),        # Cout = 2 (last U-Net conv)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    K = _pkg().kernels
+    N, Cin, H, W, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, b, s, p, d)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    cv = K.Conv(xd, Cout, k, s, p, d)
+    st = K.zeros_stats(Cout, xd)
+    y = cv.fwd(cv.pack(wd, 0), bd, st)
+    assert_close(y, y_ref, 2e-5, "fwd")
+    st_ref = torch.cat([y_ref.double().sum((0, 2, 3)), (y_ref.double() ** 2).sum((0, 2, 3))])
+    assert_close(st, st_ref, 1e-5, "stats")
+    dx = cv.dgrad(cv.pack(wd, 1), dyd)
+    assert_close(dx, xr.grad, 2e-5, "dgrad")
+    dw, db = cv.wgrad(dyd, want_bias=True)
+    assert_close(dw, wr.grad, 2e-5, "wgrad")
+    assert_close(db, dy.sum((0, 2, 3)), 2e-5, "dbias")
+
+
+@pytest.mark.parametrize("up2x", [False, True])
+def test_conv_virtual_input(dev, up2x):
+    """two-source concat + per-channel affine + LeakyReLU/ReLU (+ bilinear x2) folded into the gather."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(5)
+    N, C0, C1, H, W, Cout = 2, 24, 40, 9, 7, 36
+    x0, x1 = torch.randn(N, C0, H, W, generator=g), torch.randn(N, C1, H, W, generator=g)
+    sc0, sh0 = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g)
+    sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g)
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.05
+    a0 = F.leaky_relu(x0 * sc0.view(1, -1, 1, 1) + sh0.view(1, -1, 1, 1), 0.2)
+    a1 = F.relu(x1 * sc1.view(1, -1, 1, 1) + sh1.view(1, -1, 1, 1))
+    v = torch.cat([a0, a1], 1)
+    if up2x:
+        v = F.interpolate(v, scale_factor=2, mode="bilinear", align_corners=True)
+    v = v.requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(v, wr, None, 1, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    t = lambda z: z.to(dev)
+    cv = K.Conv(t(x0), Cout, 3, 1, 1, x1=t(x1), sc0=t(sc0), sh0=t(sh0), act0=2, sc1=t(sc1), sh1=t(sh1), act1=1,
+                up2x=up2x)
+    y = cv.fwd(cv.pack(t(w), 0))
+    assert_close(y, y_ref, 2e-5, "fwd")
+    assert_close(cv.dgrad(cv.pack(t(w), 1), t(dy)), v.grad, 2e-5, "dgrad")
+    assert_close(cv.wgrad(t(dy))[0], wr.grad, 2e-5, "wgrad")
+
+
+def test_bn_pieces(dev):
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(6)
+    N, C, H, W = 3, 10, 12, 9
+    y = torch.randn(N, C, H, W, generator=g) * 2 + 1
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data, bn.bias.data = gamma.clone(), beta.clone()
+    yr = y.clone().requires_grad_(True)
+    z_ref = bn(yr)
+    dz = torch.randn(z_ref.shape, generator=g)
+    z_ref.backward(dz)
+    yd = y.to(dev)
+    st = K.zeros_stats(C, yd)
+    K.channel_stats(yd, st)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    rows = K.bn_finalize(st, N * H * W, gamma.to(dev), beta.to(dev), rm, rv, 0.1, 1e-5, True, yd)
+    z = K.affine_act(yd, rows[0], rows[1], None, 0)
+    assert_close(z, z_ref, 1e-5, "bn fwd")
+    assert_close(rm, bn.running_mean, 1e-5, "running_mean")
+    assert_close(rv, bn.running_var, 1e-5, "running_var")
+    dzd = dz.to(dev).clone()
+    bst = K.zeros_stats(C, yd)
+    K.affine_act_bwd_(dzd, yd, rows[0], rows[1], None, None, rows[2], rows[3], 0, bst)
+    dgamma, dbeta, pqr = K.bn_bwd_coeffs(bst, N * H * W, gamma.to(dev), rows[2], rows[3])
+    dy = K.bn_bwd_apply_(dzd, yd, pqr)
+    assert_close(dgamma, bn.weight.grad, 2e-5, "dgamma")
+    assert_close(dbeta, bn.bias.grad, 2e-5, "dbeta")
+    assert_close(dy, yr.grad, 5e-5, "bn dx")
+
+
+@pytest.mark.parametrize("bcast", [False, True])
+def test_relu_up2x(dev, bcast):
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(7)
+    N, C0, C1, H, W = 2, 6, 5, 4, 3
+    x0 = torch.randn(N, C0, generator=g) if bcast else torch.randn(N, C0, H, W, generator=g)
+    x1 = torch.randn(N, C1, H, W, generator=g)
+    sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g)
+    a0 = (x0.view(N, C0, 1, 1).expand(N, C0, H, W) if bcast else x0).clone().requires_grad_(True)
+    a1 = (x1 * sc1.view(1, -1, 1, 1) + sh1.view(1, -1, 1, 1)).requires_grad_(True)
+    out_ref = F.interpolate(F.relu(torch.cat([a0, a1], 1)), scale_factor=2, mode="bilinear", align_corners=True)
+    dout = torch.randn(out_ref.shape, generator=g)
+    out_ref.backward(dout)
+    t = lambda z: z.to(dev)
+    cat = K.Cat(t(x0), t(x1), sc1=t(sc1), sh1=t(sh1), bcast0=bcast)
+    assert_close(cat.fwd(), out_ref, 1e-6, "fwd")
+    mean1, invstd1 = torch.randn(C1, generator=g), torch.rand(C1, generator=g) + 0.5
+    bst = K.zeros_stats(C1, t(x1))
+    g0, g1 = cat.bwd(t(dout), mean1=t(mean1), invstd1=t(invstd1), bstats1=bst)
+    assert_close(g0, a0.grad.sum((2, 3)) if bcast else a0.grad, 2e-6, "g0")
+    assert_close(g1, a1.grad, 2e-6, "g1")
+    xhat = (x1 - mean1.view(1, -1, 1, 1)) * invstd1.view(1, -1, 1, 1)
+    ref = torch.cat([a1.grad.double().sum((0, 2, 3)), (a1.grad.double() * xhat).sum((0, 2, 3))])
+    assert_close(bst, ref, 1e-5, "bstats")
+
+
+def test_prepare_golden(dev, golden):
+    K = _pkg().kernels
+    G = golden("prepare")
+    mags = torch.stack([G["mags0"], G["mags1"]], 0).to(dev)
+    for tag, kw in [("bin_w", dict(binary=1, weighted=1, log_freq=1)), ("ratio_now", dict(binary=0, weighted=0, log_freq=1)),
+                    ("nolog", dict(binary=1, weighted=1, log_freq=0))]:
+        mix_w, mags_w, logm, weight, gt = K.prepare(G["mag_mix"].to(dev), mags, kw["log_freq"], kw["weighted"], kw["binary"])
+        assert_close(mix_w, G[f"{tag}.mag_mix"], 1e-5, tag + " mag_mix")
+        assert_close(logm, G[f"{tag}.log_mag_mix"], 1e-5, tag + " log")
+        assert_close(weight, G[f"{tag}.weights"], 1e-5, tag + " weight")
+        for n in range(2):
+            assert_close(mags_w[n], G[f"{tag}.mags{n}"], 1e-5, tag + " mags")
+            ref = G[f"{tag}.gt_masks{n}"]
+            if kw["binary"]:   # a mask bit may flip where mags == 0.5*mix to the last ulp
+                frac = (gt[n].cpu() != ref).float().mean().item()
+                assert frac <= 1e-4, f"{tag} gt{n}: {frac} of the mask bits differ"
+            else:
+                assert_close(gt[n], ref, 1e-4, tag + " gt ratio")
+    # unwarp (main.py:216-220) against torch grid_sample on the reference grid
+    import numpy as np
+    x = torch.rand(2, 1, 256, 24)
+    ref = F.grid_sample(x, torch.from_numpy(_warpgrid(2, 512, 24, False)), align_corners=False)
+    assert_close(K.warp(x.to(dev), 512, 24, 0), ref, 1e-5, "unwarp")
+
+
+def _warpgrid(bs, HO, WO, warp):
+    import numpy as np
+    x, y = np.linspace(-1, 1, WO), np.linspace(-1, 1, HO)
+    xv, yv = np.meshgrid(x, y)
+    gy = (np.power(21, (yv + 1) / 2) - 11) / 10 if warp else np.log(yv * 10 + 11) / np.log(21) * 2 - 1
+    grid = np.zeros((bs, HO, WO, 2))
+    grid[..., 0], grid[..., 1] = xv, gy
+    return grid.astype(np.float32)
+
+
+def test_mask_loss_and_pit_golden(dev, golden):
+    M = _pkg().models
+    G = golden("criterion")
+    t = lambda z: z.to(dev)
+    preds, tg, w = [t(G["p0"]), t(G["p1"])], [t(G["t0"]), t(G["t1"])], t(G["w"])
+    for kind, cls in (("bce", M.BCELoss), ("l1", M.L1Loss), ("l2", M.L2Loss)):
+        assert_close(cls()(preds, tg, w), G[f"{kind}.list"], 1e-5, kind + " list")
+        assert_close(cls()(preds[0], tg[0]), G[f"{kind}.tensor_now"], 1e-5, kind + " tensor")
+    pit = M.PitWrapper(F.binary_cross_entropy)
+    loss, perms = pit(t(G["pit.P"]), t(G["pit.T"]), t(G["pit.W"]))
+    assert_close(loss, G["pit.loss"], 1e-5, "pit loss")
+    assert [tuple(p) for p in perms] == [tuple(p) for p in G["pit.perms"].tolist()]
+    assert torch.equal(pit.reorder_tensor(t(G["pit.P"]), perms).cpu(), G["pit.reordered"])
+    # gradient of the fused sigmoid+BCE path against autograd
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 2, 6, 5, generator=g) * 3
+    gt = (torch.rand(2, 2, 1, 6, 5, generator=g) > 0.5).float()
+    wt = torch.rand(2, 1, 6, 5, generator=g)
+    lr = logits.clone().requires_grad_(True)
+    ref = sum(F.binary_cross_entropy(torch.sigmoid(lr[:, n:n + 1]), gt[n], weight=wt) for n in range(2)) / 2
+    ref.backward()
+    from avsep_amd.models.criterion import mask_loss
+    ld = logits.to(dev).requires_grad_(True)
+    pred, sums, FT = mask_loss(ld, gt.to(dev), wt.to(dev), 3, "bce")
+    err = torch.diagonal(sums, dim1=1, dim2=2).sum() / (2 * 2 * FT)
+    err.backward()
+    assert_close(err, ref, 1e-5, "fused bce")
+    assert_close(ld.grad, lr.grad, 1e-5, "fused bce grad")
+    assert_close(pred, torch.sigmoid(logits), 1e-6, "pred")
+
+
+def test_sgd_matches_torch(dev):
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(8)
+    p = torch.randn(1000, generator=g)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd, buf = p.to(dev), torch.zeros(1000, device=dev)
+    for it in range(3):
+        gr = torch.randn(1000, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        K.sgd_momentum_(pd, gr.to(dev), buf, 0.01, 0.9, 1e-4, 1.0, it == 0)
+    assert_close(pd, ref, 1e-6, "sgd")
+
+
+def test_stft_against_numpy(dev):
+    import numpy as np
+    from oracle import stft as OS
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(9)
+    wav = torch.randn(3, 65535, generator=g) * 0.3
+    for mode in ("reflect", "constant"):
+        plan = K.Stft(dev, 1022, 256, mode)
+        mag, phase = plan.stft(wav.to(dev))
+        assert mag.shape == (3, 512, 256)
+        for r in range(3):
+            m_ref, p_ref = OS.stft_mag_phase(wav[r].numpy(), 1022, 256, mode)
+            # tolerance: fp32 DFT-as-GEMM vs numpy's pocketfft in fp64-cast-to-c64, relative to the peak magnitude
+            assert_close(mag[r], torch.from_numpy(m_ref), 2e-5, "stft mag " + mode)
+            spec = mag[r].cpu() * torch.exp(1j * phase[r].cpu())
+            spec_ref = torch.from_numpy(m_ref * np.exp(1j * p_ref))
+            assert (spec - spec_ref).abs().max() / spec_ref.abs().max() < 5e-5
+        back = plan.istft(mag, phase)
+        ref = torch.from_numpy(np.stack([OS.istft(OS.stft(wav[r].numpy(), 1022, 256, mode)) for r in range(3)]))
+        assert_close(back, ref, 5e-5, "istft " + mode)
+    # round trip: interior samples are reconstructed
+    assert (back.cpu()[:, 1024:64000] - wav[:, 1024:64000]).abs().max() < 1e-3
+
+
+def test_pool_and_mean(dev):
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(3, 5, 11, 14, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    y, idx = K.maxpool3x3s2(x.to(dev))
+    assert_close(y, y_ref, 0, "maxpool")
+    assert_close(K.maxpool3x3s2_bwd(dy.to(dev), idx, 11, 14), xr.grad, 1e-6, "maxpool bwd")
+    f = torch.randn(6, 4, 3, 3, generator=g)
+    assert_close(K.temporal_mean(f.to(dev), 2, 3), f.view(2, 3, 4, 3, 3).mean(1), 1e-6, "tmean")
+    d = torch.randn(2, 4, 3, 3, generator=g)
+    assert_close(K.temporal_mean_bwd(d.to(dev), 2, 3), (d / 3).repeat_interleave(3, 0), 1e-6, "tmean bwd")
