@@ -143,7 +143,7 @@ class FlatSGD:
         params = []
         for g in groups:
             ps = [p for p in g["params"] if p.requires_grad]
-            self.param_groups.append({"params": ps, "lr": g["lr"]})
+            self.param_groups.append({"params": ps, "lr": g["lr"], "name": g.get("name", str(len(self.param_groups)))})
             params += ps
         if not params:
             raise ValueError("no parameters")
@@ -166,7 +166,6 @@ class FlatSGD:
                 self._views.append((p, gv))
                 off += n
             g["range"][1] = off
-        self._first = True
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
@@ -176,6 +175,8 @@ class FlatSGD:
     def _collect(self):
         # a caller that ran module.zero_grad(set_to_none=True) (torch default, main.py:560) left
         # autograd to allocate fresh .grad tensors: fold them back into the flat buffer
+        for g in self.param_groups:
+            g["no_grad"] = bool(g["params"]) and all(p.grad is None for p in g["params"])
         for p, gv in self._views:
             if p.grad is None:
                 gv.zero_()
@@ -183,27 +184,34 @@ class FlatSGD:
                 gv.copy_(p.grad)
             p.grad = gv
 
-    def step(self):
+    def step(self, only=None):
+        """`only`: names of the groups that took part in this step's graph.  torch.optim.SGD skips a
+        parameter whose .grad is None (no weight decay, no momentum update); with the reference's
+        model.zero_grad() (set_to_none) that is every net_frame parameter on an audio-only step."""
         self._collect()
+        active = [g for g in self.param_groups
+                  if (only is None or g["name"] in only) and g["range"][1] > g["range"][0] and not g.get("no_grad")]
         scale = 1.0
-        if self.world_size > 1:
+        if self.world_size > 1 and active:
             import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, group=self.process_group)   # RCCL sum over xGMI
+            lo, hi = min(g["range"][0] for g in active), max(g["range"][1] for g in active)
+            dist.all_reduce(self.flat_grad[lo:hi], group=self.process_group)   # ONE RCCL sum over xGMI
             scale = 1.0 / self.world_size
-        for g in self.param_groups:
+        for g in active:
             a, b = g["range"]
-            if b > a:
-                K.sgd_momentum_(self.flat_param[a:b], self.flat_grad[a:b], self.flat_buf[a:b], g["lr"],
-                                self.momentum, self.weight_decay, scale, self._first)
-        self._first = False
+            first = not g.get("started", False)
+            K.sgd_momentum_(self.flat_param[a:b], self.flat_grad[a:b], self.flat_buf[a:b], g["lr"],
+                            self.momentum, self.weight_decay, scale, first)
+            g["started"] = True
 
 
 def create_optimizer(nets, args, process_group=None, world_size=1):
     (net_sound, net_frame) = nets
-    groups = [{"params": list(net_sound.parameters()), "lr": args.lr_sound},
-              {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound}]
+    groups = [{"params": list(net_sound.parameters()), "lr": args.lr_sound, "name": "sound"},
+              {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound, "name": "frame_fc"}]
     if not args.fix_vis:
-        groups.append({"params": list(net_frame.features.parameters()), "lr": args.lr_frame})
+        groups.append({"params": list(net_frame.features.parameters()), "lr": args.lr_frame,
+                       "name": "frame_features"})
     return FlatSGD(groups, momentum=args.beta1, weight_decay=args.weight_decay,
                    process_group=process_group, world_size=world_size)
 
@@ -226,7 +234,10 @@ def train_step_async(model, batch, optimizer, use_vis, step_args=None):
     err, outputs = model.forward(batch, a, use_vis)
     err = err.mean()
     err.backward()
-    optimizer.step()
+    if isinstance(optimizer, FlatSGD):
+        optimizer.step(only=None if use_vis else ("sound",))   # the visual net is not in an audio-only graph
+    else:
+        optimizer.step()
     match_loss = outputs["match_loss"].mean() if use_vis else None
     return err.detach(), (match_loss.detach() if match_loss is not None else None), outputs
 

@@ -22,6 +22,9 @@ def _load_unet(P, G, tag, downs, ngf, ftype, att, dev, **kw):
     sd = {k[len(tag) + 3:]: v for k, v in G.items() if k.startswith(tag + ".w.")}
     assert list(net.state_dict().keys()) == list(sd.keys()), "state_dict keys/order differ from the reference"
     net.load_state_dict(sd)
+    # the golden state_dict was captured after the reference's train passes: restart the BN buffers
+    for k, b in net.named_buffers():
+        b.copy_(torch.ones_like(b) if k.endswith("running_var") else torch.zeros_like(b))
     return net.to(dev)
 
 
@@ -49,12 +52,13 @@ def test_unet_golden(dev, golden, tag, downs, ngf, ftype, att, fuse):
     for k, p in net.named_parameters():
         assert p.grad is not None, k
         assert_close(p.grad, G[f"{tag}.g.{k}"], 3e-3, "grad " + k)
+    # BatchNorm running statistics after exactly one train-mode forward
     for k, b in net.named_buffers():
         ref = G[f"{tag}.b.{k}"]
         if ref.dtype.is_floating_point:
-            pass  # checked after the AO/eval passes below would have advanced them; compare now:
-    # running stats after exactly one train forward equal the reference's after its first forward?
-    # (the golden buffers were captured after train-AV + train-AO forwards) -> run the AO pass, then compare
+            assert_close(b, ref, 1e-4, "buffer " + k)
+        else:
+            assert int(b) == int(ref), k
     net.ao_draws = G[f"{tag}.draws"]
     yao, meta = net(x, None)
     assert meta == (None, None)
