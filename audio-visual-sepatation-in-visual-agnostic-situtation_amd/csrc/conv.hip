@@ -29,6 +29,7 @@ struct CArgs {
   int M, Ncols, K;
   int gridM;
   int chunk, P;  // wgrad: pixels per split, total pixels
+  int lstride;   // log2(stride) (dgrad)
 };
 
 __device__ __forceinline__ float load_src(const CArgs& a, long long nb0, long long nb1, int ci, int off) {
@@ -69,6 +70,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
   __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
   __shared__ float Bs[2][BK][LDB];
   __shared__ int s_tab[(MODE == M_WGRAD) ? BN : 24];
+  __shared__ float s_sc[(MODE == M_WGRAD) ? BN : 1], s_sh[(MODE == M_WGRAD) ? BN : 1];
+  __shared__ int s_code[(MODE == M_WGRAD) ? BN : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -112,12 +115,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
     nK = (p_end - p_begin + BK - 1) / BK;
     // per-column (k) decode table: ci | dh<<16 | dw<<24
     for (int c = tid; c < BN; c += 256) {
-      int k = n0 + c, v = -1;
+      int k = n0 + c, v = -1, code = 0;
+      float sc = 1.f, sh = 0.f;
       if (k < Ncols) {
         int ci = k / KHW, r = k % KHW;
         v = ci | ((r / a.KW) * a.dil << 16) | ((r % a.KW) * a.dil << 24);
+        bool first = ci < a.C0;
+        int cs = first ? ci : ci - a.C0;
+        const float* sp = first ? a.sc0 : a.sc1;
+        const float* hp = first ? a.sh0 : a.sh1;
+        if (sp) { sc = sp[cs]; sh = hp[cs]; code = 1; }
+        code |= (first ? a.act0 : a.act1) << 1;
       }
       s_tab[c] = v;
+      s_sc[c] = sc;
+      s_sh[c] = sh;
+      s_code[c] = code;
     }
     __syncthreads();
   } else {
@@ -125,11 +138,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
   }
 
   // ---------------- per-thread loader state ----------------
-  // fwd/dgrad: thread owns one column (bcol) and BROWS consecutive k rows
+  // fwd/dgrad: thread owns one column (bcol) and BROWS consecutive k rows.
+  // Loads are split in two phases so that their latency hides behind the MFMA loop:
+  //   issue(kt+1): address math + UNCONDITIONAL global loads (clamped addresses) into raw registers
+  //   finish():    affine + activation + zero-masking, then the LDS stores, after the MFMA loop.
   constexpr int BGROUPS = 256 / BN, BROWS = (MODE == M_WGRAD) ? 1 : BK / BGROUPS;
   constexpr int A4 = BM / 4, AV = (MODE == M_WGRAD) ? 1 : (BK * A4) / 256;
   constexpr int PG = 256 / BK, AE = BM / PG, BE = BN / PG;  // wgrad
-  const int bcol = tid % BN, brow0 = (tid / BN) * BROWS;
+  constexpr int NBR = (MODE == M_WGRAD) ? BE : BROWS;
+  constexpr int NSC = (MODE == M_FWD) ? BROWS : 1;
+  // BN >= 64, so all lanes of a wave own the same k rows: keep everything k-dependent on the scalar unit
+  const int bcol = tid % BN, brow0 = __builtin_amdgcn_readfirstlane((tid / BN) * BROWS);
   bool cvalid = false;
   long long nb0 = 0, nb1 = 0, nbdy = 0;
   int hi0 = 0, wi0 = 0;
@@ -151,62 +170,81 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
     wi0 = (r % Wc) * a.stride + pw + a.pad;
     nbdy = (long long)n * a.Cout * HoWo;
   }
+  const bool has0 = a.sc0 != nullptr, has1 = a.sc1 != nullptr;
+  const int pixoff = hi0 * a.Ws + wi0;   // fwd: offset of the (possibly out-of-range) window origin
 
-  float breg[(MODE == M_WGRAD) ? BE : BROWS];
+  float braw[NBR], bsc[NSC], bsh[NSC];
   float4 areg4[AV];
   float areg[(MODE == M_WGRAD) ? AE : 1];
+  unsigned bmask = 0, bfirst = 0, amask = 0;
 
-  auto load_tile = [&](int kt) {
+  auto issue = [&](int kt) {
     if (MODE == M_FWD) {
 #pragma unroll
       for (int e = 0; e < AV; ++e) {
         int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
         areg4[e] = *reinterpret_cast<const float4*>(a.wp + (long long)(kt * BK + row) * a.wp_ld + m0 + c4 * 4);
       }
-      int k = kt * BK + brow0;
+      const int k = kt * BK + brow0;                       // wave-uniform
       int ci = k / KHW, r = k % KHW, kh = r / a.KW, kw = r % a.KW;
+      bmask = 0;
+      bfirst = 0;
 #pragma unroll
       for (int e = 0; e < BROWS; ++e) {
-        float v = 0.f;
-        if (cvalid && k + e < K) {
-          int hi = hi0 + kh * a.dil, wi = wi0 + kw * a.dil;
-          if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
-            v = load_virtual(a, nb0, nb1, ci, hi, wi);
+        const int dh = kh * a.dil, dw = kw * a.dil;          // uniform
+        const int hi = hi0 + dh, wi = wi0 + dw;
+        const bool ok = cvalid && (k + e < K) && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        const int cc = min(ci, a.Cin - 1);
+        if (a.up2x) {  // kernel-uniform: the bilinear gather finishes here (raw value is final)
+          braw[e] = ok ? load_virtual(a, nb0, nb1, cc, hi, wi) : 0.f;
+          bsc[e] = 1.f;
+          bsh[e] = 0.f;
+        } else {
+          const bool first = cc < a.C0;                      // uniform
+          const int c = first ? cc : cc - a.C0;
+          const float* xc = (first ? a.x0 : a.x1) + (long long)c * srcHW + (dh * a.Ws + dw);   // uniform pointer
+          const long long lane_off = (first ? nb0 : nb1) + (ok ? pixoff : -(dh * a.Ws + dw));
+          braw[e] = xc[lane_off];
+          const bool has = first ? has0 : has1;
+          bsc[e] = has ? (first ? a.sc0 : a.sc1)[c] : 1.f;   // uniform -> scalar loads
+          bsh[e] = has ? (first ? a.sh0 : a.sh1)[c] : 0.f;
+          bfirst |= (unsigned)first << e;
         }
-        breg[e] = v;
+        bmask |= (unsigned)ok << e;
         if (++kw == a.KW) {
           kw = 0;
           if (++kh == a.KH) { kh = 0; ++ci; }
         }
       }
     } else if (MODE == M_DGRAD) {
+      amask = 0;
 #pragma unroll
       for (int e = 0; e < AV; ++e) {
         int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
         int k = kt * BK + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < K) {
-          int co = k % a.Cout, t = k / a.Cout;
-          int kh = s_tab[2 + t / ntw], kw = s_tab[12 + t % ntw];
-          v = *reinterpret_cast<const float4*>(a.wp + (long long)((kh * a.KW + kw) * a.Cout + co) * a.wp_ld + m0 +
-                                               c4 * 4);
-        }
-        areg4[e] = v;
+        bool ok = k < K;
+        int kk = ok ? k : 0;
+        int co = kk % a.Cout, t = kk / a.Cout;
+        int kh = s_tab[2 + t / ntw], kw = s_tab[12 + t % ntw];
+        areg4[e] = *reinterpret_cast<const float4*>(a.wp + (long long)((kh * a.KW + kw) * a.Cout + co) * a.wp_ld + m0 +
+                                                    c4 * 4);
+        amask |= (unsigned)ok << e;
       }
-      int k = kt * BK + brow0;
+      const int k = kt * BK + brow0;                       // wave-uniform
       int co = k % a.Cout, t = k / a.Cout;
+      bmask = 0;
 #pragma unroll
       for (int e = 0; e < BROWS; ++e) {
-        float v = 0.f;
-        if (cvalid && k + e < K) {
-          int kh = s_tab[2 + t / ntw], kw = s_tab[12 + t % ntw];
-          int th = hi0 - kh * a.dil, tw = wi0 - kw * a.dil;
-          if (th >= 0 && tw >= 0) {
-            int ho = th / a.stride, wo = tw / a.stride;
-            if (ho < a.Ho && wo < a.Wo) v = a.dy[nbdy + (long long)co * HoWo + ho * a.Wo + wo];
-          }
-        }
-        breg[e] = v;
+        const bool kok = k + e < K;
+        const int tt = kok ? t : 0;
+        const int kh = __builtin_amdgcn_readfirstlane(s_tab[2 + tt / ntw]);
+        const int kw = __builtin_amdgcn_readfirstlane(s_tab[12 + tt % ntw]);
+        const int th = hi0 - kh * a.dil, tw = wi0 - kw * a.dil;
+        const int ho = th >> a.lstride, wo = tw >> a.lstride;   // exact: the parity class makes th,tw multiples of stride
+        const bool ok = cvalid && kok && th >= 0 && tw >= 0 && ho < a.Ho && wo < a.Wo;
+        const float* yc = a.dy + (long long)co * HoWo;       // uniform pointer
+        braw[e] = yc[nbdy + (ok ? ho * a.Wo + wo : 0)];
+        bmask |= (unsigned)ok << e;
         if (++co == a.Cout) { co = 0; ++t; }
       }
     } else {  // WGRAD: thread owns one pixel row (p_local) and AE/BE strided columns
@@ -218,39 +256,75 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
       long long b0 = (long long)n * a.C0 * srcHW, b1 = (long long)n * a.C1 * srcHW;
       long long bdy = (long long)n * a.Cout * HoWo + hw;
       const int grp = tid / BK;
+      amask = pv ? 0xffffffffu : 0u;
 #pragma unroll
       for (int e = 0; e < AE; ++e) {
-        int co = m0 + grp + PG * e;
-        areg[e] = (pv && co < M) ? a.dy[bdy + (long long)co * HoWo] : 0.f;
+        int co = min(m0 + grp + PG * e, M - 1);   // rows >= M are never stored by the epilogue
+        areg[e] = a.dy[bdy + (long long)co * HoWo];
       }
+      bmask = 0;
 #pragma unroll
       for (int e = 0; e < BE; ++e) {
         int tab = s_tab[grp + PG * e];
-        float v = 0.f;
-        if (pv && tab >= 0) {
-          int ci = tab & 0xffff, hi = hb + ((tab >> 16) & 0xff), wi = wb + ((tab >> 24) & 0xff);
-          if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) v = load_virtual(a, b0, b1, ci, hi, wi);
+        int tt = tab >= 0 ? tab : 0;
+        int ci = tt & 0xffff, hi = hb + ((tt >> 16) & 0xff), wi = wb + ((tt >> 24) & 0xff);
+        bool ok = pv && tab >= 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        if (a.up2x) {
+          braw[e] = ok ? load_virtual(a, b0, b1, ci, hi, wi) : 0.f;
+        } else {
+          bool first = ci < a.C0;
+          int c = first ? ci : ci - a.C0;
+          const float* xb = first ? a.x0 + b0 : a.x1 + b1;
+          int off = ok ? hi * a.Ws + wi : 0;
+          braw[e] = xb[(long long)c * srcHW + off];
         }
-        breg[e] = v;
+        bmask |= (unsigned)ok << e;
       }
     }
   };
 
-  auto store_tile = [&](int buf) {
-    if (MODE != M_WGRAD) {
+  auto finish = [&](int buf) {
+    if (MODE == M_FWD) {
 #pragma unroll
       for (int e = 0; e < AV; ++e) {
         int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
         *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = areg4[e];
       }
 #pragma unroll
-      for (int e = 0; e < BROWS; ++e) Bs[buf][brow0 + e][bcol] = breg[e];
+      for (int e = 0; e < BROWS; ++e) {
+        float v = braw[e];
+        if (!a.up2x) {
+          bool first = (bfirst >> e) & 1u;
+          if (first ? has0 : has1) v = fmaf(v, bsc[e], bsh[e]);
+          v = act_apply(v, first ? a.act0 : a.act1);
+        }
+        Bs[buf][brow0 + e][bcol] = ((bmask >> e) & 1u) ? v : 0.f;
+      }
+    } else if (MODE == M_DGRAD) {
+#pragma unroll
+      for (int e = 0; e < AV; ++e) {
+        int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
+        float4 v = areg4[e];
+        if (!((amask >> e) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = v;
+      }
+#pragma unroll
+      for (int e = 0; e < BROWS; ++e) Bs[buf][brow0 + e][bcol] = ((bmask >> e) & 1u) ? braw[e] : 0.f;
     } else {
       const int pl = tid % BK, grp = tid / BK;
 #pragma unroll
-      for (int e = 0; e < AE; ++e) As[buf][pl][grp + PG * e] = areg[e];
+      for (int e = 0; e < AE; ++e) As[buf][pl][grp + PG * e] = amask ? areg[e] : 0.f;
 #pragma unroll
-      for (int e = 0; e < BE; ++e) Bs[buf][pl][grp + PG * e] = breg[e];
+      for (int e = 0; e < BE; ++e) {
+        float v = braw[e];
+        if (!a.up2x) {
+          int col = grp + PG * e;
+          int code = s_code[col];   // bit0: affine present, bits1-2: activation
+          if (code & 1) v = fmaf(v, s_sc[col], s_sh[col]);
+          v = act_apply(v, code >> 1);
+        }
+        Bs[buf][pl][grp + PG * e] = ((bmask >> e) & 1u) ? v : 0.f;
+      }
     }
   };
 
@@ -263,14 +337,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (nK > 0) {
-    load_tile(0);
-    store_tile(0);
+    issue(0);
+    finish(0);
   }
   __syncthreads();
   const int li = lane & 31, lk = lane >> 5;
   for (int kt = 0; kt < nK; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nK) load_tile(kt + 1);
+    if (kt + 1 < nK) issue(kt + 1);
 #pragma unroll
     for (int k2 = 0; k2 < BK / 2; ++k2) {
       float av[TM], bv[TN];
@@ -283,7 +357,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nK) store_tile(buf ^ 1);
+    if (kt + 1 < nK) finish(buf ^ 1);
     __syncthreads();
   }
 
@@ -307,11 +381,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
     }
   }
   const long long rstride = (MODE == M_FWD) ? HoWo : (MODE == M_DGRAD ? HW : Ncols);
+  const bool want_stats = (MODE == M_FWD) && a.stats != nullptr;
+  // per-row partial sums of this wave go to LDS (the operand tiles are dead after the last barrier),
+  // so each workgroup issues ONE pair of double atomics per output channel
+  float* s_sum = &As[0][0][0];   // [WN][BM]
+  float* s_sq = &Bs[0][0][0];    // [WN][BM]
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      int lrow = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      int row = m0 + lrow;
       bool rok = row < M;
       float bias = (MODE == M_FWD && a.bias && rok) ? a.bias[row] : 0.f;
       float s = 0.f, q = 0.f;
@@ -324,13 +404,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
           q += v * v;
         }
       }
-      if (MODE == M_FWD && a.stats) {
+      if (want_stats) {
         s = half_sum(s);
         q = half_sum(q);
-        if (li == 0 && rok) {
-          atomicAdd(&a.stats[row], (double)s);
-          atomicAdd(&a.stats[M + row], (double)q);
+        if (li == 0) {
+          s_sum[wn * BM + lrow] = s;
+          s_sq[wn * BM + lrow] = q;
         }
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int rr = tid; rr < BM; rr += 256) {
+      int row = m0 + rr;
+      if (row < M) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) { s += s_sum[w * BM + rr]; q += s_sq[w * BM + rr]; }
+        atomicAdd(&a.stats[row], (double)s);
+        atomicAdd(&a.stats[M + row], (double)q);
       }
     }
   }
@@ -476,6 +569,8 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   a.wp = w_packed_dgrad; a.wp_ld = packed_ld(d, 1); a.dy = dy; a.out = dx;
   a.M = d->Cin;
   const int s = d->stride;
+  if (s != 1 && s != 2 && s != 4) return AVSEP_ERR_ARG;
+  a.lstride = s == 1 ? 0 : (s == 2 ? 1 : 2);
   long long ncols = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);  // largest parity class
   if ((long long)d->N * d->H * d->W > 0x7fffffffLL) return AVSEP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;

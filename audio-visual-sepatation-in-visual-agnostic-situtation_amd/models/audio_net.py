@@ -81,7 +81,7 @@ class _Level(nn.Module):
 
 class Unet(nn.Module):
     def __init__(self, fc_dim=64, num_downs=5, ngf=64, use_dropout=False, fusion_type="con_motion",
-                 att_type="cos", fuse_upsample=True):
+                 att_type="cos", fuse_upsample=False):
         super().__init__()
         if use_dropout:
             raise NotImplementedError("use_dropout is never enabled by the reference builders")
