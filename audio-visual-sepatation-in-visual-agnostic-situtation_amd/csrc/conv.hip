@@ -480,6 +480,11 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// direct.hip: VALU kernels for convolutions with <= 4 output channels (3x3, stride 1)
+bool smallco_applicable(const avsep_conv_desc* d);
+int smallco_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* bias, float* y, hipStream_t st);
+size_t smallco_wgrad_workspace_floats(const avsep_conv_desc* d);
+int smallco_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st);
 static int check_desc(const avsep_conv_desc* d, bool fwd_only = false) {
   if (!d || !d->x0) return AVSEP_ERR_ARG;
   if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return AVSEP_ERR_ARG;
@@ -542,6 +547,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   int rc = check_desc(d, true);
   if (rc) return rc;
   if (!w_packed || !y) return AVSEP_ERR_ARG;
+  if (!stats && smallco_applicable(d)) return smallco_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.wp = w_packed; a.wp_ld = packed_ld(d, 0); a.out = y; a.bias = bias; a.stats = stats;
   a.M = d->Cout; a.K = d->Cin * d->KH * d->KW;
@@ -611,6 +617,7 @@ static WgradPlan wgrad_plan(const avsep_conv_desc* d) {
 
 extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (check_desc(d)) return 0;
+  if (smallco_applicable(d)) return smallco_wgrad_workspace_floats(d) * sizeof(float);
   WgradPlan p = wgrad_plan(d);
   if (p.splits <= 1) return 0;
   return (size_t)p.splits * d->Cout * d->Cin * d->KH * d->KW * sizeof(float);
@@ -624,6 +631,7 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   WgradPlan p = wgrad_plan(d);
   size_t need = avsep_conv2d_wgrad_workspace_bytes(d);
   if (need > workspace_bytes || (need && !workspace)) return AVSEP_ERR_WORKSPACE;
+  if (smallco_applicable(d)) return smallco_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.dy = dy;
   a.M = d->Cout; a.Ncols = d->Cin * d->KH * d->KW; a.K = 0;

@@ -26,7 +26,9 @@ CONV_CASES = [
     (2, 32, 15, 15, 48, 3, 2, 1, 1),       # 3x3 stride 2, odd size
     (2, 32, 14, 14, 64, 1, 2, 0, 1),       # 1x1 stride 2 downsample
     (4, 256, 4, 4, 256, 4, 2, 1, 1),       # deep, tiny spatial
-    (1, 20, 12, 12, 2, 3, 1, 1, 1),        # Cout = 2 (last U-Net conv)
+    (1, 20, 12, 16, 2, 3, 1, 1, 1),        # Cout = 2 (last U-Net conv) -> direct small-Cout kernels
+    (2, 37, 21, 144, 2, 3, 1, 1, 1),       # same path: ragged H, W > one 128 tile, Cin not a multiple of the chunk
+    (2, 16, 10, 10, 3, 3, 1, 1, 1),        # W % 16 != 0 -> falls back to the MFMA path
 ]
 
 
@@ -47,6 +49,7 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     st = K.zeros_stats(Cout, xd)
     y = cv.fwd(cv.pack(wd, 0), bd, st)
     assert_close(y, y_ref, 2e-5, "fwd")
+    assert_close(cv.fwd(cv.pack(wd, 0), bd, None), y_ref, 2e-5, "fwd without stats (direct path when Cout <= 4)")
     st_ref = torch.cat([y_ref.double().sum((0, 2, 3)), (y_ref.double() ** 2).sum((0, 2, 3))])
     assert_close(st, st_ref, 1e-5, "stats")
     dx = cv.dgrad(cv.pack(wd, 1), dyd)
