@@ -485,6 +485,12 @@ bool smallco_applicable(const avsep_conv_desc* d);
 int smallco_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* bias, float* y, hipStream_t st);
 size_t smallco_wgrad_workspace_floats(const avsep_conv_desc* d);
 int smallco_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st);
+// conv3x3.hip: LDS-halo-patch kernel for 3x3 / stride 1 / pad 1 (forward, and dgrad through flipped weights)
+bool c3_applicable(const avsep_conv_desc* d, int mode);
+size_t c3_packed_floats(const avsep_conv_desc* d, int mode);
+int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
+int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st);
+int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
 static int check_desc(const avsep_conv_desc* d, bool fwd_only = false) {
   if (!d || !d->x0) return AVSEP_ERR_ARG;
   if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return AVSEP_ERR_ARG;
@@ -523,12 +529,14 @@ static inline int packed_ld(const avsep_conv_desc* d, int mode) { return roundup
 
 extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
   if (!d || (mode != 0 && mode != 1)) return 0;
+  if (c3_applicable(d, mode)) return c3_packed_floats(d, mode);
   return (size_t)packed_rows(d, mode) * packed_ld(d, mode);
 }
 
 extern "C" int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w, float* packed, int mode,
                                        avsep_stream_t stream) {
   if (!d || !w || !packed || (mode != 0 && mode != 1)) return AVSEP_ERR_ARG;
+  if (c3_applicable(d, mode)) return c3_pack(d, w, packed, mode, (hipStream_t)stream);
   int rows = packed_rows(d, mode), ld = packed_ld(d, mode);
   long long total = (long long)rows * ld;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed,
@@ -548,6 +556,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   if (rc) return rc;
   if (!w_packed || !y) return AVSEP_ERR_ARG;
   if (!stats && smallco_applicable(d)) return smallco_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
+  if (c3_applicable(d, 0)) return c3_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.wp = w_packed; a.wp_ld = packed_ld(d, 0); a.out = y; a.bias = bias; a.stats = stats;
   a.M = d->Cout; a.K = d->Cin * d->KH * d->KW;
@@ -571,6 +580,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   int rc = check_desc(d);
   if (rc) return rc;
   if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
+  if (c3_applicable(d, 1)) return c3_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.wp = w_packed_dgrad; a.wp_ld = packed_ld(d, 1); a.dy = dy; a.out = dx;
   a.M = d->Cin;

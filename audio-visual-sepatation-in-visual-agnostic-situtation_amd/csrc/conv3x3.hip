@@ -1,0 +1,324 @@
+// 3x3 / stride 1 / pad 1 convolution on the f32 MFMA with an LDS halo patch ("v2" path).
+// These are the U-Net decoder convs (audio_net.py:75-76,85-87,96-98,180-182): 77 % of the U-Net's MACs.
+//
+// Instead of gathering an im2col operand (every input element fetched and transformed 9 times, with
+// per-element address arithmetic that out-weighs the 64-cycle f32 MFMA), a workgroup stages, per chunk of
+// CK input channels, the (TH+2)x(TW+2) input halo patch of its TH x TW output tile ONCE — the folded
+// BatchNorm affine, ReLU, the two-source skip concat and the optional bilinear x2 upsample are applied
+// while staging — and the MFMA loop reads both operands from LDS with immediate offsets:
+//   K order is (channel pair, tap, channel parity); lane half (lane>>5) selects the parity, so the B
+//   operand address is  lane_base(pixel, parity) + const(pair, tap)  — zero VALU per operand.
+// The same kernel computes the data gradient (a 3x3/s1/p1 conv of dY with flipped, transposed weights):
+// only the weight packing differs.  D[co][pix], pixels on the lanes -> coalesced NCHW stores.
+#include "common.h"
+
+struct C3Args {
+  int N, Cin, H, W, Cout;
+  int C0, C1, act0, act1, up2x, Hs, Ws;
+  float rh, rw;
+  const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
+  const float* wp;
+  int wp_ld;
+  float* out;
+  const float* bias;
+  double* stats;
+  int tilesX, tilesY, gridM;
+};
+
+constexpr int C3_CK = 4;            // input channels per K-tile
+constexpr int C3_KT = C3_CK * 9;    // 36 GEMM-K rows per K-tile
+
+__device__ __forceinline__ float c3_src(const C3Args& a, int n, int c, int hs, int ws) {
+  float v;
+  if (c < a.C0) {
+    v = a.x0[(((long long)n * a.C0 + c) * a.Hs + hs) * a.Ws + ws];
+    if (a.sc0) v = fmaf(v, a.sc0[c], a.sh0[c]);
+    v = act_apply(v, a.act0);
+  } else {
+    int c1 = c - a.C0;
+    v = a.x1[(((long long)n * a.C1 + c1) * a.Hs + hs) * a.Ws + ws];
+    if (a.sc1) v = fmaf(v, a.sc1[c1], a.sh1[c1]);
+    v = act_apply(v, a.act1);
+  }
+  return v;
+}
+
+template <int TH, int TW, int BM>
+__global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
+  constexpr int PH = TH + 2, PW = TW + 2, PS = PH * PW;   // patch per channel
+  constexpr int LDA = BM + 4;
+  constexpr int NPATCH = C3_CK * PS;
+  constexpr int PE = (NPATCH + 255) / 256;                // patch elements per thread
+  constexpr int A4 = BM / 4, NA4 = C3_KT * A4, AE = (NA4 + 255) / 256;
+  constexpr int WTM = BM / 2, TM = WTM / 32;              // waves 2 (M) x 2 (N); wave N-tile = 64 pixels
+  __shared__ __attribute__((aligned(16))) float As[2][C3_KT][LDA];
+  __shared__ float Ps[2][NPATCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  // block -> (pixel tile, image, M tile); consecutive logical ids share the pixel tile (same XCD L2)
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = t % a.gridM; t /= a.gridM;
+  const int tx = t % a.tilesX; t /= a.tilesX;
+  const int ty = t % a.tilesY;
+  const int n = t / a.tilesY;
+  const int h0 = ty * TH, w0 = tx * TW, m0 = mt * BM;
+
+  // ---- loader state: patch element e of this thread is flat index tid + 256*e = (c, r, col) ----
+  // issue(): branch-free address math + unconditional loads (clamped coordinates) into registers;
+  // finish(): affine + activation (+ bilinear blend) + zero masking + LDS stores, after the MFMA loop.
+  constexpr int NRAW = 4;                                 // up2x needs the 4 bilinear corners
+  float praw[PE][NRAW], psc[PE], psh[PE], plh[PE], plw[PE];
+  unsigned pok = 0, pfirst = 0;
+  float4 areg[AE];
+  const bool has0 = a.sc0 != nullptr, has1 = a.sc1 != nullptr;
+  const long long sHW = (long long)a.Hs * a.Ws;
+
+  auto issue = [&](int kt) {
+    const int cbase = kt * C3_CK;
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      int idx = tid + 256 * e;
+      if (AE * 256 == NA4 || idx < NA4) {
+        int row = idx / A4, c4 = idx % A4;
+        areg[e] = *reinterpret_cast<const float4*>(a.wp + (long long)(kt * C3_KT + row) * a.wp_ld + m0 + c4 * 4);
+      }
+    }
+    pok = 0;
+    pfirst = 0;
+#pragma unroll
+    for (int e = 0; e < PE; ++e) {
+      int idx = min(tid + 256 * e, NPATCH - 1);
+      int cc = idx / PS, r = (idx % PS) / PW, col = idx % PW;
+      int gh = h0 - 1 + r, gw = w0 - 1 + col, c = cbase + cc;
+      bool ok = (PE * 256 == NPATCH || tid + 256 * e < NPATCH) && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+      int ghc = min(max(gh, 0), a.H - 1), gwc = min(max(gw, 0), a.W - 1);
+      bool first = c < a.C0;
+      int cs = first ? c : c - a.C0;
+      const float* xb = (first ? a.x0 : a.x1) + ((long long)n * (first ? a.C0 : a.C1) + cs) * sHW;
+      if (!a.up2x) {   // kernel-uniform
+        praw[e][0] = xb[ghc * a.Ws + gwc];
+      } else {         // nn.Upsample(x2, bilinear, align_corners=True): src = dst*(in-1)/(out-1)
+        float fh = a.rh * (float)ghc, fw = a.rw * (float)gwc;
+        int hh0 = (int)fh, ww0 = (int)fw;
+        int hh1 = hh0 + (hh0 < a.Hs - 1), ww1 = ww0 + (ww0 < a.Ws - 1);
+        plh[e] = fh - (float)hh0;
+        plw[e] = fw - (float)ww0;
+        praw[e][0] = xb[hh0 * a.Ws + ww0];
+        praw[e][1] = xb[hh0 * a.Ws + ww1];
+        praw[e][2] = xb[hh1 * a.Ws + ww0];
+        praw[e][3] = xb[hh1 * a.Ws + ww1];
+      }
+      bool has = first ? has0 : has1;
+      const float* sp = has ? (first ? a.sc0 : a.sc1) : a.x0;
+      const float* hp = has ? (first ? a.sh0 : a.sh1) : a.x0;
+      psc[e] = sp[has ? cs : 0];
+      psh[e] = hp[has ? cs : 0];
+      pok |= (unsigned)ok << e;
+      pfirst |= (unsigned)first << e;
+    }
+  };
+  auto finish = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      int idx = tid + 256 * e;
+      if (AE * 256 == NA4 || idx < NA4) {
+        int row = idx / A4, c4 = idx % A4;
+        *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = areg[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < PE; ++e) {
+      int idx = tid + 256 * e;
+      const bool first = (pfirst >> e) & 1u;
+      const bool has = first ? has0 : has1;
+      const int act = first ? a.act0 : a.act1;
+      float v;
+      if (!a.up2x) {
+        v = praw[e][0];
+        if (has) v = fmaf(v, psc[e], psh[e]);
+        v = act_apply(v, act);
+      } else {
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float t = praw[e][k];
+          if (has) t = fmaf(t, psc[e], psh[e]);
+          q[k] = act_apply(t, act);
+        }
+        v = (1.f - plh[e]) * ((1.f - plw[e]) * q[0] + plw[e] * q[1]) + plh[e] * ((1.f - plw[e]) * q[2] + plw[e] * q[3]);
+      }
+      if (PE * 256 == NPATCH || idx < NPATCH) Ps[buf][idx] = ((pok >> e) & 1u) ? v : 0.f;
+    }
+  };
+
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // B operand lane base for the wave's two 32-pixel MFMA column tiles (+ channel parity from the lane half)
+  int lb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int p = wn * 64 + j * 32 + li;
+    lb[j] = (p / TW) * PW + (p % TW) + lk * PS;
+  }
+  const int nK = a.Cin / C3_CK;
+  issue(0);
+  finish(0);
+  __syncthreads();
+  for (int kt = 0; kt < nK; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nK) issue(kt + 1);
+    const float* P = Ps[buf];
+#pragma unroll
+    for (int k2 = 0; k2 < C3_KT / 2; ++k2) {
+      const int cp = k2 / 9, tap = k2 % 9;                          // compile-time after unrolling
+      const int koff = (2 * cp) * PS + (tap / 3) * PW + (tap % 3);
+      float av[TM], bv[2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = As[buf][2 * k2 + lk][wm * WTM + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = P[lb[j] + koff];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nK) finish(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
+  const long long HW = (long long)a.H * a.W;
+  long long cbase[2];
+  bool cok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int p = wn * 64 + j * 32 + li;
+    int gh = h0 + p / TW, gw = w0 + p % TW;
+    cok[j] = gh < a.H && gw < a.W;
+    cbase[j] = (long long)n * a.Cout * HW + (long long)gh * a.W + gw;
+  }
+  const bool want_stats = a.stats != nullptr;
+  float* s_sum = &As[0][0][0];   // [2][BM] per-wave-column partial sums (operand tiles are dead now)
+  float* s_sq = &As[1][0][0];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int lrow = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      int row = m0 + lrow;
+      bool rok = row < a.Cout;
+      float bias = (a.bias && rok) ? a.bias[row] : 0.f;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v = acc[i][j][r] + bias;
+        if (rok && cok[j]) {
+          a.out[cbase[j] + (long long)row * HW] = v;
+          s += v;
+          q += v * v;
+        }
+      }
+      if (want_stats) {
+        s = half_sum(s);
+        q = half_sum(q);
+        if (li == 0) {
+          s_sum[wn * BM + lrow] = s;
+          s_sq[wn * BM + lrow] = q;
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int rr = tid; rr < BM; rr += 256) {
+      int row = m0 + rr;
+      if (row < a.Cout) {
+        atomicAdd(&a.stats[row], (double)(s_sum[rr] + s_sum[BM + rr]));
+        atomicAdd(&a.stats[a.Cout + row], (double)(s_sq[rr] + s_sq[BM + rr]));
+      }
+    }
+  }
+}
+
+// weight packing for this path.  Rows r = ((cpair*9 + tap)*2 + parity), column = output channel.
+//   mode 0 (forward): in-channel ci = 2*cpair+parity, value w[co][ci][tap],          column co
+//   mode 1 (dgrad)  : "in"-channel co = 2*cpair+parity, value w[co][ci][8 - tap],    column ci
+__global__ void c3_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int rows, int ld,
+                               int mode) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * ld) return;
+  int row = (int)(i / ld), col = (int)(i % ld);
+  int parity = row & 1, q = row >> 1, tap = q % 9, ch = 2 * (q / 9) + parity;
+  float v = 0.f;
+  if (mode == 0) {
+    if (ch < Cin && col < Cout) v = w[((long long)col * Cin + ch) * 9 + tap];
+  } else {
+    if (ch < Cout && col < Cin) v = w[((long long)ch * Cin + col) * 9 + (8 - tap)];
+  }
+  out[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// host side (called from conv.hip)
+// ---------------------------------------------------------------------------
+// forward: needs Cin % 4 == 0 and the source split on a chunk boundary; dgrad: Cout % 4 == 0
+bool c3_applicable(const avsep_conv_desc* d, int mode) {
+  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1)) return false;
+  if (d->W < 16 || d->H < 4 || d->N > 65535) return false;
+  if (mode == 0) return d->Cin % C3_CK == 0 && d->C0 % C3_CK == 0 && d->Cout > 4;
+  return d->Cout % C3_CK == 0 && d->Cin >= 32;
+}
+size_t c3_packed_floats(const avsep_conv_desc* d, int mode) {
+  int rows = (mode == 0 ? d->Cin : d->Cout) * 9, ld = roundup(mode == 0 ? d->Cout : d->Cin, 128);
+  return (size_t)rows * ld;
+}
+int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st) {
+  int rows = (mode == 0 ? d->Cin : d->Cout) * 9, ld = roundup(mode == 0 ? d->Cout : d->Cin, 128);
+  long long total = (long long)rows * ld;
+  hipLaunchKernelGGL(c3_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, packed, d->Cout, d->Cin, rows, ld, mode);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+static int c3_launch(C3Args& a, hipStream_t st) {
+  const bool narrow = a.Cout <= 64;            // 64-row tiles when the GEMM M dimension is small
+  a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
+  const bool wide = a.W >= 32;
+  a.tilesX = cdiv(a.W, wide ? 32 : 16);
+  a.tilesY = cdiv(a.H, wide ? 4 : 8);
+  dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
+  if (wide && !narrow) hipLaunchKernelGGL((conv3x3_kernel<4, 32, 128>), grid, dim3(256), 0, st, a);
+  else if (wide) hipLaunchKernelGGL((conv3x3_kernel<4, 32, 64>), grid, dim3(256), 0, st, a);
+  else if (!narrow) hipLaunchKernelGGL((conv3x3_kernel<8, 16, 128>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv3x3_kernel<8, 16, 64>), grid, dim3(256), 0, st, a);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st) {
+  C3Args a{};
+  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = d->up2x;
+  a.Hs = d->up2x ? d->H / 2 : d->H; a.Ws = d->up2x ? d->W / 2 : d->W;
+  a.rh = (d->up2x && d->H > 1) ? (float)(a.Hs - 1) / (float)(d->H - 1) : 0.f;
+  a.rw = (d->up2x && d->W > 1) ? (float)(a.Ws - 1) / (float)(d->W - 1) : 0.f;
+  a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
+  a.wp = wp; a.wp_ld = roundup(d->Cout, 128); a.out = y; a.bias = bias; a.stats = stats;
+  return c3_launch(a, st);
+}
+
+// dX[N,Cin,H,W] = conv3x3(dY[N,Cout,H,W], flipped/transposed weights)
+int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st) {
+  C3Args a{};
+  a.N = d->N; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
+  a.C0 = d->Cout; a.C1 = 0; a.Hs = d->H; a.Ws = d->W;
+  a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
+  return c3_launch(a, st);
+}

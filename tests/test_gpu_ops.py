@@ -20,6 +20,8 @@ CONV_CASES = [
     (2, 1, 32, 32, 64, 4, 2, 1, 1),        # U-Net d1 shape family
     (2, 64, 16, 16, 128, 4, 2, 1, 1),
     (3, 96, 8, 8, 40, 3, 1, 1, 1),         # ragged channel counts
+    (2, 64, 12, 40, 136, 3, 1, 1, 1),      # 3x3 halo-patch path, 4x32 tiles, ragged H/W/Cout
+    (2, 36, 19, 20, 48, 3, 1, 1, 1),       # 3x3 halo-patch path, 8x16 tiles, 64-row M tile
     (2, 160, 10, 6, 130, 3, 1, 1, 1),      # > one 128 tile in M, odd spatial
     (2, 3, 30, 30, 64, 7, 2, 3, 1),        # resnet stem
     (2, 32, 14, 14, 48, 3, 1, 2, 2),       # dilated
@@ -59,12 +61,13 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert_close(db, dy.sum((0, 2, 3)), 2e-5, "dbias")
 
 
-@pytest.mark.parametrize("up2x", [False, True])
-def test_conv_virtual_input(dev, up2x):
-    """two-source concat + per-channel affine + LeakyReLU/ReLU (+ bilinear x2) folded into the gather."""
+@pytest.mark.parametrize("up2x,H,W", [(False, 9, 7), (True, 9, 7), (False, 10, 36), (True, 10, 18), (True, 6, 10)])
+def test_conv_virtual_input(dev, up2x, H, W):
+    """two-source concat + per-channel affine + LeakyReLU/ReLU (+ bilinear x2) folded into the gather;
+    the larger sizes go through the 3x3 halo-patch kernel, the small ones through the im2col gather."""
     K = _pkg().kernels
     g = torch.Generator().manual_seed(5)
-    N, C0, C1, H, W, Cout = 2, 24, 40, 9, 7, 36
+    N, C0, C1, Cout = 2, 24, 40, 36
     x0, x1 = torch.randn(N, C0, H, W, generator=g), torch.randn(N, C1, H, W, generator=g)
     sc0, sh0 = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g)
     sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g)
