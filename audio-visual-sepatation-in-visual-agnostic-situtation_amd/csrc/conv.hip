@@ -491,6 +491,9 @@ size_t c3_packed_floats(const avsep_conv_desc* d, int mode);
 int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
 int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st);
 int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
+bool w3_applicable(const avsep_conv_desc* d);
+size_t w3_workspace_floats(const avsep_conv_desc* d);
+int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 static int check_desc(const avsep_conv_desc* d, bool fwd_only = false) {
   if (!d || !d->x0) return AVSEP_ERR_ARG;
   if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return AVSEP_ERR_ARG;
@@ -628,6 +631,7 @@ static WgradPlan wgrad_plan(const avsep_conv_desc* d) {
 extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (check_desc(d)) return 0;
   if (smallco_applicable(d)) return smallco_wgrad_workspace_floats(d) * sizeof(float);
+  if (w3_applicable(d)) return w3_workspace_floats(d) * sizeof(float);
   WgradPlan p = wgrad_plan(d);
   if (p.splits <= 1) return 0;
   return (size_t)p.splits * d->Cout * d->Cin * d->KH * d->KW * sizeof(float);
@@ -642,6 +646,16 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   size_t need = avsep_conv2d_wgrad_workspace_bytes(d);
   if (need > workspace_bytes || (need && !workspace)) return AVSEP_ERR_WORKSPACE;
   if (smallco_applicable(d)) return smallco_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
+  if (w3_applicable(d)) {
+    int rc3 = w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
+    if (rc3) return rc3;
+    if (dbias) {
+      hipLaunchKernelGGL(channel_sum_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, dy, d->N, d->Cout,
+                         d->Ho * d->Wo, dbias);
+      AVSEP_LAUNCH_CHECK();
+    }
+    return AVSEP_OK;
+  }
   CArgs a = make_args(d);
   a.dy = dy;
   a.M = d->Cout; a.Ncols = d->Cin * d->KH * d->KW; a.K = 0;

@@ -322,3 +322,221 @@ int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
   a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
   return c3_launch(a, st);
 }
+
+// ===========================================================================
+// Weight gradient of the 3x3/s1/p1 conv with the same LDS halo patch.
+//   dW[co][ci][tap] = sum_pix dY[co][pix] * X[ci][pix + tap]
+// GEMM: M = co (128 per workgroup), N = (tap, ci) with 32 input channels on the lanes and the 9 taps as
+// 9 MFMA column tiles, K = pixels of a TH x TW tile (MFMA lane half = pixel parity).  8 waves: wave w owns
+// output rows [32(w&3), +32) x taps {0..4} (w<4) or {5..8} (w>=4) — waves w and w+4 share a SIMD, so every
+// SIMD carries 9 MFMAs per k-step; <=80 accumulator registers leave room for 2 workgroups (4 waves/SIMD).
+// Per k-step 1 A read + 4-5 B reads; every B address is  lane*PS + parity + const(tap, pixel pair).
+// A workgroup sweeps `tiles_per_split` pixel tiles and writes one partial slab; a reduce kernel sums the
+// slabs (deterministic, no atomics).
+// ===========================================================================
+struct W3Args {
+  int N, Cin, H, W, Cout;
+  int C0, C1, act0, act1, up2x, Hs, Ws;
+  float rh, rw;
+  const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
+  const float* dy;
+  float* out;
+  int tilesX, tilesY, gridM, gridC, tiles_per_split;
+};
+
+constexpr int W3_CC = 32;   // input channels per workgroup (one MFMA column tile per tap)
+
+__device__ __forceinline__ float w3_src(const W3Args& a, int n, int c, int hs, int ws) {
+  float v;
+  if (c < a.C0) {
+    v = a.x0[(((long long)n * a.C0 + c) * a.Hs + hs) * a.Ws + ws];
+    if (a.sc0) v = fmaf(v, a.sc0[c], a.sh0[c]);
+    v = act_apply(v, a.act0);
+  } else {
+    int c1 = c - a.C0;
+    v = a.x1[(((long long)n * a.C1 + c1) * a.Hs + hs) * a.Ws + ws];
+    if (a.sc1) v = fmaf(v, a.sc1[c1], a.sh1[c1]);
+    v = act_apply(v, a.act1);
+  }
+  return v;
+}
+
+template <int TH, int TW, bool UP2X, int BM>
+__global__ __launch_bounds__(512, 4) void wgrad3x3_kernel(W3Args a) {
+  constexpr int NPIX = TH * TW, PH = TH + 2, PW = TW + 2;
+  constexpr int PS = (PH * PW) | 1;                       // odd per-channel stride: lanes = channels -> no bank conflicts
+  constexpr int LDA = NPIX + 1;
+  constexpr int NT = 512;
+  constexpr int NP = W3_CC * PH * PW, PE = (NP + NT - 1) / NT;
+  constexpr int NA4 = BM * NPIX / 4, AE = NA4 / NT;
+  static_assert(NA4 % NT == 0, "A tile must split evenly");
+  __shared__ float As[BM * LDA];
+  __shared__ float Ps[W3_CC * PS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+  const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
+  const int m0 = mt * BM, c0 = ct * W3_CC;
+  const int tiles_img = a.tilesX * a.tilesY, tiles_all = tiles_img * a.N;
+  const int t_begin = split * a.tiles_per_split, t_end = min(tiles_all, t_begin + a.tiles_per_split);
+  const long long HW = (long long)a.H * a.W;
+
+  // BM=128: 4 row blocks x tap groups {0-4},{5-8};  BM=64: 2 row blocks x tap groups {0-2},{3,4},{5,6},{7,8}
+  constexpr int RB = BM / 32, MAXT = (BM == 128) ? 5 : 3;
+  const int wrow = wave % RB, tg = wave / RB;
+  const int tap0 = __builtin_amdgcn_readfirstlane(BM == 128 ? (tg ? 5 : 0) : (tg == 0 ? 0 : 1 + 2 * tg));
+  const int ntap = __builtin_amdgcn_readfirstlane(BM == 128 ? (tg ? 4 : 5) : (tg == 0 ? 3 : 2));
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // No register prefetch here: the 144 accumulators leave no room for it.  Staging goes straight to LDS and
+  // the two resident workgroups of a CU overlap each other's staging and MFMA phases.
+  auto stage_tile = [&](int t) {
+    const int n = t / tiles_img, tt = t % tiles_img, h0 = (tt / a.tilesX) * TH, w0 = (tt % a.tilesX) * TW;
+    // dY tile: rows = output channels, TW-contiguous pixel segments (float4, W % 4 == 0 and TW % 4 == 0)
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      int idx = tid + NT * e;
+      int q = idx % (TW / 4), r = (idx / (TW / 4)) % TH, co = idx / (NPIX / 4);
+      int gh = h0 + r, gw = w0 + 4 * q, row = min(m0 + co, a.Cout - 1);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gh < a.H && gw < a.W && m0 + co < a.Cout)
+        v = *reinterpret_cast<const float4*>(a.dy + ((long long)n * a.Cout + row) * HW + (long long)gh * a.W + gw);
+      float* d = &As[co * LDA + r * TW + 4 * q];
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+#pragma unroll 3
+    for (int e = 0; e < PE; ++e) {
+      int idx = tid + NT * e;
+      float v = 0.f;
+      if (PE * NT == NP || idx < NP) {
+        int cc = idx / (PH * PW), r = (idx % (PH * PW)) / PW, col = idx % PW;
+        int gh = h0 - 1 + r, gw = w0 - 1 + col, c = c0 + cc;
+        if (c < a.Cin && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W) {
+          if (!UP2X) {
+            v = w3_src(a, n, c, gh, gw);
+          } else {
+            float fh = a.rh * (float)gh, fw = a.rw * (float)gw;
+            int hh0 = (int)fh, ww0 = (int)fw;
+            int hh1 = hh0 + (hh0 < a.Hs - 1), ww1 = ww0 + (ww0 < a.Ws - 1);
+            float lh = fh - (float)hh0, lw = fw - (float)ww0;
+            float v00 = w3_src(a, n, c, hh0, ww0), v01 = w3_src(a, n, c, hh0, ww1);
+            float v10 = w3_src(a, n, c, hh1, ww0), v11 = w3_src(a, n, c, hh1, ww1);
+            v = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+          }
+        }
+      }
+      if (PE * NT == NP || idx < NP) Ps[(idx / (PH * PW)) * PS + idx % (PH * PW)] = v;
+    }
+  };
+
+  const float* Ap = As + (wrow * 32 + li) * LDA + lk;
+  // per-wave tap group folded into the base pointer: tap = tap0 + j, and (tap/3, tap%3) offsets are
+  // resolved per j below from the wave-uniform tap0
+  const float* Bp = Ps + li * PS + lk;
+  for (int t = t_begin; t < t_end; ++t) {
+    stage_tile(t);
+    __syncthreads();
+    // k-steps = pixel pairs; a modest unroll keeps the 144 accumulators + operands inside 256 registers
+    int toff[MAXT];                                         // wave-uniform (kh*PW + kw) per owned tap
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      int tp = min(tap0 + j, 8);
+      toff[j] = (tp / 3) * PW + (tp % 3);
+    }
+    for (int py = 0; py < TH; ++py) {
+      const float* ar = Ap + py * TW;
+      const float* br = Bp + py * PW;
+#pragma unroll 2
+      for (int px = 0; px < TW; px += 2) {
+        const float av = ar[px];
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+          if (j < ntap) {                                    // wave-uniform
+            const float bv = br[toff[j] + px];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // epilogue: row = output channel, MFMA column = input channel (lane), column tile = tap
+  const int ci = c0 + li;
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+    if (j < ntap) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int co = m0 + wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (co < a.Cout && ci < a.Cin)
+          a.out[(((long long)split * a.Cout + co) * a.Cin + ci) * 9 + tap0 + j] = acc[j][r];
+      }
+    }
+}
+
+bool w3_applicable(const avsep_conv_desc* d) {
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->W >= 16 && d->H >= 2 &&
+         (d->W & 3) == 0 && d->Cout > 4 && d->Cin >= 32 && d->N <= 65535;
+}
+
+struct W3Plan { int tilesX, tilesY, gridM, gridC, splits, tps; bool wide; };
+static W3Plan w3_plan(const avsep_conv_desc* d) {
+  W3Plan p;
+  p.wide = d->W >= 32;
+  p.tilesX = cdiv(d->W, p.wide ? 32 : 16);
+  p.tilesY = cdiv(d->H, p.wide ? 2 : 4);
+  p.gridM = cdiv(d->Cout, d->Cout <= 64 ? 64 : 128);
+  p.gridC = cdiv(d->Cin, W3_CC);
+  long long tiles = (long long)p.tilesX * p.tilesY * d->N;
+  int want = cdiv(768, p.gridM * p.gridC);                 // ~3 workgroups per CU in flight
+  long long maxs = tiles / 4 > 0 ? tiles / 4 : 1;           // at least 4 pixel tiles per slab
+  int splits = (int)(want < maxs ? want : maxs);
+  if (splits < 1) splits = 1;
+  p.tps = (int)((tiles + splits - 1) / splits);
+  p.splits = (int)((tiles + p.tps - 1) / p.tps);
+  return p;
+}
+size_t w3_workspace_floats(const avsep_conv_desc* d) {
+  W3Plan p = w3_plan(d);
+  return p.splits > 1 ? (size_t)p.splits * d->Cout * d->Cin * 9 : 0;
+}
+__global__ void w3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n, int S) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < S; ++z) s += ws[(long long)z * n + i];
+  out[i] = s;
+}
+int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st) {
+  W3Plan p = w3_plan(d);
+  W3Args a{};
+  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = d->up2x;
+  a.Hs = d->up2x ? d->H / 2 : d->H; a.Ws = d->up2x ? d->W / 2 : d->W;
+  a.rh = (d->up2x && d->H > 1) ? (float)(a.Hs - 1) / (float)(d->H - 1) : 0.f;
+  a.rw = (d->up2x && d->W > 1) ? (float)(a.Ws - 1) / (float)(d->W - 1) : 0.f;
+  a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
+  a.dy = dy; a.out = p.splits > 1 ? ws : dw;
+  a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.gridM = p.gridM; a.gridC = p.gridC; a.tiles_per_split = p.tps;
+  dim3 grid(p.gridM * p.gridC, p.splits);
+#define W3_LAUNCH(TH_, TW_, UP_)                                                                             \
+  do {                                                                                                     \
+    if (d->Cout <= 64) hipLaunchKernelGGL((wgrad3x3_kernel<TH_, TW_, UP_, 64>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((wgrad3x3_kernel<TH_, TW_, UP_, 128>), grid, dim3(512), 0, st, a);             \
+  } while (0)
+  if (p.wide && !d->up2x) W3_LAUNCH(2, 32, false);
+  else if (p.wide) W3_LAUNCH(2, 32, true);
+  else if (!d->up2x) W3_LAUNCH(4, 16, false);
+  else W3_LAUNCH(4, 16, true);
+#undef W3_LAUNCH
+  AVSEP_LAUNCH_CHECK();
+  if (p.splits > 1) {
+    long long n = (long long)d->Cout * d->Cin * 9;
+    hipLaunchKernelGGL(w3_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, n, p.splits);
+    AVSEP_LAUNCH_CHECK();
+  }
+  return AVSEP_OK;
+}
