@@ -29,6 +29,8 @@ struct CArgs {
   int M, Ncols, K;
   int gridM;
   int chunk, P;  // wgrad: pixels per split, total pixels
+  int kts;       // fwd/dgrad split-K: K-tiles per split (0 = no split)
+  long long slab;  // fwd/dgrad split-K: elements of one partial output slab
   int lstride;   // log2(stride) (dgrad)
 };
 
@@ -135,6 +137,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
     __syncthreads();
   } else {
     nK = (K + BK - 1) / BK;
+  }
+  // split-K (fwd: blockIdx.y, dgrad: blockIdx.z): this block reduces K-tiles [kt0, nK) of its slice
+  int kt0 = 0, ksplit = 0;
+  if (MODE != M_WGRAD && a.kts > 0) {
+    ksplit = (MODE == M_FWD) ? blockIdx.y : blockIdx.z;
+    kt0 = ksplit * a.kts;
+    nK = min(nK, kt0 + a.kts);
   }
 
   // ---------------- per-thread loader state ----------------
@@ -336,13 +345,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nK > 0) {
-    issue(0);
-    finish(0);
+  if (nK > kt0) {
+    issue(kt0);
+    finish(kt0 & 1);
   }
   __syncthreads();
   const int li = lane & 31, lk = lane >> 5;
-  for (int kt = 0; kt < nK; ++kt) {
+  for (int kt = kt0; kt < nK; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nK) issue(kt + 1);
 #pragma unroll
@@ -372,16 +381,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
     int cc = cok[j] ? col : 0;
     if (MODE == M_FWD) {
       int n = cc / HoWo, hw = cc % HoWo;
-      cbase[j] = (long long)n * a.Cout * HoWo + hw;
+      cbase[j] = (long long)ksplit * a.slab + (long long)n * a.Cout * HoWo + hw;
     } else if (MODE == M_DGRAD) {
       int n = cc / (Hc * Wc), r = cc % (Hc * Wc);
-      cbase[j] = (long long)n * a.Cin * HW + ((r / Wc) * a.stride + ph) * a.W + (r % Wc) * a.stride + pw;
+      cbase[j] = (long long)ksplit * a.slab + (long long)n * a.Cin * HW + ((r / Wc) * a.stride + ph) * a.W +
+                 (r % Wc) * a.stride + pw;
     } else {
       cbase[j] = (long long)blockIdx.y * M * Ncols + cc;
     }
   }
   const long long rstride = (MODE == M_FWD) ? HoWo : (MODE == M_DGRAD ? HW : Ncols);
-  const bool want_stats = (MODE == M_FWD) && a.stats != nullptr;
+  const bool want_stats = (MODE == M_FWD) && a.stats != nullptr && a.kts == 0;
   // per-row partial sums of this wave go to LDS (the operand tiles are dead after the last barrier),
   // so each workgroup issues ONE pair of double atomics per output channel
   float* s_sum = &As[0][0][0];   // [WN][BM]
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
       int lrow = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
       int row = m0 + lrow;
       bool rok = row < M;
-      float bias = (MODE == M_FWD && a.bias && rok) ? a.bias[row] : 0.f;
+      float bias = (MODE == M_FWD && a.bias && rok && a.kts == 0) ? a.bias[row] : 0.f;
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -457,6 +467,37 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
   float s = 0.f;
   for (int z = 0; z < S; ++z) s += ws[(long long)z * n + i];
   out[i] = s;
+}
+
+// split-K forward combine: y = sum of slabs (+ bias); per-channel (sum, sumsq) for the following BatchNorm.
+// grid (C, chunks); a block owns one channel over a slice of (n, hw)
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ ws, long long slab, int S, int N, int C,
+                                                             int HW, const float* __restrict__ bias,
+                                                             float* __restrict__ y, double* stats) {
+  const int c = blockIdx.x;
+  const float b = bias ? bias[c] : 0.f;
+  const int n_per = (N + gridDim.y - 1) / gridDim.y, n_beg = blockIdx.y * n_per, n_end = min(N, n_beg + n_per);
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = n_beg; n < n_end; ++n) {
+    const long long base = ((long long)n * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      float v = b;
+      for (int z = 0; z < S; ++z) v += ws[(long long)z * slab + base + i];
+      y[base + i] = v;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  if (stats) {
+    double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+    __shared__ double sh[8];
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = d1; sh[4 + (threadIdx.x >> 6)] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&stats[c], sh[0] + sh[1] + sh[2] + sh[3]);
+      atomicAdd(&stats[C + c], sh[4] + sh[5] + sh[6] + sh[7]);
+    }
+  }
 }
 
 // dbias[c] = sum over n,hw of dy[n,c,hw]; one block per channel
@@ -553,8 +594,52 @@ static inline bool use_big(int M, long long ncols) {
   return M > 64 && (long long)cdiv(M, 128) * cdiv(ncols, 128) >= 320;
 }
 
+// split-K plan for layers whose output grid cannot fill the chip (deep U-Net levels: 2x2 .. 8x8 maps, K ~ 8-9k)
+struct SplitPlan { int splits, kts; };
+static SplitPlan splitk_plan(long long tiles, int K) {
+  SplitPlan p{1, 0};
+  int nK = cdiv(K, 16);
+  if (tiles >= 1024 || nK < 64) return p;
+  int want = cdiv(1024, tiles), maxs = nK / 32;
+  int s = want < maxs ? want : maxs;
+  if (s > 32) s = 32;
+  if (s < 2) return p;
+  p.kts = cdiv(nK, s);
+  p.splits = cdiv(nK, p.kts);
+  if (p.splits < 2) { p.splits = 1; p.kts = 0; }
+  return p;
+}
+static bool fwd_uses_igemm(const avsep_conv_desc* d, const double* stats) {
+  return !((!stats && smallco_applicable(d)) || c3_applicable(d, 0));
+}
+static SplitPlan fwd_split(const avsep_conv_desc* d) {
+  long long ncols = (long long)d->N * d->Ho * d->Wo;
+  bool big = use_big(d->Cout, ncols);
+  long long tiles = big ? (long long)cdiv(d->Cout, 128) * cdiv(ncols, 128) : (long long)cdiv(d->Cout, 64) * cdiv(ncols, 64);
+  return splitk_plan(tiles, d->Cin * d->KH * d->KW);
+}
+static SplitPlan dgrad_split(const avsep_conv_desc* d) {
+  const int s = d->stride;
+  long long ncols = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);
+  bool big = use_big(d->Cin, ncols * s * s);
+  long long tiles = (big ? (long long)cdiv(d->Cin, 128) * cdiv(ncols, 128) : (long long)cdiv(d->Cin, 64) * cdiv(ncols, 64)) * s * s;
+  int taps = cdiv(d->KH, s) * cdiv(d->KW, s);               // taps of the fullest parity class
+  return splitk_plan(tiles, taps * d->Cout);
+}
+
+extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
+  if (check_desc(d, true) || !fwd_uses_igemm(d, (const double*)1)) return 0;
+  SplitPlan p = fwd_split(d);
+  return p.splits > 1 ? (size_t)p.splits * d->N * d->Cout * d->Ho * d->Wo * sizeof(float) : 0;
+}
+extern "C" size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d) {
+  if (check_desc(d) || c3_applicable(d, 1)) return 0;
+  SplitPlan p = dgrad_split(d);
+  return p.splits > 1 ? (size_t)p.splits * d->N * d->Cin * d->H * d->W * sizeof(float) : 0;
+}
+
 extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed, const float* bias, float* y,
-                                double* stats, avsep_stream_t stream) {
+                                double* stats, void* workspace, size_t workspace_bytes, avsep_stream_t stream) {
   int rc = check_desc(d, true);
   if (rc) return rc;
   if (!w_packed || !y) return AVSEP_ERR_ARG;
@@ -567,19 +652,35 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   if (ncols > 0x7fffffffLL) return AVSEP_ERR_ARG;
   a.Ncols = (int)ncols;
   hipStream_t st = (hipStream_t)stream;
+  SplitPlan sp = fwd_split(d);
+  if (sp.splits > 1 && (!workspace || workspace_bytes < avsep_conv2d_fwd_workspace_bytes(d))) sp = SplitPlan{1, 0};
+  if (sp.splits > 1) {
+    a.kts = sp.kts;
+    a.slab = (long long)d->N * d->Cout * d->Ho * d->Wo;
+    a.out = (float*)workspace;
+  }
   if (use_big(a.M, ncols)) {
     a.gridM = cdiv(a.M, 128);
-    hipLaunchKernelGGL((igemm_kernel<M_FWD, 128, 128, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 128)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_kernel<M_FWD, 128, 128, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 128), sp.splits), dim3(256), 0,
+                       st, a);
   } else {
     a.gridM = cdiv(a.M, 64);
-    hipLaunchKernelGGL((igemm_kernel<M_FWD, 64, 64, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 64)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_kernel<M_FWD, 64, 64, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 64), sp.splits), dim3(256), 0, st,
+                       a);
   }
   AVSEP_LAUNCH_CHECK();
+  if (sp.splits > 1) {
+    int chunks = min(cdiv(1024, d->Cout), d->N);
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(splitk_combine_kernel, dim3(d->Cout, chunks), dim3(256), 0, st, (const float*)workspace, a.slab,
+                       sp.splits, d->N, d->Cout, d->Ho * d->Wo, bias, y, stats);
+    AVSEP_LAUNCH_CHECK();
+  }
   return AVSEP_OK;
 }
 
 extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packed_dgrad, const float* dy, float* dx,
-                                  avsep_stream_t stream) {
+                                  void* workspace, size_t workspace_bytes, avsep_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
@@ -593,16 +694,28 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   long long ncols = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);  // largest parity class
   if ((long long)d->N * d->H * d->W > 0x7fffffffLL) return AVSEP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  SplitPlan sp = dgrad_split(d);
+  if (sp.splits > 1 && (!workspace || workspace_bytes < avsep_conv2d_dgrad_workspace_bytes(d))) sp = SplitPlan{1, 0};
+  if (sp.splits > 1) {
+    a.kts = sp.kts;
+    a.slab = (long long)d->N * d->Cin * d->H * d->W;
+    a.out = (float*)workspace;
+  }
   if (use_big(a.M, ncols * s * s)) {
     a.gridM = cdiv(a.M, 128);
-    hipLaunchKernelGGL((igemm_kernel<M_DGRAD, 128, 128, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 128), s * s), dim3(256), 0,
-                       st, a);
+    hipLaunchKernelGGL((igemm_kernel<M_DGRAD, 128, 128, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 128), s * s, sp.splits),
+                       dim3(256), 0, st, a);
   } else {
     a.gridM = cdiv(a.M, 64);
-    hipLaunchKernelGGL((igemm_kernel<M_DGRAD, 64, 64, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 64), s * s), dim3(256), 0, st,
-                       a);
+    hipLaunchKernelGGL((igemm_kernel<M_DGRAD, 64, 64, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 64), s * s, sp.splits),
+                       dim3(256), 0, st, a);
   }
   AVSEP_LAUNCH_CHECK();
+  if (sp.splits > 1) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(a.slab, 256)), dim3(256), 0, st, (const float*)workspace, dx, a.slab,
+                       sp.splits);
+    AVSEP_LAUNCH_CHECK();
+  }
   return AVSEP_OK;
 }
 

@@ -250,23 +250,36 @@ __device__ __forceinline__ float cat_relu_val(const CatArgs& a, int n, int c, in
   return v;
 }
 
-__global__ __launch_bounds__(256) void relu_up2x_fwd_kernel(CatArgs a, float* __restrict__ out) {
+// grid (ceil(Wo/Wb), ceil(Ho/rows), N*C) with Wb = 2^lw columns x rows = 256/Wb rows per block:
+// no per-element div/mod, full 256-thread blocks on narrow planes too
+__global__ __launch_bounds__(256) void relu_up2x_fwd_kernel(CatArgs a, float* __restrict__ out, int lw) {
   const int Ho = 2 * a.H, Wo = 2 * a.W, C = a.C0 + a.C1;
-  const long long total = (long long)a.N * C * Ho * Wo;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    int wo = (int)(i % Wo);
-    long long t = i / Wo;
-    int ho = (int)(t % Ho);
-    t /= Ho;
-    int c = (int)(t % C), n = (int)(t / C);
+  const int nc = blockIdx.z, n = nc / C, c = nc % C;   // block-uniform
+  const int wo = (blockIdx.x << lw) + (threadIdx.x & ((1 << lw) - 1));
+  const int ho = blockIdx.y * (256 >> lw) + (threadIdx.x >> lw);
+  if (wo >= Wo || ho >= Ho) return;
+  const bool first = c < a.C0;
+  const int cs = first ? c : c - a.C0;
+  const float* sc = first ? a.sc0 : a.sc1;
+  const float* sh = first ? a.sh0 : a.sh1;
+  const float scv = sc ? sc[cs] : 1.f, shv = sc ? sh[cs] : 0.f;
+  const bool bc = first ? a.b0 : a.b1;
+  const float* src = first ? a.x0 : a.x1;
+  const int Cs = first ? a.C0 : a.C1;
+  float v;
+  if (bc) {
+    v = fmaxf(fmaf(src[(long long)n * Cs + cs], scv, shv), 0.f);
+  } else {
+    const float* p = src + ((long long)n * Cs + cs) * a.H * a.W;
     float fh = a.rh * (float)ho, fw = a.rw * (float)wo;
     int h0 = (int)fh, w0 = (int)fw;
     int h1 = h0 + (h0 < a.H - 1), w1 = w0 + (w0 < a.W - 1);
     float lh = fh - (float)h0, lw = fw - (float)w0;
-    float v00 = fmaxf(cat_relu_val(a, n, c, h0, w0), 0.f), v01 = fmaxf(cat_relu_val(a, n, c, h0, w1), 0.f);
-    float v10 = fmaxf(cat_relu_val(a, n, c, h1, w0), 0.f), v11 = fmaxf(cat_relu_val(a, n, c, h1, w1), 0.f);
-    out[i] = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+    float v00 = fmaxf(fmaf(p[h0 * a.W + w0], scv, shv), 0.f), v01 = fmaxf(fmaf(p[h0 * a.W + w1], scv, shv), 0.f);
+    float v10 = fmaxf(fmaf(p[h1 * a.W + w0], scv, shv), 0.f), v11 = fmaxf(fmaf(p[h1 * a.W + w1], scv, shv), 0.f);
+    v = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
   }
+  out[((long long)nc * Ho + ho) * Wo + wo] = v;
 }
 
 static CatArgs make_cat(const avsep_cat_desc* d) {
@@ -287,9 +300,12 @@ extern "C" int avsep_relu_up2x_fwd(const avsep_cat_desc* d, float* out, avsep_st
   int rc = check_cat(d);
   if (rc || !out) return AVSEP_ERR_ARG;
   CatArgs a = make_cat(d);
-  long long total = (long long)d->N * (d->C0 + d->C1) * 4 * d->H * d->W;
-  int blocks = (int)min((total + 255) / 256, (long long)65536);
-  hipLaunchKernelGGL(relu_up2x_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, out);
+  long long planes = (long long)d->N * (d->C0 + d->C1);
+  if (planes > 0x7fffffffLL || 2 * d->H > 65535) return AVSEP_ERR_ARG;
+  int lw = 8;
+  while (lw > 2 && (1 << (lw - 1)) >= 2 * d->W) --lw;      // smallest power of two >= Wo, capped at 256
+  hipLaunchKernelGGL(relu_up2x_fwd_kernel, dim3(cdiv(2 * d->W, 1 << lw), cdiv(2 * d->H, 256 >> lw), (unsigned)planes),
+                     dim3(256), 0, (hipStream_t)stream, a, out, lw);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
@@ -335,30 +351,42 @@ __global__ __launch_bounds__(256) void relu_up2x_bwd_kernel(CatArgs a, const flo
         g[o] = (acc0 && first) ? g[o] + tot : tot;
       }
     } else {
-      const long long total = (long long)a.N * HW;
-      const long long per = (total + gridDim.y - 1) / gridDim.y;
-      const long long beg = per * blockIdx.y, end = min(total, beg + per);
-      for (long long i = beg + threadIdx.x; i < end; i += 256) {
-        int n = (int)(i / HW), hw = (int)(i % HW), h = hw / a.W, w = hw % a.W;
-        float pre = cat_relu_val(a, n, c, h, w);
-        float tot = 0.f;
-        if (pre > 0.f) {
-          int ih[8], iw[8];
-          float wh[8], ww[8];
-          int nh = up2x_taps(h, a.H, a.rh, ih, wh), nw = up2x_taps(w, a.W, a.rw, iw, ww);
-          const float* p = dout + ((long long)n * C + c) * Ho * Wo;
-          for (int y = 0; y < nh; ++y) {
-            float row = 0.f;
-            for (int x = 0; x < nw; ++x) row += ww[x] * p[ih[y] * Wo + iw[x]];
-            tot += wh[y] * row;
+      // thread (tx, ty) of a 32 x 8 tile; images of this block's slice, rows and columns by strides:
+      // no per-element div/mod; the transpose-bilinear taps are computed once per row / column
+      const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+      const int n_per = (a.N + gridDim.y - 1) / gridDim.y;
+      const int n_beg = blockIdx.y * n_per, n_end = min(a.N, n_beg + n_per);
+      const float* xsrc = first ? a.x0 : a.x1;
+      const float* scp = first ? a.sc0 : a.sc1;
+      const float* shp = first ? a.sh0 : a.sh1;
+      const float scv = scp ? scp[cs] : 1.f, shv = scp ? shp[cs] : 0.f;
+      for (int h = ty; h < a.H; h += 8) {
+        int ih[8];
+        float wh[8];
+        const int nh = up2x_taps(h, a.H, a.rh, ih, wh);
+        for (int w = tx; w < a.W; w += 32) {
+          int iw[8];
+          float ww[8];
+          const int nw = up2x_taps(w, a.W, a.rw, iw, ww);
+          for (int n = n_beg; n < n_end; ++n) {
+            const long long o = ((long long)n * Cs + cs) * HW + h * a.W + w;
+            const float yv = xsrc[o];
+            const float pre = fmaf(yv, scv, shv);
+            float tot = 0.f;
+            if (pre > 0.f) {
+              const float* p = dout + ((long long)n * C + c) * Ho * Wo;
+              for (int y = 0; y < nh; ++y) {
+                float row = 0.f;
+                for (int x = 0; x < nw; ++x) row += ww[x] * p[ih[y] * Wo + iw[x]];
+                tot += wh[y] * row;
+              }
+            }
+            g[o] = (acc0 && first) ? g[o] + tot : tot;
+            if (!first && bstats1) {
+              s1 += tot;
+              s2 += tot * (yv - mu) * is;
+            }
           }
-        }
-        long long o = ((long long)n * Cs + cs) * HW + hw;
-        g[o] = (acc0 && first) ? g[o] + tot : tot;
-        if (!first && bstats1) {
-          float yv = a.x1[o];
-          s1 += tot;
-          s2 += tot * (yv - mu) * is;
         }
       }
     }
@@ -383,8 +411,7 @@ extern "C" int avsep_relu_up2x_bwd(const avsep_cat_desc* d, const float* dout, f
   if (bstats1 && (!mean1 || !invstd1 || d->bcast1 || !g1)) return AVSEP_ERR_ARG;
   CatArgs a = make_cat(d);
   int C = d->C0 + d->C1;
-  long long total = (long long)d->N * d->H * d->W;
-  int chunks = (int)min((long long)cdiv(4096, C), (total + 511) / 512);
+  int chunks = min(cdiv(2048, C), d->N);           // blocks per channel = slices over the batch
   if (chunks < 1) chunks = 1;
   hipLaunchKernelGGL(relu_up2x_bwd_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, a, dout, g0, g1, mean1,
                      invstd1, bstats1, acc0);

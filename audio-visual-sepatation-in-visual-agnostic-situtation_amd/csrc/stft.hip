@@ -103,7 +103,7 @@ extern "C" int avsep_stft_mag(const float* wav, int32_t R, int32_t L, int32_t n_
   avsep_conv_desc d{};
   d.N = R; d.Cin = 1; d.H = 1; d.W = Lp; d.Cout = 2 * bins; d.Ho = 1; d.Wo = frames;
   d.KH = 1; d.KW = n_fft; d.stride = hop; d.pad = 0; d.dil = 1; d.C0 = 1; d.x0 = padded;
-  int rc = avsep_conv2d_fwd(&d, basis, nullptr, spec, nullptr, stream);
+  int rc = avsep_conv2d_fwd(&d, basis, nullptr, spec, nullptr, nullptr, 0, stream);
   if (rc) return rc;
   long long n = (long long)bins * frames;
   hipLaunchKernelGGL(stft_magphase_kernel, dim3((int)min((n + 255) / 256, (long long)1024), R), dim3(256), 0, st, spec, bins,
@@ -167,7 +167,7 @@ extern "C" int avsep_istft(const float* mag, const float* phase, int32_t R, int3
   avsep_conv_desc d{};
   d.N = R; d.Cin = 2 * bins; d.H = 1; d.W = frames; d.Cout = n_fft; d.Ho = 1; d.Wo = frames;
   d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0; d.dil = 1; d.C0 = 2 * bins; d.x0 = spec;
-  int rc = avsep_conv2d_fwd(&d, inv_basis, nullptr, td, nullptr, stream);
+  int rc = avsep_conv2d_fwd(&d, inv_basis, nullptr, td, nullptr, nullptr, 0, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(istft_ola_kernel, dim3(min(cdiv(out_len, 256), 1024), R), dim3(256), 0, st, td, n_fft, hop, frames,
                      out_len, wav);

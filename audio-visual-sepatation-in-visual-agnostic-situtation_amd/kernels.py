@@ -49,14 +49,21 @@ class Conv:
         call("avsep_conv_pack_weights", self.ref, ptr(w), ptr(out), mode)
         return out
 
+    def _ws(self, query):
+        nbytes = getattr(lib.load(), query)(self.ref)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=self.like.device) if nbytes else None
+        return ws, nbytes
+
     def fwd(self, w_packed, bias=None, stats=None):
         y = _f32((self.N, self.Cout, self.Ho, self.Wo), self.like)
-        call("avsep_conv2d_fwd", self.ref, ptr(w_packed), ptr(bias), ptr(y), ptr(stats))
+        ws, nbytes = self._ws("avsep_conv2d_fwd_workspace_bytes")
+        call("avsep_conv2d_fwd", self.ref, ptr(w_packed), ptr(bias), ptr(y), ptr(stats), ptr(ws), nbytes)
         return y
 
     def dgrad(self, w_packed_d, dy):
         dx = _f32((self.N, self.Cin, self.H, self.W), self.like)
-        call("avsep_conv2d_dgrad", self.ref, ptr(w_packed_d), ptr(dy), ptr(dx))
+        ws, nbytes = self._ws("avsep_conv2d_dgrad_workspace_bytes")
+        call("avsep_conv2d_dgrad", self.ref, ptr(w_packed_d), ptr(dy), ptr(dx), ptr(ws), nbytes)
         return dx
 
     def wgrad(self, dy, want_bias=False):

@@ -43,8 +43,10 @@ SIGNATURES = {
     "avsep_strerror": (C.c_char_p, [C.c_int]),
     "avsep_conv_packed_floats": (_Z, [_CD, C.c_int]),
     "avsep_conv_pack_weights": (C.c_int, [_CD, _P, _P, C.c_int, _P]),
-    "avsep_conv2d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P]),
-    "avsep_conv2d_dgrad": (C.c_int, [_CD, _P, _P, _P, _P]),
+    "avsep_conv2d_fwd_workspace_bytes": (_Z, [_CD]),
+    "avsep_conv2d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _Z, _P]),
+    "avsep_conv2d_dgrad_workspace_bytes": (_Z, [_CD]),
+    "avsep_conv2d_dgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
     "avsep_conv2d_wgrad_workspace_bytes": (_Z, [_CD]),
     "avsep_conv2d_wgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
     "avsep_channel_stats": (C.c_int, [_P, _I, _I, _I, _P, _P]),

@@ -76,12 +76,16 @@ int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w, float* pac
                             avsep_stream_t stream);
 
 /* y = conv(virtual input) (+bias).  stats (optional, double[2*Cout], pre-zeroed):
- * per-channel sum and sum of squares of y, for the following BatchNorm.          */
+ * per-channel sum and sum of squares of y, for the following BatchNorm.
+ * workspace (avsep_conv2d_fwd_workspace_bytes; may be 0/NULL): split-K partial slabs for layers whose
+ * output grid cannot fill the chip; without it the call falls back to an unsplit launch.        */
+size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d);
 int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed, const float* bias, float* y,
-                     double* stats, avsep_stream_t stream);
+                     double* stats, void* workspace, size_t workspace_bytes, avsep_stream_t stream);
 /* dx = gradient w.r.t. the VIRTUAL input [N,Cin,H,W] (after affine/activation/upsample). */
+size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d);
 int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packed_dgrad, const float* dy,
-                       float* dx, avsep_stream_t stream);
+                       float* dx, void* workspace, size_t workspace_bytes, avsep_stream_t stream);
 /* dw OIHW; dbias optional ([Cout]).  workspace from avsep_conv2d_wgrad_workspace_bytes(). */
 size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d);
 int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias,

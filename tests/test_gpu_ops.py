@@ -28,6 +28,8 @@ CONV_CASES = [
     (2, 32, 15, 15, 48, 3, 2, 1, 1),       # 3x3 stride 2, odd size
     (2, 32, 14, 14, 64, 1, 2, 0, 1),       # 1x1 stride 2 downsample
     (4, 256, 4, 4, 256, 4, 2, 1, 1),       # deep, tiny spatial
+    (8, 512, 4, 4, 512, 4, 2, 1, 1),       # deep level: few tiles, K = 8192 -> split-K slabs + combine (bias, stats)
+    (4, 640, 8, 8, 96, 3, 1, 1, 1),        # split-K on the 3x3 im2col path (W < 16)
     (1, 20, 12, 16, 2, 3, 1, 1, 1),        # Cout = 2 (last U-Net conv) -> direct small-Cout kernels
     (2, 37, 21, 144, 2, 3, 1, 1, 1),       # same path: ragged H, W > one 128 tile, Cin not a multiple of the chunk
     (2, 16, 10, 10, 3, 3, 1, 1, 1),        # W % 16 != 0 -> falls back to the MFMA path
