@@ -43,7 +43,7 @@ __device__ __forceinline__ float c3_src(const C3Args& a, int n, int c, int hs, i
   return v;
 }
 
-template <int TH, int TW, int BM>
+template <int TH, int TW, int BM, bool UP2X>
 __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
   constexpr int PH = TH + 2, PW = TW + 2, PS = PH * PW;   // patch per channel
   constexpr int LDA = BM + 4;
@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
   // ---- loader state: patch element e of this thread is flat index tid + 256*e = (c, r, col) ----
   // issue(): branch-free address math + unconditional loads (clamped coordinates) into registers;
   // finish(): affine + activation (+ bilinear blend) + zero masking + LDS stores, after the MFMA loop.
-  constexpr int NRAW = 4;                                 // up2x needs the 4 bilinear corners
-  float praw[PE][NRAW], psc[PE], psh[PE], plh[PE], plw[PE];
+  constexpr int NRAW = UP2X ? 4 : 1;                      // up2x needs the 4 bilinear corners
+  float praw[PE][NRAW], psc[PE], psh[PE], plh[UP2X ? PE : 1], plw[UP2X ? PE : 1];
   unsigned pok = 0, pfirst = 0;
   float4 areg[AE];
   const bool has0 = a.sc0 != nullptr, has1 = a.sc1 != nullptr;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
       bool first = c < a.C0;
       int cs = first ? c : c - a.C0;
       const float* xb = (first ? a.x0 : a.x1) + ((long long)n * (first ? a.C0 : a.C1) + cs) * sHW;
-      if (!a.up2x) {   // kernel-uniform
+      if constexpr (!UP2X) {
         praw[e][0] = xb[ghc * a.Ws + gwc];
       } else {         // nn.Upsample(x2, bilinear, align_corners=True): src = dst*(in-1)/(out-1)
         float fh = a.rh * (float)ghc, fw = a.rw * (float)gwc;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
       const bool has = first ? has0 : has1;
       const int act = first ? a.act0 : a.act1;
       float v;
-      if (!a.up2x) {
+      if constexpr (!UP2X) {
         v = praw[e][0];
         if (has) v = fmaf(v, psc[e], psh[e]);
         v = act_apply(v, act);
@@ -294,10 +294,16 @@ static int c3_launch(C3Args& a, hipStream_t st) {
   a.tilesX = cdiv(a.W, wide ? 32 : 16);
   a.tilesY = cdiv(a.H, wide ? 4 : 8);
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
-  if (wide && !narrow) hipLaunchKernelGGL((conv3x3_kernel<4, 32, 128>), grid, dim3(256), 0, st, a);
-  else if (wide) hipLaunchKernelGGL((conv3x3_kernel<4, 32, 64>), grid, dim3(256), 0, st, a);
-  else if (!narrow) hipLaunchKernelGGL((conv3x3_kernel<8, 16, 128>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv3x3_kernel<8, 16, 64>), grid, dim3(256), 0, st, a);
+#define C3_LAUNCH(TH_, TW_, BM_)                                                                        \
+  do {                                                                                                \
+    if (a.up2x) hipLaunchKernelGGL((conv3x3_kernel<TH_, TW_, BM_, true>), grid, dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((conv3x3_kernel<TH_, TW_, BM_, false>), grid, dim3(256), 0, st, a);       \
+  } while (0)
+  if (wide && !narrow) C3_LAUNCH(4, 32, 128);
+  else if (wide) C3_LAUNCH(4, 32, 64);
+  else if (!narrow) C3_LAUNCH(8, 16, 128);
+  else C3_LAUNCH(8, 16, 64);
+#undef C3_LAUNCH
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }

@@ -310,19 +310,23 @@ extern "C" int avsep_relu_up2x_fwd(const avsep_cat_desc* d, float* out, avsep_st
   return AVSEP_OK;
 }
 
-// transpose-gather of the bilinear weights for one low-res position along one axis
-__device__ __forceinline__ int up2x_taps(int h, int Hin, float r, int* idx, float* wt) {
-  int cnt = 0;
-  int lo = max(0, 2 * h - 3), hi = min(2 * Hin - 1, 2 * h + 4);
-  for (int ho = lo; ho <= hi; ++ho) {
-    float f = r * (float)ho;
-    int h0 = (int)f;
-    int h1 = h0 + (h0 < Hin - 1);
-    float l = f - (float)h0;
-    float w = (h0 == h ? 1.f - l : 0.f) + (h1 == h ? l : 0.f);
-    if (w != 0.f) { idx[cnt] = ho; wt[cnt] = w; ++cnt; }
+// Transpose of the bilinear x2 (align_corners=True) along one axis: the hi-res indices that read low-res
+// index h lie in [2h-2, 2h+3] (src = dst*(H-1)/(2H-1) is slightly below dst/2); their weights go into six
+// registers (static indices only - no scratch).  The forward's float arithmetic is repeated exactly.
+__device__ __forceinline__ void up2x_taps6(int h, int Hin, float r, float (&wt)[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int ho = 2 * h - 2 + k;
+    float w = 0.f;
+    if (ho >= 0 && ho < 2 * Hin) {
+      float f = r * (float)ho;
+      int h0 = (int)f;
+      int h1 = h0 + (h0 < Hin - 1);
+      float l = f - (float)h0;
+      w = (h0 == h ? 1.f - l : 0.f) + (h1 == h ? l : 0.f);
+    }
+    wt[k] = w;
   }
-  return cnt;
 }
 
 // grid (C0+C1, chunks); a block reduces the BN-backward sums of its channel
@@ -361,24 +365,27 @@ __global__ __launch_bounds__(256) void relu_up2x_bwd_kernel(CatArgs a, const flo
       const float* shp = first ? a.sh0 : a.sh1;
       const float scv = scp ? scp[cs] : 1.f, shv = scp ? shp[cs] : 0.f;
       for (int h = ty; h < a.H; h += 8) {
-        int ih[8];
-        float wh[8];
-        const int nh = up2x_taps(h, a.H, a.rh, ih, wh);
+        float wh[6];
+        up2x_taps6(h, a.H, a.rh, wh);
         for (int w = tx; w < a.W; w += 32) {
-          int iw[8];
-          float ww[8];
-          const int nw = up2x_taps(w, a.W, a.rw, iw, ww);
+          float ww[6];
+          up2x_taps6(w, a.W, a.rw, ww);
           for (int n = n_beg; n < n_end; ++n) {
             const long long o = ((long long)n * Cs + cs) * HW + h * a.W + w;
             const float yv = xsrc[o];
             const float pre = fmaf(yv, scv, shv);
             float tot = 0.f;
             if (pre > 0.f) {
-              const float* p = dout + ((long long)n * C + c) * Ho * Wo;
-              for (int y = 0; y < nh; ++y) {
-                float row = 0.f;
-                for (int x = 0; x < nw; ++x) row += ww[x] * p[ih[y] * Wo + iw[x]];
-                tot += wh[y] * row;
+              const float* p = dout + ((long long)n * C + c) * Ho * Wo + (long long)(2 * h - 2) * Wo + (2 * w - 2);
+#pragma unroll
+              for (int y = 0; y < 6; ++y) {
+                if (wh[y] != 0.f) {
+                  float row = 0.f;
+#pragma unroll
+                  for (int x = 0; x < 6; ++x)
+                    if (ww[x] != 0.f) row = fmaf(ww[x], p[y * Wo + x], row);
+                  tot = fmaf(wh[y], row, tot);
+                }
               }
             }
             g[o] = (acc0 && first) ? g[o] + tot : tot;
