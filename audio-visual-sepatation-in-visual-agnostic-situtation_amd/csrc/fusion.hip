@@ -27,6 +27,31 @@ __device__ __forceinline__ void wave_argmax(const float* s, int n, int lane, flo
   }
 }
 
+// block-wide sums of four per-thread values (256 threads); results in out[0..3] (LDS), all threads may read after
+__device__ __forceinline__ void block_sum4(float v0, float v1, float v2, float v3, float* s_red, float* out) {
+  v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    int w = threadIdx.x >> 6;
+    s_red[w * 4 + 0] = v0; s_red[w * 4 + 1] = v1; s_red[w * 4 + 2] = v2; s_red[w * 4 + 3] = v3;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) out[threadIdx.x] = s_red[threadIdx.x] + s_red[4 + threadIdx.x] + s_red[8 + threadIdx.x] + s_red[12 + threadIdx.x];
+  __syncthreads();
+}
+
+// MixVis penalty terms: u = v[:, where0], w = v[:, where1]; out = {u.w, |u|^2, |w|^2, sum of both maps}
+__device__ __forceinline__ void mixvis_sums(const float* v, int Dc, int HW, int where0, int where1, const float* s_m,
+                                            float* s_red, float* out) {
+  float duw = 0.f, nu = 0.f, nw = 0.f, sm = 0.f;
+  for (int d = threadIdx.x; d < Dc; d += 256) {
+    float u = v[(long long)d * HW + where0], w = v[(long long)d * HW + where1];
+    duw = fmaf(u, w, duw); nu = fmaf(u, u, nu); nw = fmaf(w, w, nw);
+  }
+  for (int hw = threadIdx.x; hw < HW; hw += 256) sm += s_m[(0 * 2 + 0) * HW + hw] + s_m[(1 * 2 + 0) * HW + hw];
+  block_sum4(duw, nu, nw, sm, s_red, out);
+}
+
 // maps m[k][c][hw] (k = audio block, c = visual map) into s_m; v norms into s_nv (cos); a norms into s_na
 __device__ void fusion_maps(const FusArgs& a, int b, const float* s_a, float* s_m, float* s_nv, float* s_na,
                             float* s_red) {
@@ -113,6 +138,27 @@ __global__ __launch_bounds__(256) void fusion_av_fwd_kernel(FusArgs a, float* __
     if (lane == 0) { s_mx[wave] = mx; s_arg[wave] = am; }
   }
   __syncthreads();
+  if (a.kind == 2) {  // MixVis (fusion_net.py:248-285): ONE mixed visual map (v0 == v1), one map per audio block
+    const int w0 = s_arg[0 * 2 + 0], w1 = s_arg[1 * 2 + 0];
+    float* s4 = s_nv;                      // [4] scratch (the cos norms of v are no longer needed here)
+    mixvis_sums(a.v0 + (long long)b * Dc * HW, Dc, HW, w0, w1, s_m, s_red, s4);
+    if (tid == 0) {
+      float nu = fmaxf(sqrtf(s4[1]), FUS_EPS), nw = fmaxf(sqrtf(s4[2]), FUS_EPS);
+      float cosv = s4[0] / (nu * nw);
+      match_part[b] = -(s_mx[0] + s_mx[2]) + s4[3] / (float)HW + cosv;
+      best_out[b] = 0;
+    }
+    for (int i = tid; i < 2 * HW; i += 256) {
+      int k = i / HW, hw = i % HW;
+      att_maps[((long long)b * 2 + k) * HW + hw] = s_m[(k * 2 + 0) * HW + hw];
+    }
+    for (int i = tid; i < D; i += 256) {
+      int k = i / Dc, d = i % Dc, arg = k ? w1 : w0;
+      feat[(long long)b * D + i] = a.v0[((long long)b * Dc + d) * HW + arg];
+      sel_idx[(long long)b * D + i] = arg;
+    }
+    return;
+  }
   // 4. permutation scores: p=0 pairs (k=c), p=1 pairs (k=1-c)
   if (tid == 0) {
     float p0 = s_mx[0 * 2 + 0] + s_mx[1 * 2 + 1];
@@ -187,16 +233,30 @@ __global__ __launch_bounds__(256) void fusion_av_bwd_kernel(FusArgs a, const flo
   __syncthreads();
   const int best = best_in[b];
   const float dmatch = (dmatch_ptr ? dmatch_ptr[0] : 1.f) * dmatch_scale;
-  // match loss: -score(best) + score(other); score_p = sum_c max_hw m[k=c^p][c]
-  if (tid < 4) {
-    int k = tid >> 1, c = tid & 1, p = k ^ c;
-    atomicAdd(&s_E[tid * HW + s_arg[tid]], (p == best ? -1.f : 1.f) * dmatch);
-  }
-  if (dmaps)
+  float* s_mv = s_S + 2;                 // MixVis: {u.w, |u|^2, |w|^2, sum maps}
+  const int mw0 = s_arg[0], mw1 = s_arg[2];
+  if (a.kind == 2) {
+    // T_b = -(max m0 + max m1) + sum(m0 + m1)/HW + cos(v[:,w0], v[:,w1])
+    mixvis_sums(a.v0 + (long long)b * Dc * HW, Dc, HW, mw0, mw1, s_m, s_red, s_mv);
     for (int i = tid; i < 2 * HW; i += 256) {
-      int c = i / HW, hw = i % HW;
-      atomicAdd(&s_E[((c ^ best) * 2 + c) * HW + hw], dmaps[((long long)b * 2 + c) * HW + hw]);
+      int k = i / HW, hw = i % HW;
+      float e = dmatch / (float)HW;
+      if (dmaps) e += dmaps[((long long)b * 2 + k) * HW + hw];
+      if (hw == (k ? mw1 : mw0)) e -= dmatch;
+      s_E[(k * 2 + 0) * HW + hw] = e;
     }
+  } else {
+    // match loss: -score(best) + score(other); score_p = sum_c max_hw m[k=c^p][c]
+    if (tid < 4) {
+      int k = tid >> 1, c = tid & 1, p = k ^ c;
+      atomicAdd(&s_E[tid * HW + s_arg[tid]], (p == best ? -1.f : 1.f) * dmatch);
+    }
+    if (dmaps)
+      for (int i = tid; i < 2 * HW; i += 256) {
+        int c = i / HW, hw = i % HW;
+        atomicAdd(&s_E[((c ^ best) * 2 + c) * HW + hw], dmaps[((long long)b * 2 + c) * HW + hw]);
+      }
+  }
   if (a.kind == 0)  // attended vector: f = v[d,h*] * att[c][h*]
     for (int i = tid; i < D; i += 256) {
       int c = i / Dc, d = i % Dc, h = sel_idx[(long long)b * D + i];
@@ -271,15 +331,30 @@ __global__ __launch_bounds__(256) void fusion_av_bwd_kernel(FusArgs a, const flo
       int sel = sel_idx[(long long)b * D + c * Dc + d];
       if (a.kind == 0) {
         if (hw == sel) g += dfeat[(long long)b * D + c * Dc + d] * at[hw];
-      } else {
+      } else if (a.kind == 1) {
         if (hw == where) g += dfeat[(long long)b * D + c * Dc + d];
+      } else if (hw == mw0 || hw == mw1) {
+        // selected vectors u = v[:,w0], w = v[:,w1]: gradient of feat and of cos(u, w) (F.cosine_similarity, eps 1e-8)
+        const float u = vsrc[(long long)d * HW + mw0], w = vsrc[(long long)d * HW + mw1];
+        const float nu = sqrtf(s_mv[1]), nw = sqrtf(s_mv[2]);
+        const float nuc = fmaxf(nu, FUS_EPS), nwc = fmaxf(nw, FUS_EPS), cosv = s_mv[0] / (nuc * nwc);
+        if (hw == mw0) {
+          float t = w / (nuc * nwc);
+          if (nu > FUS_EPS) t -= cosv * u / (nu * nu);
+          g += dfeat[(long long)b * D + d] + dmatch * t;
+        }
+        if (hw == mw1) {
+          float t = u / (nuc * nwc);
+          if (nw > FUS_EPS) t -= cosv * w / (nw * nw);
+          g += dfeat[(long long)b * D + Dc + d] + dmatch * t;
+        }
       }
       dv[(long long)b * Dc * HW + i] = g;
     }
   }
 }
 
-static size_t fusion_smem(int Dc, int HW) { return (size_t)(2 * Dc + 4 * HW + 2 * HW + 16 + 2 + 4 + 4 + 4 + 4 * HW + 2) * 4; }
+static size_t fusion_smem(int Dc, int HW) { return (size_t)(2 * Dc + 4 * HW + 2 * HW + 16 + 2 + 4 + 4 + 4 + 4 * HW + 2 + 8) * 4; }
 
 extern "C" int avsep_fusion_av_fwd(const float* x, const float* v0, const float* v1, int32_t B, int32_t Dc, int32_t FT,
                                    int32_t HW, int32_t kind, int32_t att, float* a_pool, int32_t* pool_idx, float* feat,
@@ -288,7 +363,7 @@ extern "C" int avsep_fusion_av_fwd(const float* x, const float* v0, const float*
   if (!x || !v0 || !v1 || !a_pool || !pool_idx || !feat || !sel_idx || !att_maps || !match_part || !best)
     return AVSEP_ERR_ARG;
   if (B <= 0 || Dc <= 0 || FT <= 0 || HW <= 0 || (att != 0 && att != 1)) return AVSEP_ERR_ARG;
-  if (kind != 0 && kind != 1) return AVSEP_ERR_ARG;  // MixVis (kind 2) is not built yet
+  if (kind < 0 || kind > 2) return AVSEP_ERR_ARG;
   size_t smem = fusion_smem(Dc, HW);
   if (smem > 160 * 1024) return AVSEP_ERR_ARG;
   FusArgs a{x, v0, v1, B, Dc, FT, HW, kind, att};
@@ -308,7 +383,7 @@ extern "C" int avsep_fusion_av_bwd(const float* x, const float* v0, const float*
   (void)att_maps;
   if (!x || !v0 || !v1 || !a_pool || !pool_idx || !sel_idx || !best || !dfeat) return AVSEP_ERR_ARG;
   if (B <= 0 || Dc <= 0 || FT <= 0 || HW <= 0 || (att != 0 && att != 1)) return AVSEP_ERR_ARG;
-  if (kind != 0 && kind != 1) return AVSEP_ERR_ARG;
+  if (kind < 0 || kind > 2) return AVSEP_ERR_ARG;
   size_t smem = fusion_smem(Dc, HW);
   if (smem > 160 * 1024) return AVSEP_ERR_ARG;
   FusArgs a{x, v0, v1, B, Dc, FT, HW, kind, att};

@@ -42,8 +42,9 @@ class _FusionBase(nn.Module):
                  ptr(out["pool_idx"]))
             return out
         if self.kind == 2:
-            raise lib.AvsepError("MixVis fusion is not built on the HIP path yet")
-        if len(vs) != 2:
+            assert len(vs) == 1                      # fusion_net.py:287: one mixed visual map
+            vs = [vs[0], vs[0]]
+        elif len(vs) != 2:
             raise AssertionError("CoLoc fusion takes one visual map per source (C = 2)")
         H, W = vs[0].shape[-2:]
         HW = H * W
@@ -68,13 +69,14 @@ class _FusionBase(nn.Module):
                  ptr(dfeat), ptr(dx_accum))
             return []
         dvs = [torch.empty_like(v) for v in vs]
+        v1, dv1 = (vs[0], None) if self.kind == 2 else (vs[1], dvs[1])
         dm = None
         if dmatch is not None:
             dm = dmatch.reshape(1).contiguous().float()
-        call("avsep_fusion_av_bwd", ptr(x), ptr(vs[0]), ptr(vs[1]), B, Dc, FT, fus["HW"], self.kind,
+        call("avsep_fusion_av_bwd", ptr(x), ptr(vs[0]), ptr(v1), B, Dc, FT, fus["HW"], self.kind,
              _ATT[self.att_type], ptr(fus["a_pool"]), ptr(fus["pool_idx"]), ptr(fus["sel_idx"]),
              ptr(fus["att_maps"]), ptr(fus["best"]), ptr(dfeat), None, ptr(dm), 1.0 / B if dm is not None else 0.0,
-             ptr(dx_accum), ptr(dvs[0]), ptr(dvs[1]))
+             ptr(dx_accum), ptr(dvs[0]), ptr(dv1))
         return dvs
 
     # ------------------------------------------------------------------ module interface

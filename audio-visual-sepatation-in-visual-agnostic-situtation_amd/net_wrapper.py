@@ -100,6 +100,29 @@ class NetWrapper(torch.nn.Module):
                      "weight": weight, "match_loss": match_loss.reshape(1), "att_maps": meta[1],
                      "logits": feat_sound}
 
+    # ------------------------------------------------------------------ main.py:162-192 (MixVis)
+    def forward_avmiximg(self, data, args):
+        frames, _, mags, mag_mix, log_mag_mix, gt_masks, weight = data
+        mix_frame = torch.cat(list(frames), dim=-1)                          # B x 3 x T x H x (W*S)
+        feat_frame = activate(self.net_frame.forward_multiframe(mix_frame, pool=args.not_pool_vis),
+                              args.img_activation)
+        feat_sound, meta = self.net_sound(log_mag_mix, [feat_frame])
+        act = ACT_BY_NAME.get(args.output_activation)
+        if act is None:
+            raise Exception("Unkown activation!")
+        pred, sums, FT = mask_loss(feat_sound, self._gt_stack, weight, act, "bce")
+        mat = sums / FT
+        perms = best_permutations(mat.detach().cpu().numpy())
+        idx = torch.tensor(perms, device=mat.device)
+        err = torch.gather(mat, 2, idx[:, :, None]).squeeze(-1).mean(-1).mean().to(torch.float32).reshape(1)
+        ordered = PitWrapper.reorder_tensor(pred.permute(0, 2, 3, 1), perms)
+        gt = torch.stack(gt_masks, dim=-1)[:, 0]
+        match_loss = meta[0].reshape(1)
+        err = err + match_loss * args.match_weight
+        return err, {"pred_masks": [ordered[..., i].unsqueeze(1) for i in range(2)],
+                     "gt_masks": [gt[..., i].unsqueeze(1) for i in range(2)],
+                     "mag_mix": mag_mix, "mags": mags, "weight": weight, "match_loss": match_loss, "maps": meta[1]}
+
     # ------------------------------------------------------------------ main.py:150-160
     def forward(self, batch_data, args, use_vis, is_share=False):
         if "mag_mix" not in batch_data:
@@ -107,7 +130,7 @@ class NetWrapper(torch.nn.Module):
         data = self.prepare(batch_data, args, use_vis, is_share)
         if use_vis:
             if args.fusion_type == "MixVis":
-                raise lib.AvsepError("forward_avmiximg (MixVis) is not built on the HIP path yet")
+                return self.forward_avmiximg(data, args)
             return self.forward_av(data, args)
         return self.forward_ao(data, args)
 

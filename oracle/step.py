@@ -106,7 +106,11 @@ class NetWrapper(torch.nn.Module):
         feat_sound, meta = self.net_sound(log_mag_mix, [feat_frame])
         pred = activate(feat_sound, args.output_activation).permute(0, 2, 3, 1)
         gt = torch.stack(gt_masks, -1)[:, 0]
-        err, perms = self.crit_ao(pred, gt, weight)
+        # main.py:181 passes the un-stacked [B,1,F,T] weight, which makes PitWrapper's
+        # binary_cross_entropy raise a broadcast error: the MixVis branch cannot run as shipped.
+        # Build-defined repair: the per-target weight stacking of forward_ao (main.py:103).
+        w2 = torch.stack([weight[:, 0]] * 2, -1)
+        err, perms = self.crit_ao(pred, gt, w2)
         err = err.mean().reshape(1)
         pred = self.crit_ao.reorder_tensor(pred, perms)
         err = err + meta[0] * args.match_weight
