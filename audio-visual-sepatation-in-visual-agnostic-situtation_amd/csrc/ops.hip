@@ -815,6 +815,36 @@ extern "C" int avsep_innerprod_fwd(const float* img, const float* snd, const flo
   return AVSEP_OK;
 }
 
+// backward of the synthesizer GEMV: dsnd[b,k,hw] = w[b,k]*dz[b,hw];  r[b,k] = sum_hw snd[b,k,hw]*dz[b,hw]
+// (w = img*scale; the caller forms dimg = scale*r, dscale = sum_b img*r, dbias = sum dz from r and dz)
+__global__ __launch_bounds__(256) void innerprod_bwd_kernel(const float* __restrict__ img, const float* __restrict__ snd,
+                                                            const float* __restrict__ scale, const float* __restrict__ dz,
+                                                            int K, int HW, float* __restrict__ dsnd, float* __restrict__ r) {
+  const int k = blockIdx.x, b = blockIdx.y;
+  const float w = img[(long long)b * K + k] * (scale ? scale[k] : 1.f);
+  const float* sp = snd + ((long long)b * K + k) * HW;
+  const float* dp = dz + (long long)b * HW;
+  float* op = dsnd ? dsnd + ((long long)b * K + k) * HW : nullptr;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    float d = dp[i];
+    acc = fmaf(sp[i], d, acc);
+    if (op) op[i] = w * d;
+  }
+  acc = wave_sum(acc);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) r[(long long)b * K + k] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+extern "C" int avsep_innerprod_bwd(const float* img, const float* snd, const float* scale, const float* dz, int32_t B,
+                                   int32_t K, int32_t HW, float* dsnd, float* r, avsep_stream_t stream) {
+  if (!img || !snd || !dz || !r || B <= 0 || B > 65535 || K <= 0 || HW <= 0) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(innerprod_bwd_kernel, dim3(K, B), dim3(256), 0, (hipStream_t)stream, img, snd, scale, dz, K, HW, dsnd, r);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
 extern "C" int avsep_version(void) { return 100; }
 extern "C" const char* avsep_arch(void) { return "gfx950"; }
 extern "C" const char* avsep_strerror(int code) {

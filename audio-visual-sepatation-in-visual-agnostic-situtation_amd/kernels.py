@@ -125,15 +125,15 @@ def affine_act_bwd_(dz, y, scale, shift, residual, add, mean, invstd, act, bstat
 class Cat:
     def __init__(self, x0, x1, sc0=None, sh0=None, sc1=None, sh1=None, bcast0=False, hw=None):
         N, C0 = x0.shape[:2]
-        C1 = x1.shape[1]
-        H, W = hw if hw is not None else x1.shape[2:]
+        C1 = x1.shape[1] if x1 is not None else 0
+        H, W = hw if hw is not None else (x1.shape[2:] if x1 is not None else x0.shape[2:])
         self.shape = (N, C0, C1, H, W)
         self.keep = (x0, x1, sc0, sh0, sc1, sh1)
         d = CatDesc()
         d.N, d.C0, d.C1, d.H, d.W, d.bcast0, d.bcast1 = N, C0, C1, H, W, int(bcast0), 0
         d.x0, d.x1 = ptr(x0), ptr(x1)
         d.scale0, d.shift0, d.scale1, d.shift1 = ptr(sc0), ptr(sh0), ptr(sc1), ptr(sh1)
-        self.d, self.ref, self.like, self.bcast0 = d, C.byref(d), x1, bcast0
+        self.d, self.ref, self.like, self.bcast0 = d, C.byref(d), (x1 if x1 is not None else x0), bcast0
 
     def fwd(self):
         N, C0, C1, H, W = self.shape
@@ -144,7 +144,7 @@ class Cat:
     def bwd(self, dout, mean1=None, invstd1=None, bstats1=None):
         N, C0, C1, H, W = self.shape
         g0 = _f32((N, C0) if self.bcast0 else (N, C0, H, W), self.like)
-        g1 = _f32((N, C1, H, W), self.like)
+        g1 = _f32((N, C1, H, W), self.like) if C1 else None
         call("avsep_relu_up2x_bwd", self.ref, ptr(dout), ptr(g0), ptr(g1), ptr(mean1), ptr(invstd1),
              ptr(bstats1), 0)
         return g0, g1

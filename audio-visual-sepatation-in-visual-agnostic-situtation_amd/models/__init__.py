@@ -13,6 +13,7 @@ from .audio_net import Unet
 from .vision_net import ResnetFC, ResnetDilated
 from .criterion import BCELoss, L1Loss, L2Loss, PitWrapper
 from .fusion_net import get_fusion_net
+from .attention_net import get_attmodule, AttModel, MatchAtt
 
 _ACTIVATIONS = {
     "sigmoid": torch.sigmoid,
@@ -53,10 +54,13 @@ class ModelBuilder:
         elif "Linear" in name:
             m.weight.data.normal_(0.0, 0.0001)
 
-    def build_sound(self, arch="unet5", fc_dim=64, weights="", fusion_type="con_motion", att_type="cos"):
+    def build_sound(self, arch="unet5", fc_dim=64, weights="", fusion_type="con_motion", att_type="cos",
+                    extra_size=None):
+        # extra_size: the SoP++ driver's extra keyword (SoP++/main.py:727-732) selects the basis U-Net
         if arch not in _UNET_DOWNS:
             raise Exception("Architecture undefined!")
-        net = Unet(fc_dim=fc_dim, num_downs=_UNET_DOWNS[arch], fusion_type=fusion_type, att_type=att_type)
+        net = Unet(fc_dim=fc_dim, num_downs=_UNET_DOWNS[arch], fusion_type=fusion_type, att_type=att_type,
+                   extra_size=extra_size)
         net.apply(self.weights_init)
         return _maybe_load(net, weights, "net_sound")
 

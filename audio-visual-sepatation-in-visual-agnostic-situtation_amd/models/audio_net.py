@@ -81,14 +81,21 @@ class _Level(nn.Module):
 
 class Unet(nn.Module):
     def __init__(self, fc_dim=64, num_downs=5, ngf=64, use_dropout=False, fusion_type="con_motion",
-                 att_type="cos", fuse_upsample=False):
+                 att_type="cos", fuse_upsample=False, extra_size=None):
         super().__init__()
         if use_dropout:
             raise NotImplementedError("use_dropout is never enabled by the reference builders")
-        self.fusion = fusion_net.get_fusion_net(fusion_type)(att_type=att_type)
+        self.extra_size = extra_size
         self.fusion_type, self.att_type = fusion_type, att_type
         self.fuse_upsample = fuse_upsample
-        lvl = _Level(ngf * 8, ngf * 8, ngf * 8, ngf * 16, "inner", None)
+        if extra_size is None:
+            self.fusion = fusion_net.get_fusion_net(fusion_type)(att_type=att_type)
+            lvl = _Level(ngf * 8, ngf * 8, ngf * 8, ngf * 16, "inner", None)
+        else:
+            # SoP++ variant (SoP++/audio_net.py:151-198): the bottleneck conv also emits 2*extra_size
+            # per-source "weight" channels, split off before the decoder; no fusion
+            self.fusion = None
+            lvl = _Level(ngf * 8, ngf * 8 + 2 * extra_size, ngf * 8, ngf * 8, "inner", None)
         for _ in range(num_downs - 5):
             lvl = _Level(ngf * 8, ngf * 8, ngf * 8, ngf * 16, "mid", lvl)
         lvl = _Level(ngf * 4, ngf * 8, ngf * 4, ngf * 16, "mid", lvl)
@@ -131,6 +138,9 @@ class Unet(nn.Module):
     def forward(self, x, v=None):
         lib.require_gpu(x)
         B = x.shape[0]
+        if self.extra_size is not None:
+            feat, extra, _ = _UnetFn.apply(self, None, 0, x.contiguous().float(), *self.param_list())
+            return feat, (extra,)
         draws = None
         if v is None:
             draws = self.ao_draws if self.ao_draws is not None else (torch.rand(B) > 0.5)
@@ -183,11 +193,16 @@ class _UnetFn(torch.autograd.Function):
             S["dconv"].append(cv); S["yd"].append(y); S["dbn"].append(bn)
             src, aff, act = y, bn, ACT_LRELU02
 
-        # ---- bottleneck fusion (models/fusion_net.py) ----
+        # ---- bottleneck fusion (models/fusion_net.py) / SoP++ split ----
         ybot = S["yd"][-1]
-        fus = net.fusion.run_forward(ybot, vs, draws)
-        S["fus"] = fus
-        feat_vec = fus["feat"]                                   # [B, D] broadcast vectors
+        extra = fus = feat_vec = None
+        if net.extra_size is None:
+            fus = net.fusion.run_forward(ybot, vs, draws)
+            feat_vec = fus["feat"]                               # [B, D] broadcast vectors
+        else:
+            e2 = 2 * net.extra_size
+            extra, ybot = ybot[:, :e2].contiguous(), ybot[:, e2:].contiguous()
+        S["fus"], S["ybot"] = fus, ybot
 
         # ---- decoder: ReLU + bilinear x2 + conv k3 p1 over concat(skip, inner) ----
         S["uconv"], S["yu"], S["ubn"], S["cat"], S["U"] = [None] * L, [None] * L, [None] * L, [None] * L, [None] * L
@@ -195,7 +210,7 @@ class _UnetFn(torch.autograd.Function):
             l = lv[i]
             w = l.up_conv.weight.detach()
             if i == L - 1:
-                cat = K.Cat(feat_vec, ybot, bcast0=True)
+                cat = K.Cat(feat_vec, ybot, bcast0=True) if feat_vec is not None else K.Cat(ybot, None)
                 fused = False
             else:
                 dbn, ubn = S["dbn"][i], S["ubn"][i + 1]
@@ -217,6 +232,8 @@ class _UnetFn(torch.autograd.Function):
 
         ctx.S, ctx.net, ctx.nv, ctx.training = S, net, nv, training
         logits = S["yu"][0]
+        if net.extra_size is not None:
+            return logits, extra, x.new_zeros(())
         if nv:
             match = fus["match_part"].mean()
             att = fus["att_maps"]
@@ -228,6 +245,7 @@ class _UnetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits, dmatch, _datt):
+        # dmatch is the cotangent of the second output: the match loss, or the SoP++ `extra` channels
         S, net, nv = ctx.S, ctx.net, ctx.nv
         if not ctx.training:
             raise lib.AvsepError("backward through the U-Net needs train mode (batch statistics)")
@@ -254,7 +272,11 @@ class _UnetFn(torch.autograd.Function):
                 grads[l.up_conv.bias] = db
             dU = cv.dgrad(cv.pack(w, 1), g)                    # wrt the (virtual) upsampled input
             if i == L - 1:
-                dfeat, dbot = cat.bwd(dU)
+                if net.extra_size is None:
+                    dfeat, dbot = cat.bwd(dU)
+                else:
+                    dxb, _ = cat.bwd(dU)
+                    dbot = torch.cat([dmatch.to(dxb.dtype).contiguous(), dxb], 1)
             else:
                 ubn = S["ubn"][i + 1]
                 bst = K.zeros_stats(ubn.shape[1], x)
@@ -265,7 +287,9 @@ class _UnetFn(torch.autograd.Function):
             del dU
 
         # ---- fusion backward: adds into dbot, returns the visual-feature gradients ----
-        dvs = net.fusion.run_backward(S["yd"][-1], S["vs"], S["fus"], dfeat, dbot, None, dmatch if nv else None)
+        dvs = []
+        if net.extra_size is None:
+            dvs = net.fusion.run_backward(S["ybot"], S["vs"], S["fus"], dfeat, dbot, None, dmatch if nv else None)
 
         # ---- encoder backward, innermost -> outermost ----
         g = dbot

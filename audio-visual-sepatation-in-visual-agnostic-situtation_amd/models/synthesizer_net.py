@@ -1,7 +1,7 @@
 """Mask synthesizer (reference: models/synthesizer_net.py:6-70); used by the SoP++ variant only.
 
-forward() of InnerProd/Bias (the K-vector x K basis maps GEMV, HBM bound) is a HIP kernel when no
-gradient is required; the differentiable and the per-pixel inference forms use PyTorch-ROCm ops.
+``forward`` — the K-vector x K basis maps GEMV (8.4 MB of basis per sample at K=32: HBM bound) — and its
+backward are HIP kernels; ``forward_nosum`` / ``forward_pixelwise`` (inference helpers) use PyTorch-ROCm ops.
 """
 import torch
 import torch.nn as nn
@@ -10,27 +10,48 @@ from .. import lib
 from ..lib import call, ptr
 
 
+class _InnerProdFn(torch.autograd.Function):
+    """z[b,hw] = sum_k img[b,k]*scale[k]*snd[b,k,hw] + bias  (scale may be None for `Bias`)."""
+
+    @staticmethod
+    def forward(ctx, img, snd, scale, bias):
+        lib.require_gpu(snd)
+        B, K = snd.shape[:2]
+        HW = snd[0, 0].numel()
+        img, snd = img.reshape(B, K).contiguous().float(), snd.contiguous().float()
+        z = torch.empty((B, 1) + tuple(snd.shape[2:]), dtype=torch.float32, device=snd.device)
+        call("avsep_innerprod_fwd", ptr(img), ptr(snd), ptr(scale), ptr(bias), B, K, HW, ptr(z))
+        ctx.save_for_backward(img, snd, scale)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        img, snd, scale = ctx.saved_tensors
+        B, K = snd.shape[:2]
+        HW = snd[0, 0].numel()
+        dz = dz.contiguous()
+        dsnd = torch.empty_like(snd) if ctx.needs_input_grad[1] else None
+        r = torch.empty((B, K), dtype=torch.float32, device=snd.device)
+        call("avsep_innerprod_bwd", ptr(img), ptr(snd), ptr(scale), ptr(dz), B, K, HW, ptr(dsnd), ptr(r))
+        dimg = r * scale if scale is not None else r
+        dscale = (img * r).sum(0) if scale is not None else None
+        return dimg, dsnd, dscale, dz.sum().reshape(1)
+
+
 class InnerProd(nn.Module):
     def __init__(self, fc_dim):
         super().__init__()
         self.scale = nn.Parameter(torch.ones(fc_dim))
         self.bias = nn.Parameter(torch.zeros(1))
 
+    def _scale(self):
+        return self.scale
+
     def _w(self, f):
         return f * self.scale
 
     def forward(self, feat_img, feat_sound):
-        B, C = feat_sound.shape[:2]
-        if feat_sound.is_cuda and not (torch.is_grad_enabled() and (
-                feat_img.requires_grad or feat_sound.requires_grad or self.bias.requires_grad)):
-            z = torch.empty((B, 1) + tuple(feat_sound.shape[2:]), dtype=torch.float32, device=feat_sound.device)
-            scale = getattr(self, "scale", None)
-            call("avsep_innerprod_fwd", ptr(feat_img.reshape(B, C).contiguous().float()),
-                 ptr(feat_sound.contiguous().float()), ptr(scale.detach() if scale is not None else None),
-                 ptr(self.bias.detach()), B, C, feat_sound[0, 0].numel(), ptr(z))
-            return z
-        z = torch.bmm(self._w(feat_img.view(B, 1, C)), feat_sound.reshape(B, C, -1))
-        return z.view(B, 1, *feat_sound.shape[2:]) + self.bias
+        return _InnerProdFn.apply(feat_img, feat_sound, self._scale(), self.bias)
 
     def forward_nosum(self, feat_img, feat_sound):
         B, C = feat_sound.shape[:2]
@@ -47,6 +68,9 @@ class Bias(InnerProd):
     def __init__(self):
         nn.Module.__init__(self)
         self.bias = nn.Parameter(torch.zeros(1))
+
+    def _scale(self):
+        return None
 
     def _w(self, f):
         return f

@@ -242,6 +242,10 @@ int avsep_sgd_momentum(float* p, const float* g, float* buf, size_t n, float lr,
 /* InnerProd / Bias synthesizer (models/synthesizer_net.py:12-19): z[b,hw] = sum_k img[b,k]*scale[k]*snd[b,k,hw] + bias */
 int avsep_innerprod_fwd(const float* img, const float* snd, const float* scale, const float* bias,
                         int32_t B, int32_t K, int32_t HW, float* z, avsep_stream_t stream);
+/* backward: dsnd[b,k,hw] = img[b,k]*scale[k]*dz[b,hw] (optional) and r[b,k] = sum_hw snd[b,k,hw]*dz[b,hw],
+ * from which the caller forms dimg = scale*r, dscale = sum_b img*r, dbias = sum dz. */
+int avsep_innerprod_bwd(const float* img, const float* snd, const float* scale, const float* dz,
+                        int32_t B, int32_t K, int32_t HW, float* dsnd, float* r, avsep_stream_t stream);
 
 #ifdef __cplusplus
 }

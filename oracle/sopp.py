@@ -67,3 +67,55 @@ class AttModule(nn.Module):
         a = both[torch.arange(B), idx[:, 0]]
         ctx, (_, maps) = self.infer(a, mix_vis)
         return ctx, (match, maps)
+
+
+# ---------------------------------------------------------------------------
+# Stage math of SoP++/main.py:94-246 on the oracle modules (same documented repairs as the product:
+# stacked PIT weight in ao_forward; stages 2/3 need AttModel's 3-tuple meta).
+# ---------------------------------------------------------------------------
+class SopNetWrapper(nn.Module):
+    def __init__(self, nets, crit_ao, crit_av):
+        super().__init__()
+        self.net_sound, self.net_frame, self.net_synthesizer, self.net_pit = nets
+        self.crit_ao, self.crit_av = crit_ao, crit_av
+
+    def forward(self, batch, args, use_vis, stage=3):
+        from .step import prepare
+        from .nets import activate
+        mags, mag_mix, log_mag_mix, gt_masks, weight = prepare(batch, args)
+        N = args.num_mix
+        basis, meta = self.net_sound(log_mag_mix)
+        basis = activate(basis, args.sound_activation)
+        fw = torch.tensor_split(meta[0], N, dim=1)
+
+        def synth(ctx):
+            return [activate(self.net_synthesizer(ctx[:, n, :], basis), args.output_activation) for n in range(N)]
+        if not use_vis:
+            ctx, _ = self.net_pit(fw, None, None)
+            pred = torch.stack(synth(ctx), -1).squeeze(1)
+            gt = torch.stack(gt_masks, -1)[:, 0]
+            err, perms = self.crit_ao(pred, gt, torch.stack([weight[:, 0]] * N, -1))
+            ordered = self.crit_ao.reorder_tensor(pred, perms)
+            return err.mean(), {"pred_masks": [ordered[..., i].unsqueeze(1) for i in range(N)]}
+        frames = batch["frames"]
+
+        def vis():
+            return [activate(self.net_frame.forward_multiframe(f, args.not_pool_vis), args.img_activation) for f in frames]
+        if stage == 1:
+            ff = vis()
+        else:
+            with torch.no_grad():
+                ff = vis()
+            mix = activate(self.net_frame.forward_multiframe(torch.cat(frames, -1), args.not_pool_vis), args.img_activation)
+            ctx3, m = self.net_pit(fw, mix, ff)
+        gctx = activate(torch.stack(ff, 1).mean(dim=(-2, -1)), args.output_activation)
+        if stage == 3:
+            pred = synth(activate(ctx3, args.output_activation))
+            extra = m[1] + m[0]
+        else:
+            pred = synth(gctx)
+            extra = m[1] if stage == 2 else None
+        err = self.crit_av(pred, gt_masks, weight).reshape(1)
+        if extra is not None:
+            err = err + extra * args.match_weight
+        return err, {"pred_masks": pred, "match_loss": extra}

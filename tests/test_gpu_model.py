@@ -240,3 +240,69 @@ def test_mixvis_step_vs_oracle(dev):
         for n in range(2):
             assert ((outs["pred_masks"][n].detach().cpu() - oouts["pred_masks"][n].detach()) ** 2).mean().item() < 1e-6
         assert_close(outs["maps"], oouts["maps"], 2e-4, "maps")
+
+
+def test_sopp_variant_vs_oracle(dev, golden):
+    """SoP++ operators (A17-A20): basis U-Net (golden from the reference's SoP++/audio_net.py), InnerProd
+    fwd/bwd, attention module, and the four stage forwards + backward against the CPU oracle."""
+    P = _pkg()
+    from oracle import nets as O, sopp as OSP, criterion as OC
+    from avsep_amd import sopp as PS
+    G = golden("sopp")
+    net = P.models.Unet(fc_dim=6, num_downs=5, ngf=4, extra_size=6)
+    sd = {k[7:]: v for k, v in G.items() if k.startswith("unet.w.")}
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    y, (extra,) = net(G["unet.x"].to(dev))
+    assert_close(y, G["unet.basis"], 2e-4, "sopp basis")
+    assert_close(extra, G["unet.extra"], 2e-4, "sopp extra")
+    # attention modules against the reference's goldens
+    aud, sep = [G["aud0"].to(dev), G["aud1"].to(dev)], [G["sep0"].to(dev), G["sep1"].to(dev)]
+    for cname, cls in (("AttModel", P.models.AttModel), ("MatchAtt", P.models.MatchAtt)):
+        for at in ("cos", "sig"):
+            m, tag = cls(att_type=at), f"{cname}.{at}"
+            assert_close(m(aud, None, None)[0], G[tag + ".ao.ctx"], 1e-5)
+            ctx, meta = m(aud, G["mix"].to(dev), sep)
+            assert_close(ctx, G[tag + ".train.ctx"], 1e-5)
+            for i, t in enumerate(meta):
+                assert_close(t, G[tag + f".train.meta{i}"], 1e-5)
+    # stage math on small nets, product vs oracle (same weights, same inputs)
+    torch.manual_seed(9)
+    gen = torch.Generator().manual_seed(9)
+    K = 8
+    osnd = O.Unet(fc_dim=K, num_downs=5, ngf=8, extra_size=K)
+    O.wide_init(osnd, gen)
+    ofrm = O.VisualNet(fc_dim=K, pool_type="maxpool", dilate_scale=16)
+    osyn, opit = O.InnerProd(K), OSP.AttModule("AttModel", "sig")
+    with torch.no_grad():
+        osyn.scale.copy_(torch.rand(K, generator=gen) + 0.5)
+    snd = P.models.Unet(fc_dim=K, num_downs=5, ngf=8, extra_size=K)
+    frm = P.models.ResnetDilated(None, fc_dim=K, pool_type="maxpool")
+    syn = P.ModelBuilder().build_synthesizer("linear", fc_dim=K)
+    snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict()); syn.load_state_dict(osyn.state_dict())
+    snd, frm, syn = snd.to(dev), frm.to(dev), syn.to(dev)
+    args = _args(sound_activation="no", fusion_type="Base", att_type="sig")
+    pit = P.models.get_attmodule(args)(att_type="sig")
+    mb = P.ModelBuilder()
+    wrap = PS.NetWrapper((snd, frm, syn, pit), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
+    owrap = OSP.SopNetWrapper((osnd, ofrm, osyn, opit), OC.build_criterion("bce", True), OC.build_criterion("bce"))
+    srcs = [torch.rand(2, 1, 64, 64, generator=gen) ** 2 for _ in range(2)]
+    frames = [torch.randn(2, 3, 2, 64, 64, generator=gen) for _ in range(2)]
+
+    def batch(d):
+        return {"mag_mix": (srcs[0] + srcs[1]).to(d), "mags": [s.clone().to(d) for s in srcs], "frames": [f.to(d) for f in frames]}
+    for use_vis, stage in ((True, 1), (True, 2), (True, 3), (False, 0)):
+        for m in (snd, frm, syn, osnd, ofrm, osyn):
+            m.zero_grad()
+        wrap.train(); owrap.train()
+        err, outs = wrap(batch(dev), args, use_vis, stage)
+        oerr, oouts = owrap(batch("cpu"), args, use_vis, stage)
+        err.mean().backward(); oerr.mean().backward()
+        assert abs(err.mean().item() - oerr.mean().item()) < 2e-4, (stage, err, oerr)
+        for n in range(2):
+            assert ((outs["pred_masks"][n].detach().cpu() - oouts["pred_masks"][n].detach()) ** 2).mean().item() < 1e-6
+        assert_close(syn.scale.grad, osyn.scale.grad, 3e-3, f"stage {stage} dscale")
+        assert_close(snd.unet_block.up_forward.at(2).weight.grad, osnd.unet_block.up_conv.weight.grad, 3e-3, f"stage {stage} last conv grad")
+        k = "unet_block.mid_forward.mid_forward.mid_forward.mid_forward.down_forward.1.weight"
+        assert_close(dict(snd.named_parameters())[k].grad, dict(osnd.named_parameters())[k].grad, 3e-3, f"stage {stage} bottleneck conv grad")
