@@ -141,12 +141,13 @@ class Cat:
         call("avsep_relu_up2x_fwd", self.ref, ptr(out))
         return out
 
-    def bwd(self, dout, mean1=None, invstd1=None, bstats1=None):
+    def bwd(self, dout, mean1=None, invstd1=None, bstats1=None, g0_acc=None):
+        """g0_acc: an existing source-0 gradient to accumulate into (shared-encoder AV step)."""
         N, C0, C1, H, W = self.shape
-        g0 = _f32((N, C0) if self.bcast0 else (N, C0, H, W), self.like)
+        g0 = g0_acc if g0_acc is not None else _f32((N, C0) if self.bcast0 else (N, C0, H, W), self.like)
         g1 = _f32((N, C1, H, W), self.like) if C1 else None
         call("avsep_relu_up2x_bwd", self.ref, ptr(dout), ptr(g0), ptr(g1), ptr(mean1), ptr(invstd1),
-             ptr(bstats1), 0)
+             ptr(bstats1), int(g0_acc is not None))
         return g0, g1
 
 

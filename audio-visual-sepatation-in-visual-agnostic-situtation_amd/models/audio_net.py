@@ -135,6 +135,16 @@ class Unet(nn.Module):
                 ps += [l.up_bn.weight, l.up_bn.bias]
         return ps
 
+    def forward_pair(self, x, v_a, v_b):
+        """Two audio-visual passes on the same input with different visual inputs (the AV step of main.py:113-148),
+        sharing the encoder.  Returns ((feat_a, meta_a), (feat_b, meta_b)) exactly like two forward() calls."""
+        lib.require_gpu(x)
+        if self.extra_size is not None or len(v_a) != 2 or len(v_b) != 2:
+            return self.forward(x, v_a), self.forward(x, v_b)
+        vs = [t.contiguous().float() for t in (*v_a, *v_b)]
+        fa, ma, aa, fb, mb, ab = _UnetPairFn.apply(self, x.contiguous().float(), *vs, *self.param_list())
+        return (fa, (ma, aa)), (fb, (mb, ab))
+
     def forward(self, x, v=None):
         lib.require_gpu(x)
         B = x.shape[0]
@@ -154,166 +164,207 @@ class Unet(nn.Module):
         return feat, (match_loss, att_maps)
 
 
-def _bn_run(bn, stats, count, training, like):
-    """scale/shift/mean/invstd rows for one BatchNorm; updates the running buffers in training."""
-    out = K.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                        BN_MOMENTUM, BN_EPS, training, like)
+def _bn_run(bn, stats, count, training, like, repeat=1):
+    """scale/shift/mean/invstd rows for one BatchNorm; updates the running buffers in training
+    (`repeat` times: a shared encoder stands for `repeat` identical forward passes of the reference)."""
+    for _ in range(repeat):
+        out = K.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                            BN_MOMENTUM, BN_EPS, training, like)
     if training:
-        bn.num_batches_tracked += 1
+        bn.num_batches_tracked += repeat
     return out
+
+
+def _acc(grads, p, g):
+    if g is not None:
+        grads[p] = grads[p] + g if p in grads else g
+
+
+def _bn_back(grads, bn_mod, bnrow, bstats, count):
+    dgamma, dbeta, pqr = K.bn_bwd_coeffs(bstats, count, bn_mod.weight.detach(), bnrow[2], bnrow[3])
+    _acc(grads, bn_mod.weight, dgamma)
+    _acc(grads, bn_mod.bias, dbeta)
+    return pqr
+
+
+def _encode(net, x, training, repeat=1):
+    """bn0 + the down convs (conv k4 s2 p1; the previous level's BatchNorm + LeakyReLU are folded into the gather)."""
+    lv = net.levels()
+    B, _, H, W = x.shape
+    E = {"x": x, "lv": lv}
+    st0 = K.zeros_stats(1, x)
+    if training:
+        K.channel_stats(x, st0)
+    E["bn0"] = _bn_run(net.bn0, st0, B * H * W, training, x, repeat)     # audio_net.py:37,41
+    src, aff, act = x, E["bn0"], ACT_NONE
+    E["dconv"], E["yd"], E["dbn"] = [], [], []
+    for l in lv:
+        w = l.down_conv.weight.detach()
+        cv = K.Conv(src, w.shape[0], 4, 2, 1, sc0=aff[0] if aff is not None else None,
+                    sh0=aff[1] if aff is not None else None, act0=act)
+        st = K.zeros_stats(w.shape[0], x) if (l.down_bn is not None and training) else None
+        y = cv.fwd(cv.pack(w, 0), None, st)
+        bn = _bn_run(l.down_bn, st, y.numel() // y.shape[1], training, x, repeat) if l.down_bn is not None else None
+        E["dconv"].append(cv); E["yd"].append(y); E["dbn"].append(bn)
+        src, aff, act = y, bn, ACT_LRELU02
+    return E
+
+
+def _decode(net, E, vs, draws, training):
+    """Bottleneck fusion (or the SoP++ split) + the up path: ReLU + bilinear x2 + conv k3 p1 over concat(skip, inner)."""
+    lv, x = E["lv"], E["x"]
+    L = len(lv)
+    ybot = E["yd"][-1]
+    extra = fus = feat_vec = None
+    if net.extra_size is None:
+        fus = net.fusion.run_forward(ybot, vs, draws)
+        feat_vec = fus["feat"]                               # [B, D] broadcast vectors
+    else:
+        e2 = 2 * net.extra_size
+        extra, ybot = ybot[:, :e2].contiguous(), ybot[:, e2:].contiguous()
+    D = {"fus": fus, "ybot": ybot, "extra": extra, "vs": vs,
+         "uconv": [None] * L, "yu": [None] * L, "ubn": [None] * L, "cat": [None] * L}
+    for i in range(L - 1, -1, -1):
+        l = lv[i]
+        w = l.up_conv.weight.detach()
+        if i == L - 1:
+            cat = K.Cat(feat_vec, ybot, bcast0=True) if feat_vec is not None else K.Cat(ybot, None)
+            fused = False
+        else:
+            dbn, ubn = E["dbn"][i], D["ubn"][i + 1]
+            cat = K.Cat(E["yd"][i], D["yu"][i + 1], sc0=dbn[0] if dbn is not None else None,
+                        sh0=dbn[1] if dbn is not None else None, sc1=ubn[0], sh1=ubn[1])
+            fused = net.fuse_upsample
+        if fused:   # upsample folded into the conv's operand staging: nothing materialised
+            cv = K.Conv(cat.keep[0], w.shape[0], 3, 1, 1, x1=cat.keep[1], sc0=cat.keep[2], sh0=cat.keep[3],
+                        act0=ACT_RELU, sc1=cat.keep[4], sh1=cat.keep[5], act1=ACT_RELU, up2x=True)
+        else:
+            cv = K.Conv(cat.fwd(), w.shape[0], 3, 1, 1)
+        st = K.zeros_stats(w.shape[0], x) if (l.up_bn is not None and training) else None
+        bias = l.up_conv.bias.detach() if l.up_conv.bias is not None else None
+        y = cv.fwd(cv.pack(w, 0), bias, st)
+        bn = _bn_run(l.up_bn, st, y.numel() // y.shape[1], training, x) if l.up_bn is not None else None
+        D["uconv"][i], D["yu"][i], D["ubn"][i], D["cat"][i] = cv, y, bn, cat
+    return D
+
+
+def _decode_bwd(net, E, D, dlogits, dsecond, has_vis, grads, Gd):
+    """Decoder + fusion backward, outermost -> innermost.  Accumulates parameter gradients into `grads` and the
+    skip-path gradients into Gd[i] (gradient reaching BN(yd[i]), already ReLU-masked); returns (dbot, dvs)."""
+    lv, x = E["lv"], E["x"]
+    L = len(lv)
+    g = dlogits.contiguous()
+    dfeat = dbot = None
+    for i in range(L):
+        l, cv, cat = lv[i], D["uconv"][i], D["cat"][i]
+        w = l.up_conv.weight.detach()
+        dw, db = cv.wgrad(g, want_bias=l.up_conv.bias is not None)
+        _acc(grads, l.up_conv.weight, dw)
+        _acc(grads, l.up_conv.bias, db)
+        dU = cv.dgrad(cv.pack(w, 1), g)                    # wrt the (virtual) upsampled input
+        if i == L - 1:
+            if net.extra_size is None:
+                dfeat, dbot = cat.bwd(dU)
+            else:
+                dxb, _ = cat.bwd(dU)
+                dbot = torch.cat([dsecond.to(dxb.dtype).contiguous(), dxb], 1)
+        else:
+            ubn = D["ubn"][i + 1]
+            bst = K.zeros_stats(ubn.shape[1], x)
+            Gd[i], dz = cat.bwd(dU, mean1=ubn[2], invstd1=ubn[3], bstats1=bst, g0_acc=Gd[i])
+            yu = D["yu"][i + 1]
+            pqr = _bn_back(grads, lv[i + 1].up_bn, ubn, bst, yu.numel() // yu.shape[1])
+            g = K.bn_bwd_apply_(dz, yu, pqr)
+        del dU
+    dvs = []
+    if net.extra_size is None:   # adds the fusion's gradient wrt the bottleneck into dbot
+        dvs = net.fusion.run_backward(D["ybot"], D["vs"], D["fus"], dfeat, dbot, None, dsecond if has_vis else None)
+    return dbot, dvs
+
+
+def _encode_bwd(net, E, dbot, Gd, grads):
+    """Encoder backward, innermost -> outermost (LeakyReLU' + skip-gradient add + BN backward between the convs)."""
+    lv, x = E["lv"], E["x"]
+    g = dbot
+    for i in range(len(lv) - 1, -1, -1):
+        l, cv = lv[i], E["dconv"][i]
+        w = l.down_conv.weight.detach()
+        _acc(grads, l.down_conv.weight, cv.wgrad(g)[0])
+        dS = cv.dgrad(cv.pack(w, 1), g)                   # wrt act(BN(prev)) (or BN0(x) for i == 0)
+        if i > 0:
+            yprev, bn = E["yd"][i - 1], E["dbn"][i - 1]
+            bst = K.zeros_stats(yprev.shape[1], x) if bn is not None else None
+            K.affine_act_bwd_(dS, yprev, bn[0] if bn is not None else None, bn[1] if bn is not None else None,
+                              None, Gd[i - 1], bn[2] if bn is not None else None,
+                              bn[3] if bn is not None else None, ACT_LRELU02, bst)
+            g = K.bn_bwd_apply_(dS, yprev, _bn_back(grads, lv[i - 1].down_bn, bn, bst, yprev.numel() // yprev.shape[1])) \
+                if bn is not None else dS
+        else:
+            bn0 = E["bn0"]
+            bst = K.zeros_stats(1, x)
+            K.affine_act_bwd_(dS, x, None, None, None, None, bn0[2], bn0[3], ACT_NONE, bst)
+            _bn_back(grads, net.bn0, bn0, bst, x.numel())
+
+
+def _outputs(net, D, x):
+    logits = D["yu"][0]
+    if net.extra_size is not None:
+        return logits, D["extra"], x.new_zeros(())
+    if D["vs"]:
+        return logits, D["fus"]["match_part"].mean(), D["fus"]["att_maps"]
+    return logits, x.new_zeros(()), x.new_zeros(())
 
 
 class _UnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, draws, nv, x, *rest):
         vs, training = list(rest[:nv]), net.training
-        lv = net.levels()
-        L = len(lv)
-        B, _, H, W = x.shape
-        S = {"x": x, "vs": vs, "lv": lv}
-
-        # bn0 over the whole tile (audio_net.py:37,41)
-        st0 = K.zeros_stats(1, x)
-        if training:
-            K.channel_stats(x, st0)
-        S["bn0"] = _bn_run(net.bn0, st0, B * H * W, training, x)
-
-        # ---- encoder: conv k4 s2 p1, input = LeakyReLU(BN(prev)) folded into the gather ----
-        src, aff, act = x, S["bn0"], ACT_NONE
-        S["dconv"], S["yd"], S["dbn"] = [], [], []
-        for i, l in enumerate(lv):
-            w = l.down_conv.weight.detach()
-            cv = K.Conv(src, w.shape[0], 4, 2, 1, sc0=aff[0] if aff is not None else None,
-                        sh0=aff[1] if aff is not None else None, act0=act)
-            st = K.zeros_stats(w.shape[0], x) if (l.down_bn is not None and training) else None
-            y = cv.fwd(cv.pack(w, 0), None, st)
-            bn = None
-            if l.down_bn is not None:
-                bn = _bn_run(l.down_bn, st, y.numel() // y.shape[1], training, x)
-            S["dconv"].append(cv); S["yd"].append(y); S["dbn"].append(bn)
-            src, aff, act = y, bn, ACT_LRELU02
-
-        # ---- bottleneck fusion (models/fusion_net.py) / SoP++ split ----
-        ybot = S["yd"][-1]
-        extra = fus = feat_vec = None
+        E = _encode(net, x, training)
+        D = _decode(net, E, vs, draws, training)
+        ctx.E, ctx.D, ctx.net, ctx.nv, ctx.training = E, D, net, nv, training
+        out = _outputs(net, D, x)
         if net.extra_size is None:
-            fus = net.fusion.run_forward(ybot, vs, draws)
-            feat_vec = fus["feat"]                               # [B, D] broadcast vectors
-        else:
-            e2 = 2 * net.extra_size
-            extra, ybot = ybot[:, :e2].contiguous(), ybot[:, e2:].contiguous()
-        S["fus"], S["ybot"] = fus, ybot
-
-        # ---- decoder: ReLU + bilinear x2 + conv k3 p1 over concat(skip, inner) ----
-        S["uconv"], S["yu"], S["ubn"], S["cat"], S["U"] = [None] * L, [None] * L, [None] * L, [None] * L, [None] * L
-        for i in range(L - 1, -1, -1):
-            l = lv[i]
-            w = l.up_conv.weight.detach()
-            if i == L - 1:
-                cat = K.Cat(feat_vec, ybot, bcast0=True) if feat_vec is not None else K.Cat(ybot, None)
-                fused = False
-            else:
-                dbn, ubn = S["dbn"][i], S["ubn"][i + 1]
-                cat = K.Cat(S["yd"][i], S["yu"][i + 1], sc0=dbn[0] if dbn is not None else None,
-                            sh0=dbn[1] if dbn is not None else None, sc1=ubn[0], sh1=ubn[1])
-                fused = net.fuse_upsample
-            if fused:   # upsample folded into the conv's operand gather: nothing materialised
-                cv = K.Conv(cat.keep[0], w.shape[0], 3, 1, 1, x1=cat.keep[1], sc0=cat.keep[2], sh0=cat.keep[3],
-                            act0=ACT_RELU, sc1=cat.keep[4], sh1=cat.keep[5], act1=ACT_RELU, up2x=True)
-            else:
-                U = cat.fwd()
-                S["U"][i] = U
-                cv = K.Conv(U, w.shape[0], 3, 1, 1)
-            st = K.zeros_stats(w.shape[0], x) if (l.up_bn is not None and training) else None
-            bias = l.up_conv.bias.detach() if l.up_conv.bias is not None else None
-            y = cv.fwd(cv.pack(w, 0), bias, st)
-            bn = _bn_run(l.up_bn, st, y.numel() // y.shape[1], training, x) if l.up_bn is not None else None
-            S["uconv"][i], S["yu"][i], S["ubn"][i], S["cat"][i] = cv, y, bn, cat
-
-        ctx.S, ctx.net, ctx.nv, ctx.training = S, net, nv, training
-        logits = S["yu"][0]
-        if net.extra_size is not None:
-            return logits, extra, x.new_zeros(())
-        if nv:
-            match = fus["match_part"].mean()
-            att = fus["att_maps"]
-        else:
-            match = x.new_zeros(())
-            att = x.new_zeros(())
-        ctx.mark_non_differentiable(att)
-        return logits, match, att
+            ctx.mark_non_differentiable(out[2])
+        return out
 
     @staticmethod
-    def backward(ctx, dlogits, dmatch, _datt):
-        # dmatch is the cotangent of the second output: the match loss, or the SoP++ `extra` channels
-        S, net, nv = ctx.S, ctx.net, ctx.nv
+    def backward(ctx, dlogits, dsecond, _datt):
+        # dsecond is the cotangent of the second output: the match loss, or the SoP++ `extra` channels
         if not ctx.training:
             raise lib.AvsepError("backward through the U-Net needs train mode (batch statistics)")
-        lv = S["lv"]
-        L = len(lv)
-        x = S["x"]
-        grads = {}
+        net, E, D = ctx.net, ctx.E, ctx.D
+        grads, Gd = {}, [None] * len(E["lv"])
+        dbot, dvs = _decode_bwd(net, E, D, dlogits, dsecond, bool(ctx.nv), grads, Gd)
+        _encode_bwd(net, E, dbot, Gd, grads)
+        ctx.E = ctx.D = None
+        return (None, None, None, None, *dvs, *[grads.get(p) for p in net.param_list()])
 
-        def bn_back(bn_mod, bnrow, bstats, count):
-            dgamma, dbeta, pqr = K.bn_bwd_coeffs(bstats, count, bn_mod.weight.detach(), bnrow[2], bnrow[3])
-            grads[bn_mod.weight], grads[bn_mod.bias] = dgamma, dbeta
-            return pqr
 
-        # ---- decoder backward, outermost -> innermost ----
-        g = dlogits.contiguous()
-        Gd = [None] * L          # gradient reaching zd[i] through the skip path (already ReLU-masked)
-        dfeat = dbot = None
-        for i in range(L):
-            l, cv, cat = lv[i], S["uconv"][i], S["cat"][i]
-            w = l.up_conv.weight.detach()
-            dw, db = cv.wgrad(g, want_bias=l.up_conv.bias is not None)
-            grads[l.up_conv.weight] = dw
-            if db is not None:
-                grads[l.up_conv.bias] = db
-            dU = cv.dgrad(cv.pack(w, 1), g)                    # wrt the (virtual) upsampled input
-            if i == L - 1:
-                if net.extra_size is None:
-                    dfeat, dbot = cat.bwd(dU)
-                else:
-                    dxb, _ = cat.bwd(dU)
-                    dbot = torch.cat([dmatch.to(dxb.dtype).contiguous(), dxb], 1)
-            else:
-                ubn = S["ubn"][i + 1]
-                bst = K.zeros_stats(ubn.shape[1], x)
-                Gd[i], dz = cat.bwd(dU, mean1=ubn[2], invstd1=ubn[3], bstats1=bst)
-                yu = S["yu"][i + 1]
-                pqr = bn_back(lv[i + 1].up_bn, ubn, bst, yu.numel() // yu.shape[1])
-                g = K.bn_bwd_apply_(dz, yu, pqr)
-            del dU
+class _UnetPairFn(torch.autograd.Function):
+    """The two U-Net passes of an audio-visual step (main.py:128-141: reversed, then natural visual order) as ONE
+    node: both passes see the same input, so the encoder (and its batch statistics) is identical — it runs once
+    forward, and once backward on the SUM of the two passes' bottleneck / skip gradients (the backward is linear
+    in them).  The encoder's BatchNorm running statistics still receive two momentum updates, like two passes."""
 
-        # ---- fusion backward: adds into dbot, returns the visual-feature gradients ----
-        dvs = []
-        if net.extra_size is None:
-            dvs = net.fusion.run_backward(S["ybot"], S["vs"], S["fus"], dfeat, dbot, None, dmatch if nv else None)
+    @staticmethod
+    def forward(ctx, net, x, va0, va1, vb0, vb1, *params):
+        training = net.training
+        E = _encode(net, x, training, repeat=2)
+        Da = _decode(net, E, [va0, va1], None, training)
+        Db = _decode(net, E, [vb0, vb1], None, training)
+        ctx.E, ctx.Da, ctx.Db, ctx.net, ctx.training = E, Da, Db, net, training
+        oa, ob = _outputs(net, Da, x), _outputs(net, Db, x)
+        ctx.mark_non_differentiable(oa[2], ob[2])
+        return (*oa, *ob)
 
-        # ---- encoder backward, innermost -> outermost ----
-        g = dbot
-        for i in range(L - 1, -1, -1):
-            l, cv = lv[i], S["dconv"][i]
-            w = l.down_conv.weight.detach()
-            grads[l.down_conv.weight], _ = cv.wgrad(g)
-            dS = cv.dgrad(cv.pack(w, 1), g)                   # wrt act(BN(prev)) (or BN0(x) for i == 0)
-            if i > 0:
-                yprev, bn = S["yd"][i - 1], S["dbn"][i - 1]
-                bst = K.zeros_stats(yprev.shape[1], x) if bn is not None else None
-                K.affine_act_bwd_(dS, yprev, bn[0] if bn is not None else None, bn[1] if bn is not None else None,
-                                  None, Gd[i - 1], bn[2] if bn is not None else None,
-                                  bn[3] if bn is not None else None, ACT_LRELU02, bst)
-                if bn is not None:
-                    pqr = bn_back(lv[i - 1].down_bn, bn, bst, yprev.numel() // yprev.shape[1])
-                    g = K.bn_bwd_apply_(dS, yprev, pqr)
-                else:
-                    g = dS
-            else:
-                bn0 = S["bn0"]
-                bst = K.zeros_stats(1, x)
-                K.affine_act_bwd_(dS, x, None, None, None, None, bn0[2], bn0[3], ACT_NONE, bst)
-                bn_back(net.bn0, bn0, bst, x.numel())
-        ctx.S = None
-        plist = net.param_list()
-        return (None, None, None, None, *dvs, *[grads.get(p) for p in plist])
+    @staticmethod
+    def backward(ctx, dla, dma, _a, dlb, dmb, _b):
+        if not ctx.training:
+            raise lib.AvsepError("backward through the U-Net needs train mode (batch statistics)")
+        net, E = ctx.net, ctx.E
+        grads, Gd = {}, [None] * len(E["lv"])
+        dbot_a, dva = _decode_bwd(net, E, ctx.Da, dla, dma, True, grads, Gd)
+        dbot_b, dvb = _decode_bwd(net, E, ctx.Db, dlb, dmb, True, grads, Gd)
+        _encode_bwd(net, E, dbot_a.add_(dbot_b), Gd, grads)
+        ctx.E = ctx.Da = ctx.Db = None
+        return (None, None, *dva, *dvb, *[grads.get(p) for p in net.param_list()])

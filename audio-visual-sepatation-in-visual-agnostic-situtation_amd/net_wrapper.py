@@ -80,10 +80,15 @@ class NetWrapper(torch.nn.Module):
         fused = args.output_activation != "softmax"   # softmax over the singleton channel is identically 1 (:132)
         gt_nat = self._gt_stack
         errs, match_loss = [], 0
-        # pass 1: visual features in reversed order against reversed targets; pass 2: natural order
-        for reverse in (True, False):
+        # pass 1: visual features in reversed order against reversed targets; pass 2: natural order.
+        # Both passes read the same spectrogram: the U-Net shares its encoder between them (forward_pair).
+        if hasattr(self.net_sound, "forward_pair") and getattr(self, "share_encoder", True) and N == 2:
+            passes = self.net_sound.forward_pair(log_mag_mix, feat_frames[::-1], feat_frames)
+        else:
+            passes = None
+        for pi, reverse in enumerate((True, False)):
             vis_in = feat_frames[::-1] if reverse else feat_frames
-            feat_sound, meta = self.net_sound(log_mag_mix, vis_in)
+            feat_sound, meta = passes[pi] if passes is not None else self.net_sound(log_mag_mix, vis_in)
             if fused:
                 gt = gt_nat.flip(0).contiguous() if reverse else gt_nat
                 pred, sums, FT = mask_loss(feat_sound, gt, weight, act, kind)

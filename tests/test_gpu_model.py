@@ -306,3 +306,33 @@ def test_sopp_variant_vs_oracle(dev, golden):
         assert_close(snd.unet_block.up_forward.at(2).weight.grad, osnd.unet_block.up_conv.weight.grad, 3e-3, f"stage {stage} last conv grad")
         k = "unet_block.mid_forward.mid_forward.mid_forward.mid_forward.down_forward.1.weight"
         assert_close(dict(snd.named_parameters())[k].grad, dict(osnd.named_parameters())[k].grad, 3e-3, f"stage {stage} bottleneck conv grad")
+
+
+def test_shared_encoder_pair_equals_two_passes(dev, golden):
+    """forward_pair (one encoder, two decoders) == two forward() calls: outputs, every gradient, and the
+    BatchNorm running statistics (two momentum updates)."""
+    P = _pkg()
+    G = golden("unet")
+    x = G["u5.x"].to(dev)
+    v = [G["u5.v0"].to(dev), G["u5.v1"].to(dev)]
+    res = {}
+    for mode in ("pair", "two"):
+        net = _load_unet(P, G, "u5", 5, 8, "hidsep", "sig", dev).train()
+        va = [t.clone().requires_grad_(True) for t in v]
+        if mode == "pair":
+            (fa, (ma, _)), (fb, (mb, _)) = net.forward_pair(x, va[::-1], va)
+        else:
+            fa, (ma, _) = net(x, va[::-1])
+            fb, (mb, _) = net(x, va)
+        ((fa * G["u5.cot"].to(dev)).sum() + 2 * (fb * G["u5.cot"].to(dev)).sum() + 0.3 * ma + 0.7 * mb).backward()
+        res[mode] = dict(fa=fa.detach(), fb=fb.detach(), ma=ma.detach(), mb=mb.detach(), dv=[t.grad for t in va],
+                         g={k: p.grad for k, p in net.named_parameters()}, b={k: b.clone() for k, b in net.named_buffers()})
+    a, b = res["pair"], res["two"]
+    assert torch.equal(a["fa"], b["fa"]) and torch.equal(a["fb"], b["fb"])
+    assert_close(a["ma"], b["ma"], 1e-6); assert_close(a["mb"], b["mb"], 1e-6)
+    for i in range(2):
+        assert_close(a["dv"][i], b["dv"][i], 1e-5, "dv")
+    for k in a["g"]:
+        assert_close(a["g"][k], b["g"][k], 2e-5, "grad " + k)
+    for k in a["b"]:
+        assert_close(a["b"][k].double(), b["b"][k].double(), 1e-6, "buffer " + k)
