@@ -354,17 +354,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
   for (int kt = kt0; kt < nK; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nK) issue(kt + 1);
+    // operands of k-step k2+1 are read before the MFMAs of k-step k2 issue (order pinned with sched_barrier):
+    // the LDS latency hides behind TM*TN*64 MFMA cycles instead of stalling the wave every step
+    float av[2][TM], bv[2][TN];
+    auto read_ops = [&](int k2, int slot) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[slot][i] = As[buf][2 * k2 + lk][wm * WTM + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[slot][j] = Bs[buf][2 * k2 + lk][wn * WTN + j * 32 + li];
+    };
+    read_ops(0, 0);
 #pragma unroll
     for (int k2 = 0; k2 < BK / 2; ++k2) {
-      float av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = As[buf][2 * k2 + lk][wm * WTM + i * 32 + li];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][2 * k2 + lk][wn * WTN + j * 32 + li];
+      const int cur = k2 & 1;
+      if (k2 + 1 < BK / 2) read_ops(k2 + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (kt + 1 < nK) finish(buf ^ 1);
     __syncthreads();
@@ -591,7 +601,7 @@ extern "C" int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w,
 
 // big tiles when they still fill the chip, else 64x64
 static inline bool use_big(int M, long long ncols) {
-  return M > 64 && (long long)cdiv(M, 128) * cdiv(ncols, 128) >= 320;
+  return M > 64 && (long long)cdiv(M, 128) * cdiv(ncols, 128) >= 64;   // few big tiles are topped up by split-K
 }
 
 // split-K plan for layers whose output grid cannot fill the chip (deep U-Net levels: 2x2 .. 8x8 maps, K ~ 8-9k)
@@ -599,8 +609,8 @@ struct SplitPlan { int splits, kts; };
 static SplitPlan splitk_plan(long long tiles, int K) {
   SplitPlan p{1, 0};
   int nK = cdiv(K, 16);
-  if (tiles >= 1024 || nK < 64) return p;
-  int want = cdiv(1024, tiles), maxs = nK / 32;
+  if (tiles >= 640 || nK < 64) return p;
+  int want = cdiv(768, tiles), maxs = nK / 32;
   int s = want < maxs ? want : maxs;
   if (s > 32) s = 32;
   if (s < 2) return p;

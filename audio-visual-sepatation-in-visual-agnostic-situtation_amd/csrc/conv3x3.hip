@@ -175,19 +175,29 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
     const int buf = kt & 1;
     if (kt + 1 < nK) issue(kt + 1);
     const float* P = Ps[buf];
-#pragma unroll
-    for (int k2 = 0; k2 < C3_KT / 2; ++k2) {
+    // operands of k-step k2+1 are read into a second register set before the MFMAs of k-step k2 issue,
+    // so the LDS latency hides behind 4 x 64 MFMA cycles instead of stalling the wave every step
+    float av[2][TM], bv[2][2];
+    auto read_ops = [&](int k2, int slot) {
       const int cp = k2 / 9, tap = k2 % 9;                          // compile-time after unrolling
       const int koff = (2 * cp) * PS + (tap / 3) * PW + (tap % 3);
-      float av[TM], bv[2];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = As[buf][2 * k2 + lk][wm * WTM + i * 32 + li];
+      for (int i = 0; i < TM; ++i) av[slot][i] = As[buf][2 * k2 + lk][wm * WTM + i * 32 + li];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bv[j] = P[lb[j] + koff];
+      for (int j = 0; j < 2; ++j) bv[slot][j] = P[lb[j] + koff];
+    };
+    read_ops(0, 0);
+#pragma unroll
+    for (int k2 = 0; k2 < C3_KT / 2; ++k2) {
+      const int cur = k2 & 1;
+      if (k2 + 1 < C3_KT / 2) read_ops(k2 + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (kt + 1 < nK) finish(buf ^ 1);
     __syncthreads();
@@ -288,11 +298,12 @@ int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
 }
 
 static int c3_launch(C3Args& a, hipStream_t st) {
-  const bool narrow = a.Cout <= 64;            // 64-row tiles when the GEMM M dimension is small
-  a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
   const bool wide = a.W >= 32;
   a.tilesX = cdiv(a.W, wide ? 32 : 16);
   a.tilesY = cdiv(a.H, wide ? 4 : 8);
+  // 64-row tiles when the GEMM M dimension is small, or when 128-row tiles would leave most CUs with one workgroup
+  const bool narrow = a.Cout <= 64 || (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * a.N < 384;
+  a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
 #define C3_LAUNCH(TH_, TW_, BM_)                                                                        \
   do {                                                                                                \
@@ -455,16 +466,25 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_kernel(W3Args a) {
     for (int py = 0; py < TH; ++py) {
       const float* ar = Ap + py * TW;
       const float* br = Bp + py * PW;
-#pragma unroll 2
-      for (int px = 0; px < TW; px += 2) {
-        const float av = ar[px];
+      // operand prefetch one k-step ahead, pinned with sched_barrier (see conv3x3_kernel)
+      float av[2], bv[2][MAXT];
+      av[0] = ar[0];
 #pragma unroll
-        for (int j = 0; j < MAXT; ++j) {
-          if (j < ntap) {                                    // wave-uniform
-            const float bv = br[toff[j] + px];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-          }
+      for (int j = 0; j < MAXT; ++j) bv[0][j] = (j < ntap) ? br[toff[j]] : 0.f;
+#pragma unroll 4
+      for (int px = 0; px < TW; px += 2) {
+        const int cur = (px >> 1) & 1;
+        if (px + 2 < TW) {
+          av[cur ^ 1] = ar[px + 2];
+#pragma unroll
+          for (int j = 0; j < MAXT; ++j)
+            if (j < ntap) bv[cur ^ 1][j] = br[toff[j] + px + 2];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j)
+          if (j < ntap) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
