@@ -183,16 +183,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
   const int pixoff = hi0 * a.Ws + wi0;   // fwd: offset of the (possibly out-of-range) window origin
 
   float braw[NBR], bsc[NSC], bsh[NSC];
-  float4 areg4[AV];
+  f32x4 areg4[AV];   // native vector type (a float4 struct array would live in scratch memory)
   float areg[(MODE == M_WGRAD) ? AE : 1];
   unsigned bmask = 0, bfirst = 0, amask = 0;
 
-  auto issue = [&](int kt) {
+  auto issue = [&](int kt) __attribute__((always_inline)) {
     if (MODE == M_FWD) {
 #pragma unroll
       for (int e = 0; e < AV; ++e) {
         int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
-        areg4[e] = *reinterpret_cast<const float4*>(a.wp + (long long)(kt * BK + row) * a.wp_ld + m0 + c4 * 4);
+        areg4[e] = *reinterpret_cast<const f32x4*>(a.wp + (long long)(kt * BK + row) * a.wp_ld + m0 + c4 * 4);
       }
       const int k = kt * BK + brow0;                       // wave-uniform
       int ci = k / KHW, r = k % KHW, kh = r / a.KW, kw = r % a.KW;
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
         int kk = ok ? k : 0;
         int co = kk % a.Cout, t = kk / a.Cout;
         int kh = s_tab[2 + t / ntw], kw = s_tab[12 + t % ntw];
-        areg4[e] = *reinterpret_cast<const float4*>(a.wp + (long long)((kh * a.KW + kw) * a.Cout + co) * a.wp_ld + m0 +
-                                                    c4 * 4);
+        areg4[e] = *reinterpret_cast<const f32x4*>(a.wp + (long long)((kh * a.KW + kw) * a.Cout + co) * a.wp_ld + m0 +
+                                                   c4 * 4);
         amask |= (unsigned)ok << e;
       }
       const int k = kt * BK + brow0;                       // wave-uniform
@@ -292,12 +292,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
     }
   };
 
-  auto finish = [&](int buf) {
+  auto finish = [&](int buf) __attribute__((always_inline)) {
     if (MODE == M_FWD) {
 #pragma unroll
       for (int e = 0; e < AV; ++e) {
         int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
-        *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = areg4[e];
+        *reinterpret_cast<f32x4*>(&As[buf][row][c4 * 4]) = areg4[e];
       }
 #pragma unroll
       for (int e = 0; e < BROWS; ++e) {
@@ -313,9 +313,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
 #pragma unroll
       for (int e = 0; e < AV; ++e) {
         int idx = tid + 256 * e, row = idx / A4, c4 = idx % A4;
-        float4 v = areg4[e];
-        if (!((amask >> e) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = v;
+        f32x4 v = areg4[e];
+        if (!((amask >> e) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&As[buf][row][c4 * 4]) = v;
       }
 #pragma unroll
       for (int e = 0; e < BROWS; ++e) Bs[buf][brow0 + e][bcol] = ((bmask >> e) & 1u) ? braw[e] : 0.f;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
     // operands of k-step k2+1 are read before the MFMAs of k-step k2 issue (order pinned with sched_barrier):
     // the LDS latency hides behind TM*TN*64 MFMA cycles instead of stalling the wave every step
     float av[2][TM], bv[2][TN];
-    auto read_ops = [&](int k2, int slot) {
+    auto read_ops = [&](int k2, int slot) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) av[slot][i] = As[buf][2 * k2 + lk][wm * WTM + i * 32 + li];
 #pragma unroll
