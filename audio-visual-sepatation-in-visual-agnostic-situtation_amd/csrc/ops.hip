@@ -329,13 +329,19 @@ __device__ __forceinline__ void up2x_taps6(int h, int Hin, float r, float (&wt)[
   }
 }
 
-// grid (C0+C1, chunks); a block reduces the BN-backward sums of its channel
+// grid (tiles of 8x32 low-res pixels, C0+C1, batch slices).  Per image the (2*8+4) x (2*32+4) hi-res window of
+// dout is staged in LDS with coalesced row loads; each thread then gathers its <= 6x6 transposed-bilinear taps
+// from LDS.  The block reduces the BN-backward sums of its channel (source 1) and issues one pair of atomics.
+// Broadcast sources ([N,C] vectors, the innermost level only) take the simple path below.
+constexpr int UB_TH = 8, UB_TW = 32, UB_RH = 2 * UB_TH + 4, UB_RW = 2 * UB_TW + 4;
+
 __global__ __launch_bounds__(256) void relu_up2x_bwd_kernel(CatArgs a, const float* __restrict__ dout,
                                                             float* __restrict__ g0, float* __restrict__ g1,
                                                             const float* __restrict__ mean1,
                                                             const float* __restrict__ invstd1, double* bstats1,
-                                                            int acc0) {
-  const int C = a.C0 + a.C1, c = blockIdx.x;
+                                                            int acc0, int tilesX) {
+  __shared__ float tile[UB_RH][UB_RW + 1];
+  const int C = a.C0 + a.C1, c = blockIdx.y;
   const int Ho = 2 * a.H, Wo = 2 * a.W, HW = a.H * a.W;
   const bool first = c < a.C0;
   const int cs = first ? c : c - a.C0, Cs = first ? a.C0 : a.C1;
@@ -343,57 +349,57 @@ __global__ __launch_bounds__(256) void relu_up2x_bwd_kernel(CatArgs a, const flo
   float* g = first ? g0 : g1;
   float s1 = 0.f, s2 = 0.f;
   const float mu = (!first && mean1) ? mean1[cs] : 0.f, is = (!first && invstd1) ? invstd1[cs] : 1.f;
+  const int n_per = (a.N + gridDim.z - 1) / gridDim.z, n_beg = blockIdx.z * n_per, n_end = min(a.N, n_beg + n_per);
   if (g) {
-    if (bc) {  // one thread per sample: sum over the whole low-res map
-      for (int n = blockIdx.y * 256 + threadIdx.x; n < a.N; n += gridDim.y * 256) {
-        float v = cat_relu_val(a, n, c, 0, 0), tot = 0.f;
-        if (v > 0.f) {
-          const float* p = dout + ((long long)n * C + c) * Ho * Wo;
-          for (int i = 0; i < Ho * Wo; ++i) tot += p[i];  // bilinear weights of a constant map sum to 1 per output
+    if (bc) {  // one thread per sample: the bilinear weights of a constant map sum to 1 per output
+      if (blockIdx.x == 0)
+        for (int n = n_beg + threadIdx.x; n < n_end; n += 256) {
+          float v = cat_relu_val(a, n, c, 0, 0), tot = 0.f;
+          if (v > 0.f) {
+            const float* p = dout + ((long long)n * C + c) * Ho * Wo;
+            for (int i = 0; i < Ho * Wo; ++i) tot += p[i];
+          }
+          long long o = (long long)n * Cs + cs;
+          g[o] = (acc0 && first) ? g[o] + tot : tot;
         }
-        long long o = (long long)n * Cs + cs;
-        g[o] = (acc0 && first) ? g[o] + tot : tot;
-      }
     } else {
-      // thread (tx, ty) of a 32 x 8 tile; images of this block's slice, rows and columns by strides:
-      // no per-element div/mod; the transpose-bilinear taps are computed once per row / column
       const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-      const int n_per = (a.N + gridDim.y - 1) / gridDim.y;
-      const int n_beg = blockIdx.y * n_per, n_end = min(a.N, n_beg + n_per);
+      const int h0 = (blockIdx.x / tilesX) * UB_TH, w0 = (blockIdx.x % tilesX) * UB_TW;
+      const int h = h0 + ty, w = w0 + tx;
+      const bool inside = h < a.H && w < a.W;
+      float wh[6], ww[6];
+      up2x_taps6(min(h, a.H - 1), a.H, a.rh, wh);
+      up2x_taps6(min(w, a.W - 1), a.W, a.rw, ww);
       const float* xsrc = first ? a.x0 : a.x1;
       const float* scp = first ? a.sc0 : a.sc1;
       const float* shp = first ? a.sh0 : a.sh1;
       const float scv = scp ? scp[cs] : 1.f, shv = scp ? shp[cs] : 0.f;
-      for (int h = ty; h < a.H; h += 8) {
-        float wh[6];
-        up2x_taps6(h, a.H, a.rh, wh);
-        for (int w = tx; w < a.W; w += 32) {
-          float ww[6];
-          up2x_taps6(w, a.W, a.rw, ww);
-          for (int n = n_beg; n < n_end; ++n) {
-            const long long o = ((long long)n * Cs + cs) * HW + h * a.W + w;
-            const float yv = xsrc[o];
-            const float pre = fmaf(yv, scv, shv);
-            float tot = 0.f;
-            if (pre > 0.f) {
-              const float* p = dout + ((long long)n * C + c) * Ho * Wo + (long long)(2 * h - 2) * Wo + (2 * w - 2);
+      const int r0 = 2 * h0 - 2, c0w = 2 * w0 - 2;   // hi-res origin of the staged window
+      for (int n = n_beg; n < n_end; ++n) {
+        const float* p = dout + ((long long)n * C + c) * Ho * Wo;
+        __syncthreads();
+        for (int i = threadIdx.x; i < UB_RH * UB_RW; i += 256) {
+          int rr = i / UB_RW, cc = i % UB_RW;          // compile-time divisor
+          int ho = r0 + rr, wo = c0w + cc;
+          tile[rr][cc] = ((unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo) ? p[(long long)ho * Wo + wo] : 0.f;
+        }
+        __syncthreads();
+        if (inside) {
+          const long long o = ((long long)n * Cs + cs) * HW + h * a.W + w;
+          const float yv = xsrc[o];
+          float tot = 0.f;
+          if (fmaf(yv, scv, shv) > 0.f) {
 #pragma unroll
-              for (int y = 0; y < 6; ++y) {
-                if (wh[y] != 0.f) {
-                  float row = 0.f;
+            for (int y = 0; y < 6; ++y) {
+              float row = 0.f;
 #pragma unroll
-                  for (int x = 0; x < 6; ++x)
-                    if (ww[x] != 0.f) row = fmaf(ww[x], p[y * Wo + x], row);
-                  tot = fmaf(wh[y], row, tot);
-                }
-              }
-            }
-            g[o] = (acc0 && first) ? g[o] + tot : tot;
-            if (!first && bstats1) {
-              s1 += tot;
-              s2 += tot * (yv - mu) * is;
+              for (int x = 0; x < 6; ++x) row = fmaf(ww[x], tile[2 * ty + y][2 * tx + x], row);
+              tot = fmaf(wh[y], row, tot);
             }
           }
+          g[o] = (acc0 && first) ? g[o] + tot : tot;
+          s1 += tot;
+          s2 += tot * (yv - mu) * is;
         }
       }
     }
@@ -418,10 +424,12 @@ extern "C" int avsep_relu_up2x_bwd(const avsep_cat_desc* d, const float* dout, f
   if (bstats1 && (!mean1 || !invstd1 || d->bcast1 || !g1)) return AVSEP_ERR_ARG;
   CatArgs a = make_cat(d);
   int C = d->C0 + d->C1;
-  int chunks = min(cdiv(2048, C), d->N);           // blocks per channel = slices over the batch
+  int tilesX = cdiv(d->W, UB_TW), tiles = tilesX * cdiv(d->H, UB_TH);
+  int chunks = min(cdiv(4096, C * tiles), d->N);   // batch slices: enough blocks to fill the chip, few atomics
   if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(relu_up2x_bwd_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, a, dout, g0, g1, mean1,
-                     invstd1, bstats1, acc0);
+  if (C > 65535) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(relu_up2x_bwd_kernel, dim3(tiles, C, chunks), dim3(256), 0, (hipStream_t)stream, a, dout, g0, g1,
+                     mean1, invstd1, bstats1, acc0, tilesX);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
