@@ -413,8 +413,40 @@ __device__ __forceinline__ float w3_src(const W3Args& a, int n, int c, int hs, i
   return v;
 }
 
+// one pixel tile of the wgrad GEMM for a wave that owns NTAP consecutive taps starting at tap0 (wave-uniform)
+template <int TH, int TW, int PW, int MAXT, int NTAP>
+__device__ __forceinline__ void w3_mfma_tile(const float* Ap, const float* Bp, int tap0, f32x16 (&acc)[MAXT]) {
+  int toff[NTAP];                                           // (kh*PW + kw) per owned tap
+#pragma unroll
+  for (int j = 0; j < NTAP; ++j) {
+    int tp = tap0 + j;
+    toff[j] = (tp / 3) * PW + (tp % 3);
+  }
+  for (int py = 0; py < TH; ++py) {
+    const float* ar = Ap + py * TW;
+    const float* br = Bp + py * PW;
+    float av[2], bv[2][NTAP];                               // operands of the next k-step are read one step ahead
+    av[0] = ar[0];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) bv[0][j] = br[toff[j]];
+#pragma unroll 4
+    for (int px = 0; px < TW; px += 2) {
+      const int cur = (px >> 1) & 1;
+      if (px + 2 < TW) {
+        av[cur ^ 1] = ar[px + 2];
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) bv[cur ^ 1][j] = br[toff[j] + px + 2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NTAP; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <int TH, int TW, bool UP2X, int BM>
-__global__ __launch_bounds__(512, 4) void wgrad3x3_kernel(W3Args a) {
+__global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   constexpr int NPIX = TH * TW, PH = TH + 2, PW = TW + 2;
   constexpr int PS = (PH * PW) | 1;                       // odd per-channel stride: lanes = channels -> no bank conflicts
   constexpr int LDA = NPIX + 1;
@@ -422,8 +454,8 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_kernel(W3Args a) {
   constexpr int NP = W3_CC * PH * PW, PE = (NP + NT - 1) / NT;
   constexpr int NA4 = BM * NPIX / 4, AE = NA4 / NT;
   static_assert(NA4 % NT == 0, "A tile must split evenly");
-  __shared__ float As[BM * LDA];
-  __shared__ float Ps[W3_CC * PS];
+  __shared__ float As[2][BM * LDA];   // double buffered: one barrier per pixel tile
+  __shared__ float Ps[2][W3_CC * PS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
   const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
@@ -435,30 +467,90 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_kernel(W3Args a) {
   // BM=128: 4 row blocks x tap groups {0-4},{5-8};  BM=64: 2 row blocks x tap groups {0-2},{3,4},{5,6},{7,8}
   constexpr int RB = BM / 32, MAXT = (BM == 128) ? 5 : 3;
   const int wrow = wave % RB, tg = wave / RB;
-  const int tap0 = __builtin_amdgcn_readfirstlane(BM == 128 ? (tg ? 5 : 0) : (tg == 0 ? 0 : 1 + 2 * tg));
-  const int ntap = __builtin_amdgcn_readfirstlane(BM == 128 ? (tg ? 4 : 5) : (tg == 0 ? 3 : 2));
+  const int tap0 = __builtin_amdgcn_readfirstlane(BM == 128 ? (tg ? 4 : 0) : (tg == 0 ? 0 : 1 + 2 * tg));
+  const int ntap = __builtin_amdgcn_readfirstlane(BM == 128 ? 5 : (tg == 0 ? 3 : 2));
+  const int jskip = (BM == 128 && tg) ? 1 : 0;             // BM=128, second group: acc[0] duplicates tap 4
   f32x16 acc[MAXT];
 #pragma unroll
   for (int j = 0; j < MAXT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // No register prefetch here: the 144 accumulators leave no room for it.  Staging goes straight to LDS and
-  // the two resident workgroups of a CU overlap each other's staging and MFMA phases.
-  auto stage_tile = [&](int t) __attribute__((always_inline)) {
+  // Staging is software-pipelined through registers (issue(t+1) -> MFMAs(t) -> finish(t+1)) and double-buffered
+  // in LDS.  The f32 MFMA shares the vector ALUs, so the per-element decode is hoisted out of the tile loop:
+  // per tile only (n, h0, w0) change.
+  const bool first_src = c0 < a.C0;                        // block-uniform (C0 % 32 == 0 is checked on the host)
+  const float* xsrc = first_src ? a.x0 : a.x1;
+  const int Csrc = first_src ? a.C0 : a.C1, csrc0 = first_src ? c0 : c0 - a.C0;
+  const float* scs = first_src ? a.sc0 : a.sc1;
+  const float* shs = first_src ? a.sh0 : a.sh1;
+  const int act_s = first_src ? a.act0 : a.act1;
+  const long long sHW = (long long)a.Hs * a.Ws;
+  int a_goff[AE], a_lds[AE], a_r[AE], a_c[AE];
+  bool a_rowok[AE];
+#pragma unroll
+  for (int e = 0; e < AE; ++e) {
+    int idx = tid + NT * e;
+    int q = idx % (TW / 4), r = (idx / (TW / 4)) % TH, co = idx / (NPIX / 4);
+    a_rowok[e] = m0 + co < a.Cout;
+    a_goff[e] = min(m0 + co, a.Cout - 1) * (int)HW + r * a.W + 4 * q;   // Cout*H*W < 2^31 is checked on the host
+    a_lds[e] = co * LDA + r * TW + 4 * q;
+    a_r[e] = r;
+    a_c[e] = 4 * q;
+  }
+  int p_goff[PE], p_lds[PE], p_r[PE], p_col[PE];
+  float p_sc[PE], p_sh[PE];
+  bool p_chok[PE];
+#pragma unroll
+  for (int e = 0; e < PE; ++e) {
+    int idx = min(tid + NT * e, NP - 1);
+    int cc = idx / (PH * PW), r = (idx % (PH * PW)) / PW, col = idx % PW;
+    p_chok[e] = (PE * NT == NP || tid + NT * e < NP) && c0 + cc < a.Cin;
+    int cs = min(csrc0 + cc, Csrc - 1);
+    p_goff[e] = cs * (int)sHW + (r - 1) * a.Ws + (col - 1);
+    p_lds[e] = cc * PS + r * PW + col;
+    p_r[e] = r - 1;
+    p_col[e] = col - 1;
+    p_sc[e] = scs ? scs[cs] : 1.f;
+    p_sh[e] = scs ? shs[cs] : 0.f;
+  }
+  f32x4 areg[AE];
+  float praw[PE];
+  unsigned amask = 0, pmask = 0;
+  auto issue = [&](int t) __attribute__((always_inline)) {
     const int n = t / tiles_img, tt = t % tiles_img, h0 = (tt / a.tilesX) * TH, w0 = (tt % a.tilesX) * TW;
-    // dY tile: rows = output channels, TW-contiguous pixel segments (float4, W % 4 == 0 and TW % 4 == 0)
+    const float* dyb = a.dy + (long long)n * a.Cout * HW + (long long)h0 * a.W + w0;
+    const float* xb = xsrc + (long long)n * Csrc * sHW + (long long)h0 * a.Ws + w0;
+    amask = pmask = 0;
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
-      int idx = tid + NT * e;
-      int q = idx % (TW / 4), r = (idx / (TW / 4)) % TH, co = idx / (NPIX / 4);
-      int gh = h0 + r, gw = w0 + 4 * q, row = min(m0 + co, a.Cout - 1);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gh < a.H && gw < a.W && m0 + co < a.Cout)
-        v = *reinterpret_cast<const float4*>(a.dy + ((long long)n * a.Cout + row) * HW + (long long)gh * a.W + gw);
-      float* d = &As[co * LDA + r * TW + 4 * q];
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      const bool ok = a_rowok[e] && h0 + a_r[e] < a.H && w0 + a_c[e] < a.W;
+      areg[e] = *reinterpret_cast<const f32x4*>(ok ? dyb + a_goff[e] : a.dy);
+      amask |= (unsigned)ok << e;
     }
+#pragma unroll
+    for (int e = 0; e < PE; ++e) {
+      const bool ok = p_chok[e] && (unsigned)(h0 + p_r[e]) < (unsigned)a.H && (unsigned)(w0 + p_col[e]) < (unsigned)a.W;
+      praw[e] = *(ok ? xb + p_goff[e] : xsrc);
+      pmask |= (unsigned)ok << e;
+    }
+  };
+  auto finish = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      const bool ok = (amask >> e) & 1u;
+      float* d = &As[buf][a_lds[e]];
+      d[0] = ok ? areg[e].x : 0.f; d[1] = ok ? areg[e].y : 0.f; d[2] = ok ? areg[e].z : 0.f; d[3] = ok ? areg[e].w : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < PE; ++e) {
+      float v = act_apply(fmaf(praw[e], p_sc[e], p_sh[e]), act_s);
+      if (PE * NT == NP || tid + NT * e < NP) Ps[buf][p_lds[e]] = ((pmask >> e) & 1u) ? v : 0.f;
+    }
+  };
+  // bilinear-upsampled virtual input: staged directly (4 corner loads per element do not fit the register pipeline)
+  auto stage_up2x = [&](int t, int buf) __attribute__((always_inline)) {
+    const int n = t / tiles_img, tt = t % tiles_img, h0 = (tt / a.tilesX) * TH, w0 = (tt % a.tilesX) * TW;
 #pragma unroll 3
     for (int e = 0; e < PE; ++e) {
       int idx = tid + NT * e;
@@ -467,60 +559,43 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_kernel(W3Args a) {
         int cc = idx / (PH * PW), r = (idx % (PH * PW)) / PW, col = idx % PW;
         int gh = h0 - 1 + r, gw = w0 - 1 + col, c = c0 + cc;
         if (c < a.Cin && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W) {
-          if (!UP2X) {
-            v = w3_src(a, n, c, gh, gw);
-          } else {
-            float fh = a.rh * (float)gh, fw = a.rw * (float)gw;
-            int hh0 = (int)fh, ww0 = (int)fw;
-            int hh1 = hh0 + (hh0 < a.Hs - 1), ww1 = ww0 + (ww0 < a.Ws - 1);
-            float lh = fh - (float)hh0, lw = fw - (float)ww0;
-            float v00 = w3_src(a, n, c, hh0, ww0), v01 = w3_src(a, n, c, hh0, ww1);
-            float v10 = w3_src(a, n, c, hh1, ww0), v11 = w3_src(a, n, c, hh1, ww1);
-            v = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
-          }
+          float fh = a.rh * (float)gh, fw = a.rw * (float)gw;
+          int hh0 = (int)fh, ww0 = (int)fw;
+          int hh1 = hh0 + (hh0 < a.Hs - 1), ww1 = ww0 + (ww0 < a.Ws - 1);
+          float lh = fh - (float)hh0, lw = fw - (float)ww0;
+          float v00 = w3_src(a, n, c, hh0, ww0), v01 = w3_src(a, n, c, hh0, ww1);
+          float v10 = w3_src(a, n, c, hh1, ww0), v11 = w3_src(a, n, c, hh1, ww1);
+          v = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
         }
+        Ps[buf][(idx / (PH * PW)) * PS + idx % (PH * PW)] = v;
       }
-      if (PE * NT == NP || idx < NP) Ps[(idx / (PH * PW)) * PS + idx % (PH * PW)] = v;
     }
   };
 
-  const float* Ap = As + (wrow * 32 + li) * LDA + lk;
-  // per-wave tap group folded into the base pointer: tap = tap0 + j, and (tap/3, tap%3) offsets are
-  // resolved per j below from the wave-uniform tap0
-  const float* Bp = Ps + li * PS + lk;
+  if (t_begin < t_end) {
+    issue(t_begin);
+    finish(0);
+    if constexpr (UP2X) stage_up2x(t_begin, 0);
+  }
+  __syncthreads();
   for (int t = t_begin; t < t_end; ++t) {
-    stage_tile(t);
-    __syncthreads();
-    // k-steps = pixel pairs; a modest unroll keeps the 144 accumulators + operands inside 256 registers
-    int toff[MAXT];                                         // wave-uniform (kh*PW + kw) per owned tap
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      int tp = min(tap0 + j, 8);
-      toff[j] = (tp / 3) * PW + (tp % 3);
+    const int buf = (t - t_begin) & 1;
+    if (t + 1 < t_end) issue(t + 1);
+    const float* Ap = As[buf] + (wrow * 32 + li) * LDA + lk;
+    const float* Bp = Ps[buf] + li * PS + lk;
+    // straight-line MFMA loops per tap-group size (a per-MFMA `if (j < ntap)` would put every MFMA in its own
+    // basic block and defeat the operand prefetch)
+    if constexpr (BM == 128) {
+      // both tap groups run 5 taps ({0..4} and {4..8}: tap 4 is computed twice, the copy is dropped in the
+      // epilogue) so the whole loop is one branch-free instruction stream; costs 10 instead of 9 MFMAs per step
+      w3_mfma_tile<TH, TW, PW, MAXT, MAXT>(Ap, Bp, tap0, acc);
+    } else {
+      if (ntap == MAXT) w3_mfma_tile<TH, TW, PW, MAXT, MAXT>(Ap, Bp, tap0, acc);
+      else w3_mfma_tile<TH, TW, PW, MAXT, MAXT - 1>(Ap, Bp, tap0, acc);
     }
-    for (int py = 0; py < TH; ++py) {
-      const float* ar = Ap + py * TW;
-      const float* br = Bp + py * PW;
-      // operand prefetch one k-step ahead, pinned with sched_barrier (see conv3x3_kernel)
-      float av[2], bv[2][MAXT];
-      av[0] = ar[0];
-#pragma unroll
-      for (int j = 0; j < MAXT; ++j) bv[0][j] = (j < ntap) ? br[toff[j]] : 0.f;
-#pragma unroll 4
-      for (int px = 0; px < TW; px += 2) {
-        const int cur = (px >> 1) & 1;
-        if (px + 2 < TW) {
-          av[cur ^ 1] = ar[px + 2];
-#pragma unroll
-          for (int j = 0; j < MAXT; ++j)
-            if (j < ntap) bv[cur ^ 1][j] = br[toff[j] + px + 2];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < MAXT; ++j)
-          if (j < ntap) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][j], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    if (t + 1 < t_end) {
+      finish(buf ^ 1);
+      if constexpr (UP2X) stage_up2x(t + 1, buf ^ 1);
     }
     __syncthreads();
   }
@@ -528,7 +603,7 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_kernel(W3Args a) {
   const int ci = c0 + li;
 #pragma unroll
   for (int j = 0; j < MAXT; ++j)
-    if (j < ntap) {
+    if (j < ntap && j >= jskip) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int co = m0 + wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -540,7 +615,8 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_kernel(W3Args a) {
 
 bool w3_applicable(const avsep_conv_desc* d) {
   return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->W >= 16 && d->H >= 2 &&
-         (d->W & 3) == 0 && d->Cout > 4 && d->Cin >= 32 && d->N <= 65535;
+         (d->W & 3) == 0 && d->Cout > 4 && d->Cin >= 32 && d->N <= 65535 && (d->C0 == d->Cin || d->C0 % W3_CC == 0) &&
+         (long long)(d->Cout > d->Cin ? d->Cout : d->Cin) * d->H * d->W < 0x7fffffffLL;
 }
 
 struct W3Plan { int tilesX, tilesY, gridM, gridC, splits, tps; bool wide; };
