@@ -11,7 +11,7 @@
 // forward: y[n,co,h,w] = bias[co] + sum_{ci,kh,kw} w[co,ci,kh,kw] * x[n,ci,h+kh-1,w+kw-1]
 // block = 8 rows x 128 cols of one image; thread = 1 row x 4 consecutive cols, all Cout channels
 // ---------------------------------------------------------------------------
-constexpr int F_TH = 8, F_TW = 128, F_CH = 8, F_PH = F_TH + 2, F_PW = F_TW + 4;  // row stride 132: 16-B aligned
+constexpr int F_TH = 8, F_TW = 128, F_CH = 8, F_PH = F_TH + 2, F_PW = F_TW + 8;  // col j <-> w0 + j - 4: interior 16-B aligned
 
 template <int COUT>
 __global__ __launch_bounds__(256) void smallco_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
@@ -28,14 +28,23 @@ __global__ __launch_bounds__(256) void smallco_fwd_kernel(const float* __restric
   const long long HW = (long long)H * W;
   for (int c0 = 0; c0 < Cin; c0 += F_CH) {
     __syncthreads();
-    // halo patch: rows h0-1 .. h0+TH, cols w0-1 .. w0+TW  (col index 0 <-> w0-1)
-    for (int i = tid; i < F_CH * F_PH * (F_TW + 2); i += 256) {
-      int col = i % (F_TW + 2), r = (i / (F_TW + 2)) % F_PH, ch = i / ((F_TW + 2) * F_PH);
-      int gh = h0 - 1 + r, gw = w0 - 1 + col, c = c0 + ch;
+    // halo patch rows h0-1 .. h0+TH; interior columns as aligned 16-byte loads (dword loads cap a streaming
+    // kernel at ~1.3 TB/s on this chip), the two halo columns as scalars
+    for (int i = tid; i < F_CH * F_PH * (F_TW / 4); i += 256) {
+      int q = i % (F_TW / 4), row = i / (F_TW / 4), r = row % F_PH, ch = row / F_PH;
+      int gh = h0 - 1 + r, gw = w0 + 4 * q, c = c0 + ch;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < Cin && (unsigned)gh < (unsigned)H && gw < W)
+        v = *reinterpret_cast<const f32x4*>(x + ((long long)n * Cin + c) * HW + (long long)gh * W + gw);
+      *reinterpret_cast<f32x4*>(&patch[ch][r][4 + 4 * q]) = v;
+    }
+    for (int i = tid; i < F_CH * F_PH * 2; i += 256) {
+      int side = i & 1, row = i >> 1, r = row % F_PH, ch = row / F_PH;
+      int gh = h0 - 1 + r, gw = side ? w0 + F_TW : w0 - 1, c = c0 + ch;
       float v = 0.f;
       if (c < Cin && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
         v = x[((long long)n * Cin + c) * HW + (long long)gh * W + gw];
-      patch[ch][r][col] = v;
+      patch[ch][r][side ? F_TW + 4 : 3] = v;
     }
     __syncthreads();
     const int nch = min(F_CH, Cin - c0);
@@ -43,9 +52,10 @@ __global__ __launch_bounds__(256) void smallco_fwd_kernel(const float* __restric
       float xv[3][6];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const float4 a = *reinterpret_cast<const float4*>(&patch[ch][ty + r][4 * tx]);
-        const float2 b = *reinterpret_cast<const float2*>(&patch[ch][ty + r][4 * tx + 4]);
-        xv[r][0] = a.x; xv[r][1] = a.y; xv[r][2] = a.z; xv[r][3] = a.w; xv[r][4] = b.x; xv[r][5] = b.y;
+        const f32x4 m = *reinterpret_cast<const f32x4*>(&patch[ch][ty + r][4 * tx + 4]);
+        xv[r][0] = patch[ch][ty + r][4 * tx + 3];
+        xv[r][1] = m.x; xv[r][2] = m.y; xv[r][3] = m.z; xv[r][4] = m.w;
+        xv[r][5] = patch[ch][ty + r][4 * tx + 8];
       }
 #pragma unroll
       for (int co = 0; co < COUT; ++co) {

@@ -250,6 +250,39 @@ __device__ __forceinline__ float cat_relu_val(const CatArgs& a, int n, int c, in
   return v;
 }
 
+// value of relu(affine(src)) bilinearly upsampled at (ho, wo) of plane p (row pointers of the low-res plane)
+__device__ __forceinline__ float up2x_at(const float* p, int W, int Hs, int Ws, float rh, float rw, float scv, float shv,
+                                         int ho, int wo) {
+  float fh = rh * (float)ho, fw = rw * (float)wo;
+  int h0 = (int)fh, w0 = (int)fw;
+  int h1 = h0 + (h0 < Hs - 1), w1 = w0 + (w0 < Ws - 1);
+  float lh = fh - (float)h0, lw = fw - (float)w0;
+  float v00 = fmaxf(fmaf(p[h0 * W + w0], scv, shv), 0.f), v01 = fmaxf(fmaf(p[h0 * W + w1], scv, shv), 0.f);
+  float v10 = fmaxf(fmaf(p[h1 * W + w0], scv, shv), 0.f), v11 = fmaxf(fmaf(p[h1 * W + w1], scv, shv), 0.f);
+  return (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+}
+
+// 16-byte stores: thread = 4 consecutive output columns.  grid (ceil(Wo/4/Wb), ceil(Ho/rows), N*C)
+__global__ __launch_bounds__(256) void relu_up2x_fwd4_kernel(CatArgs a, float* __restrict__ out, int lw) {
+  const int Ho = 2 * a.H, Wo = 2 * a.W, C = a.C0 + a.C1;
+  const int nc = blockIdx.z, n = nc / C, c = nc % C;
+  const int wq = (blockIdx.x << lw) + (threadIdx.x & ((1 << lw) - 1));
+  const int ho = blockIdx.y * (256 >> lw) + (threadIdx.x >> lw);
+  if (4 * wq >= Wo || ho >= Ho) return;
+  const bool first = c < a.C0;
+  const int cs = first ? c : c - a.C0;
+  const float* sc = first ? a.sc0 : a.sc1;
+  const float* sh = first ? a.sh0 : a.sh1;
+  const float scv = sc ? sc[cs] : 1.f, shv = sc ? sh[cs] : 0.f;
+  const float* p = (first ? a.x0 : a.x1) + ((long long)n * (first ? a.C0 : a.C1) + cs) * a.H * a.W;
+  f32x4 v;
+  v.x = up2x_at(p, a.W, a.H, a.W, a.rh, a.rw, scv, shv, ho, 4 * wq);
+  v.y = up2x_at(p, a.W, a.H, a.W, a.rh, a.rw, scv, shv, ho, 4 * wq + 1);
+  v.z = up2x_at(p, a.W, a.H, a.W, a.rh, a.rw, scv, shv, ho, 4 * wq + 2);
+  v.w = up2x_at(p, a.W, a.H, a.W, a.rh, a.rw, scv, shv, ho, 4 * wq + 3);
+  *reinterpret_cast<f32x4*>(out + ((long long)nc * Ho + ho) * Wo + 4 * wq) = v;
+}
+
 // grid (ceil(Wo/Wb), ceil(Ho/rows), N*C) with Wb = 2^lw columns x rows = 256/Wb rows per block:
 // no per-element div/mod, full 256-thread blocks on narrow planes too
 __global__ __launch_bounds__(256) void relu_up2x_fwd_kernel(CatArgs a, float* __restrict__ out, int lw) {
@@ -302,6 +335,14 @@ extern "C" int avsep_relu_up2x_fwd(const avsep_cat_desc* d, float* out, avsep_st
   CatArgs a = make_cat(d);
   long long planes = (long long)d->N * (d->C0 + d->C1);
   if (planes > 0x7fffffffLL || 2 * d->H > 65535) return AVSEP_ERR_ARG;
+  if (!d->bcast0 && !d->bcast1 && d->W >= 8) {              // Wo % 4 == 0: four outputs per thread, 16-byte stores
+    int l4 = 6;
+    while (l4 > 2 && (1 << (l4 - 1)) >= d->W / 2) --l4;
+    hipLaunchKernelGGL(relu_up2x_fwd4_kernel, dim3(cdiv(d->W / 2, 1 << l4), cdiv(2 * d->H, 256 >> l4), (unsigned)planes),
+                       dim3(256), 0, (hipStream_t)stream, a, out, l4);
+    AVSEP_LAUNCH_CHECK();
+    return AVSEP_OK;
+  }
   int lw = 8;
   while (lw > 2 && (1 << (lw - 1)) >= 2 * d->W) --lw;      // smallest power of two >= Wo, capped at 256
   hipLaunchKernelGGL(relu_up2x_fwd_kernel, dim3(cdiv(2 * d->W, 1 << lw), cdiv(2 * d->H, 256 >> lw), (unsigned)planes),
