@@ -336,3 +336,51 @@ def test_shared_encoder_pair_equals_two_passes(dev, golden):
         assert_close(a["g"][k], b["g"][k], 2e-5, "grad " + k)
     for k in a["b"]:
         assert_close(a["b"][k].double(), b["b"][k].double(), 1e-6, "buffer " + k)
+
+
+def test_config1_full_size_step_vs_oracle(dev):
+    """BASELINE.json configs[0]/[1] shapes at batch 2: 65535-sample waveforms -> STFT 1022/256 -> 512x256 ->
+    log-frequency warp to 256x256, 3 frames of 224x224 per source, unet7 (64 ngf) + hidsep(sig) + resnet18dilated,
+    BCE, SGD.  One AV and one AO train step of the HIP path against the CPU oracle on identical inputs and weights
+    (reference weight init for the U-Net, i.e. N(0, 1e-3) convs, plus a wide-init variant): loss, match loss and the
+    north-star bound  mask MSE <= 1e-4  (measured ~1e-12)."""
+    import numpy as np
+    P = _pkg()
+    from oracle import nets as O, step as OS, criterion as OC, stft as OST
+    a = P.arguments.train_music_args()
+    a.stft_pad_mode = "reflect"
+    raw = P.synth.make_batch(2, a.num_mix, a.num_frames, 224, a.audLen, seed=77)
+    mags = [torch.from_numpy(np.stack([OST.stft_mag_phase(w.numpy())[0] for w in src]))[:, None] for src in raw["audios"]]
+    mix = torch.from_numpy(np.stack([OST.stft_mag_phase(w.numpy())[0] for w in raw["audio_mix"]]))[:, None]
+    for wide in (False, True):
+        torch.manual_seed(11)
+        gen = torch.Generator().manual_seed(11)
+        osnd = O.build_sound(a.arch_sound, a.num_channels, a.fusion_type, a.att_type)
+        if wide:
+            O.wide_init(osnd, gen)
+        ofrm = O.build_frame(a.arch_frame, a.vis_channels, a.img_pool)
+        mb = P.ModelBuilder()
+        snd = mb.build_sound(arch=a.arch_sound, fc_dim=a.num_channels, fusion_type=a.fusion_type, att_type=a.att_type)
+        frm = mb.build_frame(arch=a.arch_frame, fc_dim=a.vis_channels, pool_type=a.img_pool)
+        snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict())
+        snd, frm = snd.to(dev), frm.to(dev)
+        wrap = P.NetWrapper((snd, frm), mb.build_criterion(a.loss, use_pit=True), mb.build_criterion(a.loss))
+        opt = P.create_optimizer((snd, frm), a)
+        owrap = OS.NetWrapper((osnd, ofrm), OC.build_criterion(a.loss, True), OC.build_criterion(a.loss))
+        oopt = OS.create_optimizer((osnd, ofrm), a)
+        for use_vis in (True, False):
+            draws = torch.tensor([True, False])
+            snd.ao_draws = draws
+            osnd.levels()[-1].fusion.ao_draws = draws
+            gb = {"audios": [w.to(dev) for w in raw["audios"]], "audio_mix": raw["audio_mix"].to(dev),
+                  "frames": [f.to(dev) for f in raw["frames"]]}          # the HIP path runs its own STFT
+            cb = {"mag_mix": mix.clone(), "mags": [m.clone() for m in mags], "frames": raw["frames"]}
+            err, match, outs = P.net_wrapper.train_step_async(wrap, gb, opt, use_vis, a)
+            oerr, omatch, oouts = OS.train_step(owrap, cb, oopt, use_vis, a)
+            mse = max(((x.detach().cpu() - y.detach()) ** 2).mean().item()
+                      for x, y in zip(outs["pred_masks"], oouts["pred_masks"]))
+            assert mse <= 1e-4, f"mask MSE {mse} (wide={wide}, use_vis={use_vis})"
+            assert abs(err.item() - oerr) <= 1e-4 * max(1.0, abs(oerr)), (wide, use_vis, err.item(), oerr)
+            if use_vis:
+                assert abs(match.item() - omatch) <= 1e-4
+            print(f"config1 wide={wide} {'AV' if use_vis else 'AO'}: err hip={err.item():.6f} oracle={oerr:.6f} mask-MSE={mse:.2e}")
