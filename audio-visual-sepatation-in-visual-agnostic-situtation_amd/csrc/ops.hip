@@ -894,6 +894,38 @@ extern "C" int avsep_innerprod_bwd(const float* img, const float* snd, const flo
   return AVSEP_OK;
 }
 
+// Separation metrics (main.py:260-266 via asteroid.metrics.get_metrics): the three inner products every
+// SDR-type ratio is made of, per row: sums[r] = (<est,ref>, <ref,ref>, <est,est>) in fp64.  grid (chunks, R)
+__global__ __launch_bounds__(256) void sdr_sums_kernel(const float* __restrict__ est, const float* __restrict__ ref,
+                                                       int L, long long est_stride, long long ref_stride,
+                                                       double* __restrict__ sums) {
+  const int r = blockIdx.y;
+  const float* e = est + (long long)r * est_stride;
+  const float* g = ref + (long long)r * ref_stride;
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) {
+    double x = e[i], y = g[i];
+    a += x * y; b += y * y; c += x * x;
+  }
+  a = wave_sum_d(a); b = wave_sum_d(b); c = wave_sum_d(c);
+  __shared__ double sh[12];
+  if ((threadIdx.x & 63) == 0) { int w = threadIdx.x >> 6; sh[w] = a; sh[4 + w] = b; sh[8 + w] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[r * 3 + 0], sh[0] + sh[1] + sh[2] + sh[3]);
+    atomicAdd(&sums[r * 3 + 1], sh[4] + sh[5] + sh[6] + sh[7]);
+    atomicAdd(&sums[r * 3 + 2], sh[8] + sh[9] + sh[10] + sh[11]);
+  }
+}
+extern "C" int avsep_sdr_sums(const float* est, const float* ref, int32_t R, int32_t L, int64_t est_stride,
+                              int64_t ref_stride, double* sums, avsep_stream_t stream) {
+  if (!est || !ref || !sums || R <= 0 || R > 65535 || L <= 0) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(sdr_sums_kernel, dim3(min(cdiv(L, 2048), 64), R), dim3(256), 0, (hipStream_t)stream, est, ref, L,
+                     (long long)est_stride, (long long)ref_stride, sums);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
 extern "C" int avsep_version(void) { return 100; }
 extern "C" const char* avsep_arch(void) { return "gfx950"; }
 extern "C" const char* avsep_strerror(int code) {

@@ -247,6 +247,11 @@ int avsep_innerprod_fwd(const float* img, const float* snd, const float* scale, 
 int avsep_innerprod_bwd(const float* img, const float* snd, const float* scale, const float* dz,
                         int32_t B, int32_t K, int32_t HW, float* dsnd, float* r, avsep_stream_t stream);
 
+/* Separation metrics (main.py:260-266): per row r the fp64 inner products
+ * sums[3r..] += (<est,ref>, <ref,ref>, <est,est>) over L samples; SI-SDR and SDR are ratios of them. */
+int avsep_sdr_sums(const float* est, const float* ref, int32_t R, int32_t L, int64_t est_stride,
+                   int64_t ref_stride, double* sums, avsep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

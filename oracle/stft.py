@@ -66,3 +66,16 @@ def istft_reconstruction(mag, phase, hop=256):
     # utils.py:101-104
     spec = mag.astype(np.complex64) * np.exp(1j * phase)
     return np.clip(istft(spec, hop), -1.0, 1.0)
+
+
+def si_sdr(est, ref):
+    """asteroid / pb_bss_eval SI-SDR: 10 log10(|a s|^2 / |s_hat - a s|^2), a = <s_hat,s>/<s,s> (no mean removal)."""
+    est, ref = np.asarray(est, np.float64), np.asarray(ref, np.float64)
+    a = np.dot(est, ref) / np.dot(ref, ref)
+    proj = a * ref
+    return 10 * np.log10(np.sum(proj ** 2) / np.sum((est - proj) ** 2))
+
+
+def sdr_plain(est, ref):
+    est, ref = np.asarray(est, np.float64), np.asarray(ref, np.float64)
+    return 10 * np.log10(np.sum(ref ** 2) / np.sum((ref - est) ** 2))

@@ -384,3 +384,32 @@ def test_config1_full_size_step_vs_oracle(dev):
             if use_vis:
                 assert abs(match.item() - omatch) <= 1e-4
             print(f"config1 wide={wide} {'AV' if use_vis else 'AO'}: err hip={err.item():.6f} oracle={oerr:.6f} mask-MSE={mse:.2e}")
+
+
+def test_eval_path_vs_oracle(dev):
+    """N1: un-warp -> threshold -> mask*mag -> iSTFT -> SI-SDR / SDR on the GPU against the numpy/torch-CPU oracle."""
+    import numpy as np
+    import torch.nn.functional as F
+    P = _pkg()
+    from oracle import stft as OST, step as OS
+    a = P.arguments.train_music_args()
+    a.stft_pad_mode = "reflect"
+    raw = P.synth.make_batch(2, 2, 1, 32, a.audLen, seed=5)
+    gb = {"audios": [w.to(dev) for w in raw["audios"]], "audio_mix": raw["audio_mix"].to(dev)}
+    mb = P.ModelBuilder()
+    wrap = P.NetWrapper((mb.build_sound(arch="unet5", fc_dim=2, fusion_type="hidsep", att_type="sig"),
+                         mb.build_frame(arch="resnet18dilated", fc_dim=256)), None, None)
+    wrap.attach_stft(gb, a)
+    gen = torch.Generator().manual_seed(3)
+    masks = [torch.rand(2, 1, 256, 256, generator=gen) for _ in range(2)]
+    out = P.evaluate.calc_metrics(gb, {"pred_masks": [m.to(dev) for m in masks]}, a)
+    grid = torch.from_numpy(OS.warpgrid(2, 512, 256, warp=False))
+    for n in range(2):
+        lin = (F.grid_sample(masks[n], grid, align_corners=False) > a.mask_thres).float().numpy()
+        for b in range(2):
+            mag, ph = OST.stft_mag_phase(raw["audio_mix"][b].numpy())
+            wav = OST.istft_reconstruction(mag * lin[b, 0], ph)
+            ref = raw["audios"][n][b, :len(wav)].numpy()
+            assert np.abs(out["pred_wavs"][n, b].cpu().numpy() - wav).max() < 2e-4
+            assert abs(out["si_sdr"][b, n].item() - OST.si_sdr(wav, ref)) < 1e-2
+            assert abs(out["sdr"][b, n].item() - OST.sdr_plain(wav, ref)) < 1e-2
