@@ -536,6 +536,8 @@ bool smallco_applicable(const avsep_conv_desc* d);
 int smallco_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* bias, float* y, hipStream_t st);
 size_t smallco_wgrad_workspace_floats(const avsep_conv_desc* d);
 int smallco_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st);
+bool smallci_applicable(const avsep_conv_desc* d);
+int smallci_dgrad(const avsep_conv_desc* d, const float* w_oihw, const float* dy, float* dx, hipStream_t st);
 // conv3x3.hip: LDS-halo-patch kernel for 3x3 / stride 1 / pad 1 (forward, and dgrad through flipped weights)
 bool c3_applicable(const avsep_conv_desc* d, int mode);
 size_t c3_packed_floats(const avsep_conv_desc* d, int mode);
@@ -583,6 +585,7 @@ static inline int packed_ld(const avsep_conv_desc* d, int mode) { return roundup
 
 extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
   if (!d || (mode != 0 && mode != 1)) return 0;
+  if (mode == 1 && smallci_applicable(d)) return (size_t)d->Cout * d->Cin * d->KH * d->KW;   // OIHW as is
   if (c3_applicable(d, mode)) return c3_packed_floats(d, mode);
   return (size_t)packed_rows(d, mode) * packed_ld(d, mode);
 }
@@ -590,6 +593,12 @@ extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
 extern "C" int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w, float* packed, int mode,
                                        avsep_stream_t stream) {
   if (!d || !w || !packed || (mode != 0 && mode != 1)) return AVSEP_ERR_ARG;
+  if (mode == 1 && smallci_applicable(d)) {
+    if (hipMemcpyAsync(packed, w, (size_t)d->Cout * d->Cin * d->KH * d->KW * sizeof(float), hipMemcpyDeviceToDevice,
+                       (hipStream_t)stream) != hipSuccess)
+      return AVSEP_ERR_LAUNCH;
+    return AVSEP_OK;
+  }
   if (c3_applicable(d, mode)) return c3_pack(d, w, packed, mode, (hipStream_t)stream);
   int rows = packed_rows(d, mode), ld = packed_ld(d, mode);
   long long total = (long long)rows * ld;
@@ -643,7 +652,7 @@ extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cout * d->Ho * d->Wo * sizeof(float) : 0;
 }
 extern "C" size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d) {
-  if (check_desc(d) || c3_applicable(d, 1)) return 0;
+  if (check_desc(d) || c3_applicable(d, 1) || smallci_applicable(d)) return 0;
   SplitPlan p = dgrad_split(d);
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cin * d->H * d->W * sizeof(float) : 0;
 }
@@ -694,6 +703,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   int rc = check_desc(d);
   if (rc) return rc;
   if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
+  if (smallci_applicable(d)) return smallci_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c3_applicable(d, 1)) return c3_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.wp = w_packed_dgrad; a.wp_ld = packed_ld(d, 1); a.dy = dy; a.out = dx;

@@ -195,8 +195,64 @@ __global__ void smallco_reduce_kernel(const float* __restrict__ part, float* __r
 }
 
 // ---------------------------------------------------------------------------
+// data gradient for a conv with <= 4 INPUT channels (the U-Net's first conv, 1 -> 64, 4x4 s2: its input
+// gradient is only needed for the bn0 parameter gradients).  M = Cin is too small for an MFMA tile:
+// thread = one input pixel, all Cin channels; dy rows are read coalesced, weights through the scalar unit.
+//   dx[n,ci,hi,wi] = sum_{co,kh,kw} w[co,ci,kh,kw] * dy[n,co,(hi+p-kh)/s,(wi+p-kw)/s]   (exact divisions only)
+// ---------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void smallci_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                            float* __restrict__ dx, int Cout, int H, int W, int Ho,
+                                                            int Wo, int KH, int KW, int stride, int pad) {
+  const int n = blockIdx.z, hi = blockIdx.y, wi = blockIdx.x * 256 + threadIdx.x;
+  if (wi >= W) return;
+  float acc[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
+  const long long HoWo = (long long)Ho * Wo;
+  for (int kh = 0; kh < KH; ++kh) {
+    const int th = hi + pad - kh;                       // block-uniform
+    if (th < 0 || th % stride) continue;
+    const int ho = th / stride;
+    if (ho >= Ho) continue;
+    for (int kw = 0; kw < KW; ++kw) {
+      const int tw = wi + pad - kw;
+      const bool ok = tw >= 0 && tw % stride == 0 && tw / stride < Wo;
+      const int wo = ok ? tw / stride : 0;
+      const float* dp = dy + (long long)n * Cout * HoWo + (long long)ho * Wo + wo;
+      for (int co = 0; co < Cout; ++co) {
+        const float d = ok ? dp[co * HoWo] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) acc[c] = fmaf(w[((co * CIN + c) * KH + kh) * KW + kw], d, acc[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) dx[(((long long)n * CIN + c) * H + hi) * W + wi] = acc[c];
+}
+
+// ---------------------------------------------------------------------------
 // host dispatch (called from conv.hip)
 // ---------------------------------------------------------------------------
+bool smallci_applicable(const avsep_conv_desc* d) {
+  return d->Cin <= 4 && d->dil == 1 && !d->up2x && d->H <= 65535 && d->N <= 65535;
+}
+int smallci_dgrad(const avsep_conv_desc* d, const float* w_oihw, const float* dy, float* dx, hipStream_t st) {
+  dim3 grid(cdiv(d->W, 256), d->H, d->N);
+#define LAUNCH_CI(CI)                                                                                              \
+  hipLaunchKernelGGL(smallci_dgrad_kernel<CI>, grid, dim3(256), 0, st, w_oihw, dy, dx, d->Cout, d->H, d->W, d->Ho, \
+                     d->Wo, d->KH, d->KW, d->stride, d->pad)
+  switch (d->Cin) {
+    case 1: LAUNCH_CI(1); break;
+    case 2: LAUNCH_CI(2); break;
+    case 3: LAUNCH_CI(3); break;
+    default: LAUNCH_CI(4); break;
+  }
+#undef LAUNCH_CI
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
 bool smallco_applicable(const avsep_conv_desc* d) {
   return d->Cout <= SC_MAXCO && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->up2x &&
          d->C0 == d->Cin && !d->scale0 && d->act0 == AVSEP_ACT_NONE && d->W <= G_WMAX && (d->W & 15) == 0 && d->N <= 65535;

@@ -176,6 +176,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     conv_ms, conv_fl, by, fam = timer.summary()
+    # extra (outside the timed region, not part of `value`): the audio-only step and the 1:1 AV/AO alternation
+    # the shipped flags produce (iter_per_av 2: AV on even iterations, scripts/train_MUSIC.sh:10-11,50)
+    ao_rate = None
+    if not o.ao and world == 1:
+        for _ in range(2):
+            P.net_wrapper.train_step_async(wrap, batch(), opt, False, a)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(4):
+            P.net_wrapper.train_step_async(wrap, batch(), opt, False, a)
+        torch.cuda.synchronize()
+        ao_rate = 4 * B / (time.perf_counter() - t1)
 
     if rank == 0:
         ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -193,6 +205,9 @@ def main():
                        "(BASELINE configs[1])" % B,
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "loss": float(err), "match_loss": float(match) if match is not None else None,
+            "extra": None if ao_rate is None else {
+                "ao_step_mixtures_per_s": ao_rate,
+                "av_ao_1to1_blend_mixtures_per_s": 2.0 / (1.0 / (world * B * o.steps / dt) + 1.0 / ao_rate)},
             # dominant kernel = the HIP kernel with the largest time per step; achieved = its algorithmic FLOPs per
             # launch / its average launch duration (HIP events on the launch stream, inside the timed region)
             "roofline": {"bound": "mfma", "achieved": d_ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
