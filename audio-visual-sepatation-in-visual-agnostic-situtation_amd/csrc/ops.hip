@@ -152,24 +152,28 @@ extern "C" int avsep_bn_bwd_apply(const float* dz, const float* y, const float* 
 
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
-                                                         const float* __restrict__ res, int act, int C, int HW,
+                                                         const float* __restrict__ res, const float* __restrict__ rscale,
+                                                         const float* __restrict__ rshift, int act, int C, int HW,
                                                          float* __restrict__ z) {
   const int c = blockIdx.y, n = blockIdx.z;
   const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+  const float rs = rscale ? rscale[c] : 1.f, rh = rscale ? rshift[c] : 0.f;
   const long long base = ((long long)n * C + c) * HW;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
     float v = fmaf(y[base + i], sc, sh);
-    if (res) v += res[base + i];
+    if (res) v += fmaf(res[base + i], rs, rh);
     z[base + i] = act_apply(v, act);
   }
 }
 
 extern "C" int avsep_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
-                                int32_t act, int32_t N, int32_t C, int32_t HW, float* z, avsep_stream_t stream) {
+                                const float* res_scale, const float* res_shift, int32_t act, int32_t N, int32_t C,
+                                int32_t HW, float* z, avsep_stream_t stream) {
   if (!y || !z || N <= 0 || C <= 0 || HW <= 0 || C > 65535 || N > 65535) return AVSEP_ERR_ARG;
+  if ((res_scale == nullptr) != (res_shift == nullptr)) return AVSEP_ERR_ARG;
   int gx = min(cdiv(HW, 256), 64);
-  hipLaunchKernelGGL(affine_act_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, y, scale, shift, residual, act,
-                     C, HW, z);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, y, scale, shift, residual,
+                     res_scale, res_shift, act, C, HW, z);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
@@ -179,12 +183,15 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
                                                              const float* __restrict__ res,
+                                                             const float* __restrict__ rscale,
+                                                             const float* __restrict__ rshift,
                                                              const float* __restrict__ add,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int act, int N, int C,
                                                              int HW, float* __restrict__ out, double* bstats) {
   const int c = blockIdx.x;
   const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+  const float rs = rscale ? rscale[c] : 1.f, rh = rscale ? rshift[c] : 0.f;
   const float mu = mean ? mean[c] : 0.f, is = invstd ? invstd[c] : 1.f;
   const long long total = (long long)N * HW;
   const long long per = (total + gridDim.y - 1) / gridDim.y;
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
     long long o = ((long long)n * C + c) * HW + hw;
     float yv = y[o];
     float pre = fmaf(yv, sc, sh);
-    if (res) pre += res[o];
+    if (res) pre += fmaf(res[o], rs, rh);
     float g = act_grad(pre, act) * dz[o];
     if (add) g += add[o];
     out[o] = g;
@@ -215,16 +222,16 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
 }
 
 extern "C" int avsep_affine_act_bwd(const float* dz, const float* y, const float* scale, const float* shift,
-                                    const float* residual, const float* add, const float* mean, const float* invstd,
-                                    int32_t act, int32_t N, int32_t C, int32_t HW, float* dz_pre, double* bstats,
-                                    avsep_stream_t stream) {
+                                    const float* residual, const float* res_scale, const float* res_shift,
+                                    const float* add, const float* mean, const float* invstd, int32_t act, int32_t N,
+                                    int32_t C, int32_t HW, float* dz_pre, double* bstats, avsep_stream_t stream) {
   if (!dz || !y || !dz_pre || N <= 0 || C <= 0 || HW <= 0) return AVSEP_ERR_ARG;
   if (bstats && (!mean || !invstd)) return AVSEP_ERR_ARG;
   long long total = (long long)N * HW;
   int chunks = (int)min((long long)cdiv(2048, C), (total + 2047) / 2048);
   if (chunks < 1) chunks = 1;
   hipLaunchKernelGGL(affine_act_bwd_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, y, scale, shift,
-                     residual, add, mean, invstd, act, N, C, HW, dz_pre, bstats);
+                     residual, res_scale, res_shift, add, mean, invstd, act, N, C, HW, dz_pre, bstats);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
@@ -720,12 +727,16 @@ extern "C" int avsep_mask_loss_bwd(const float* logits, const float* gt, const f
 // ============================================================================
 // pooling, temporal mean, SGD, synthesizer
 // ============================================================================
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int NC, int H, int W, int Ho, int Wo,
-                                                          float* __restrict__ y, int* __restrict__ idx) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int act, int C, int NC, int H,
+                                                          int W, int Ho, int Wo, float* __restrict__ y,
+                                                          int* __restrict__ idx) {
   const long long total = (long long)NC * Ho * Wo;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho);
     long long nc = i / ((long long)Wo * Ho);
+    const int c = (int)(nc % C);
+    const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;   // folded BatchNorm + activation of the stem
     const float* p = x + nc * H * W;
     float best = -INFINITY;
     int bi = -1;
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
       for (int kw = 0; kw < 3; ++kw) {
         int w = wo * 2 - 1 + kw;
         if ((unsigned)w >= (unsigned)W) continue;
-        float v = p[h * W + w];
+        float v = act_apply(fmaf(p[h * W + w], sc, sh), act);
         if (v > best || bi < 0) { best = v; bi = h * W + w; }
       }
     }
@@ -743,13 +754,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     if (idx) idx[i] = bi;
   }
 }
-extern "C" int avsep_maxpool3x3s2_fwd(const float* x, int32_t NC, int32_t H, int32_t W, float* y, int32_t* idx,
-                                      avsep_stream_t stream) {
-  if (!x || !y || NC <= 0 || H <= 0 || W <= 0) return AVSEP_ERR_ARG;
+extern "C" int avsep_maxpool3x3s2_fwd(const float* x, const float* scale, const float* shift, int32_t act, int32_t C,
+                                      int32_t NC, int32_t H, int32_t W, float* y, int32_t* idx, avsep_stream_t stream) {
+  if (!x || !y || NC <= 0 || H <= 0 || W <= 0 || C <= 0 || NC % C) return AVSEP_ERR_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return AVSEP_ERR_ARG;
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   long long total = (long long)NC * Ho * Wo;
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((int)min((total + 255) / 256, (long long)65536)), dim3(256), 0,
-                     (hipStream_t)stream, x, NC, H, W, Ho, Wo, y, idx);
+                     (hipStream_t)stream, x, scale, shift, act, C, NC, H, W, Ho, Wo, y, idx);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }

@@ -100,26 +100,30 @@ def bn_bwd_coeffs(bstats, count, gamma, mean, invstd):
     return dgamma, dbeta, pqr
 
 
-def bn_bwd_apply_(dz, y, pqr):
+def bn_bwd_apply_(dz, y, pqr, out=None):
+    """dy = p*dz + q*y + r per channel; in place on dz unless `out` is given."""
     N, Cc = y.shape[:2]
-    call("avsep_bn_bwd_apply", ptr(dz), ptr(y), ptr(pqr), N, Cc, y.numel() // (N * Cc), ptr(dz))
-    return dz
+    dst = dz if out is None else out
+    call("avsep_bn_bwd_apply", ptr(dz), ptr(y), ptr(pqr), N, Cc, y.numel() // (N * Cc), ptr(dst))
+    return dst
 
 
-def affine_act(y, scale, shift, residual, act):
+def affine_act(y, scale, shift, residual, act, res_scale=None, res_shift=None):
     N, Cc = y.shape[:2]
     z = torch.empty_like(y)
-    call("avsep_affine_act", ptr(y), ptr(scale), ptr(shift), ptr(residual), act, N, Cc,
+    call("avsep_affine_act", ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift), act, N, Cc,
          y.numel() // (N * Cc), ptr(z))
     return z
 
 
-def affine_act_bwd_(dz, y, scale, shift, residual, add, mean, invstd, act, bstats):
-    """In place on dz: dz <- act'(scale*y+shift[+res]) * dz (+ add); accumulates bstats."""
+def affine_act_bwd_(dz, y, scale, shift, residual, add, mean, invstd, act, bstats, res_scale=None, res_shift=None,
+                    out=None):
+    """dz <- act'(scale*y+shift[+res]) * dz (+ add) (in place unless `out`); accumulates bstats."""
     N, Cc = y.shape[:2]
-    call("avsep_affine_act_bwd", ptr(dz), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(add),
-         ptr(mean), ptr(invstd), act, N, Cc, y.numel() // (N * Cc), ptr(dz), ptr(bstats))
-    return dz
+    dst = dz if out is None else out
+    call("avsep_affine_act_bwd", ptr(dz), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift),
+         ptr(add), ptr(mean), ptr(invstd), act, N, Cc, y.numel() // (N * Cc), ptr(dst), ptr(bstats))
+    return dst
 
 
 class Cat:
@@ -189,12 +193,13 @@ def temporal_mean_bwd(dy, B, T):
     return dx
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, scale=None, shift=None, act=0):
+    """MaxPool2d(3,2,1) of act(scale*x+shift) (the stem's BN+ReLU folded into the pooling read)."""
     N, Cc, H, W = x.shape
     Ho, Wo = out_size(H, 3, 2, 1, 1), out_size(W, 3, 2, 1, 1)
     y = _f32((N, Cc, Ho, Wo), x)
     idx = torch.empty((N, Cc, Ho, Wo), dtype=torch.int32, device=x.device)
-    call("avsep_maxpool3x3s2_fwd", ptr(x), N * Cc, H, W, ptr(y), ptr(idx))
+    call("avsep_maxpool3x3s2_fwd", ptr(x), ptr(scale), ptr(shift), act, Cc, N * Cc, H, W, ptr(y), ptr(idx))
     return y, idx
 
 

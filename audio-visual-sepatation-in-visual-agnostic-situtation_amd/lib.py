@@ -53,8 +53,8 @@ SIGNATURES = {
     "avsep_bn_finalize": (C.c_int, [_P, _D, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P]),
     "avsep_bn_bwd_coeffs": (C.c_int, [_P, _D, _P, _P, _P, _I, _P, _P, _P, _P]),
     "avsep_bn_bwd_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
-    "avsep_affine_act": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "avsep_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_affine_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "avsep_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "avsep_relu_up2x_fwd": (C.c_int, [_KD, _P, _P]),
     "avsep_relu_up2x_bwd": (C.c_int, [_KD, _P, _P, _P, _P, _P, _P, _I, _P]),
     "avsep_prepare": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -72,7 +72,7 @@ SIGNATURES = {
     "avsep_stft_mag": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "avsep_istft_workspace_bytes": (_Z, [_I, _I, _I]),
     "avsep_istft": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
-    "avsep_maxpool3x3s2_fwd": (C.c_int, [_P, _I, _I, _I, _P, _P, _P]),
+    "avsep_maxpool3x3s2_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "avsep_maxpool3x3s2_bwd": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "avsep_temporal_mean_fwd": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "avsep_temporal_mean_bwd": (C.c_int, [_P, _I, _I, _I, _P, _P]),

@@ -1,0 +1,143 @@
+"""ResNet-18 (dilated) frame trunk + fc conv as ONE autograd node over libavsep_gfx950.so.
+
+Reference: models/vision_net.py:62-147 (ResnetDilated / ResnetFC: torchvision resnet18 children[:-2],
+``_nostride_dilate``, the fc conv) — the per-frame visual conv stack of the AV step.
+
+Launch sequence per BasicBlock (z = block input, a materialised post-ReLU tensor):
+
+    y1 = conv3x3(z)                         BN1 batch statistics in the conv epilogue
+    y2 = conv3x3(relu(bn1(y1)))             BN1 + ReLU folded into conv2's operand gather; BN2 statistics in the epilogue
+    yd = conv1x1(z)                         only with a downsample branch; BNd statistics in the epilogue
+    z' = relu(bn2(y2) + (bnd(yd) | z))      one elementwise pass (avsep_affine_act)
+
+The stem is conv7x7/s2 with BN statistics in the epilogue, then max-pool 3x3/s2 reading relu(bn(y0)) on the fly.
+Backward mirrors it with the BatchNorm backward folded as dy = p*dz + q*y + r (see audio_net.py).  The torch
+modules in ``net.features`` / ``net.fc`` stay the parameter and running-statistics holders, so checkpoints and the
+optimizer see the same tensors whichever backend runs.
+"""
+import torch
+
+from .. import kernels as K
+from .. import lib
+from ..lib import ACT_NONE, ACT_RELU
+from .audio_net import _acc, _bn_back, _bn_run
+
+
+def _geom(conv):
+    k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+    if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or d[0] != d[1]:
+        raise lib.AvsepError("the HIP visual trunk needs square conv geometry")
+    return k[0], s[0], p[0], d[0]
+
+
+def _conv(src, conv, aff=None):
+    k, s, p, d = _geom(conv)
+    if aff is None:
+        return K.Conv(src, conv.out_channels, k, s, p, d)
+    return K.Conv(src, conv.out_channels, k, s, p, d, sc0=aff[0], sh0=aff[1], act0=ACT_RELU)
+
+
+def _conv_bn(src, conv, bn, training, aff=None):
+    cv = _conv(src, conv, aff)
+    st = K.zeros_stats(conv.out_channels, src) if training else None
+    y = cv.fwd(cv.pack(conv.weight.detach(), 0), None, st)
+    return cv, y, _bn_run(bn, st, y.numel() // y.shape[1], training, src)
+
+
+def blocks_of(features):
+    return [b for i in (4, 5, 6, 7) for b in features[i]]
+
+
+def param_list(net):
+    return list(net.features.parameters()) + list(net.fc.parameters())
+
+
+def trunk_forward(net, x, training):
+    f = net.features
+    S = {"x": x}
+    S["cv0"], S["y0"], S["bn0"] = _conv_bn(x, f[0], f[1], training)
+    z, S["idx"] = K.maxpool3x3s2(S["y0"], S["bn0"][0], S["bn0"][1], ACT_RELU)
+    S["blocks"] = []
+    for blk in blocks_of(f):
+        R = {"mod": blk, "z": z}
+        R["cv1"], R["y1"], R["bn1"] = _conv_bn(z, blk.conv1, blk.bn1, training)
+        R["cv2"], R["y2"], R["bn2"] = _conv_bn(R["y1"], blk.conv2, blk.bn2, training, aff=R["bn1"])
+        if blk.downsample is not None:
+            R["cvd"], R["yd"], R["bnd"] = _conv_bn(z, blk.downsample[0], blk.downsample[1], training)
+            z = K.affine_act(R["y2"], R["bn2"][0], R["bn2"][1], R["yd"], ACT_RELU, R["bnd"][0], R["bnd"][1])
+        else:
+            z = K.affine_act(R["y2"], R["bn2"][0], R["bn2"][1], R["z"], ACT_RELU)
+        S["blocks"].append(R)
+    S["cvf"] = _conv(z, net.fc)
+    S["zf"] = z
+    bias = net.fc.bias.detach() if net.fc.bias is not None else None
+    return S, S["cvf"].fwd(S["cvf"].pack(net.fc.weight.detach(), 0), bias, None)
+
+
+def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None):
+    """g <- relu'(bn(y) [+ residual]) * g in place; returns the folded BatchNorm-backward coefficients of bn(y)."""
+    bst = K.zeros_stats(y.shape[1], y)
+    K.affine_act_bwd_(g, y, bnrow[0], bnrow[1], res, None, bnrow[2], bnrow[3], ACT_RELU, bst, res_scale=rs, res_shift=rh)
+    return _bn_back(grads, bn_mod, bnrow, bst, y.numel() // y.shape[1])
+
+
+def trunk_backward(net, S, dout, grads):
+    f = net.features
+    cvf = S["cvf"]
+    dw, db = cvf.wgrad(dout, want_bias=net.fc.bias is not None)
+    _acc(grads, net.fc.weight, dw)
+    _acc(grads, net.fc.bias, db)
+    g = cvf.dgrad(cvf.pack(net.fc.weight.detach(), 1), dout)          # dL/dz of the last block
+    for R in reversed(S["blocks"]):
+        blk = R["mod"]
+        ds = blk.downsample is not None
+        bnd = R.get("bnd")
+        pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
+                             rs=bnd[0] if ds else None, rh=bnd[1] if ds else None)   # g = dL/d(pre-ReLU sum)
+        dy2 = K.bn_bwd_apply_(g, R["y2"], pqr2, out=torch.empty_like(g))
+        _acc(grads, blk.conv2.weight, R["cv2"].wgrad(dy2)[0])
+        da = R["cv2"].dgrad(R["cv2"].pack(blk.conv2.weight.detach(), 1), dy2)
+        del dy2
+        pqr1 = _relu_bn_back(grads, da, R["y1"], R["bn1"], blk.bn1)
+        K.bn_bwd_apply_(da, R["y1"], pqr1)                              # da = dL/dy1
+        _acc(grads, blk.conv1.weight, R["cv1"].wgrad(da)[0])
+        dz = R["cv1"].dgrad(R["cv1"].pack(blk.conv1.weight.detach(), 1), da)
+        del da
+        if ds:
+            bst = K.zeros_stats(g.shape[1], g)                          # BNd statistics of g (values of g unchanged)
+            K.affine_act_bwd_(g, R["yd"], None, None, None, None, bnd[2], bnd[3], ACT_NONE, bst)
+            pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, g.numel() // g.shape[1])
+            K.bn_bwd_apply_(g, R["yd"], pqrd)                           # g = dL/dyd
+            _acc(grads, blk.downsample[0].weight, R["cvd"].wgrad(g)[0])
+            dz.add_(R["cvd"].dgrad(R["cvd"].pack(blk.downsample[0].weight.detach(), 1), g))
+        else:
+            dz.add_(g)
+        g = dz
+    y0 = S["y0"]
+    g = K.maxpool3x3s2_bwd(g, S["idx"], y0.shape[2], y0.shape[3])
+    pqr0 = _relu_bn_back(grads, g, y0, S["bn0"], f[1])
+    K.bn_bwd_apply_(g, y0, pqr0)
+    _acc(grads, f[0].weight, S["cv0"].wgrad(g)[0])                      # the frames need no gradient
+
+
+class _ResnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        S, out = trunk_forward(net, x, net.training)
+        ctx.S, ctx.net, ctx.training = S, net, net.training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise lib.AvsepError("backward through the visual trunk needs train mode (batch statistics)")
+        grads = {}
+        trunk_backward(ctx.net, ctx.S, dout.contiguous(), grads)
+        ctx.S = None
+        return (None, None, *[grads.get(p) for p in param_list(ctx.net)])
+
+
+def run(net, x):
+    """fc(features(x)) for frames x [N,3,H,W] on the HIP kernels."""
+    lib.require_gpu(x)
+    return _ResnetFn.apply(net, x.contiguous().float(), *param_list(net))

@@ -1,17 +1,23 @@
 """Per-frame visual encoder (reference: models/vision_net.py:20-147 + torchvision resnet18).
 
-Round-1 state (BASELINE.json configs[1]: "vision on PyTorch-ROCm"): the ResNet-18 trunk runs on
-PyTorch-ROCm operators on the GPU; the temporal mean that feeds the fusion is a HIP kernel.
+Two backends for the ResNet-18 trunk + fc conv, selected by ``net.backend`` (default from the environment
+variable AVSEP_VISION_BACKEND, else "torch"): "torch" runs PyTorch-ROCm operators (BASELINE.json configs[1]:
+"vision on PyTorch-ROCm"); "hip" runs the trunk as one autograd node over libavsep_gfx950.so
+(models/vision_hip.py).  Both use the same parameter tensors.  The temporal mean that feeds the fusion is a
+HIP kernel either way.
 torchvision is not part of this image, so the standard ResNet-18 architecture is restated here
 with torchvision's child order, which keeps the reference's ``features.{0,1,4..7}.*`` /
 ``fc.*`` checkpoint keys.  ``pretrained=True`` (models/__init__.py:63) cannot be honoured
 offline: weights are PyTorch's default init unless a checkpoint is loaded.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import kernels as K
+from . import vision_hip
 
 
 class BasicBlock(nn.Module):
@@ -54,6 +60,16 @@ class _TemporalMean(torch.autograd.Function):
 
 
 class _VisualBase(nn.Module):
+    backend = os.environ.get("AVSEP_VISION_BACKEND", "torch")
+
+    def _trunk(self, x):
+        """fc(features(x)) for x [N,3,H,W]."""
+        if self.backend == "hip":
+            return vision_hip.run(self, x)
+        if self.backend != "torch":
+            raise Exception("Unknown vision backend: " + str(self.backend))
+        return self.fc(self.features(self._nhwc(x)))
+
     @staticmethod
     def _nhwc(x):
         # On the GPU the frames are handed to MIOpen channels-last: its fp32 implicit-GEMM solvers are NHWC and
@@ -61,7 +77,7 @@ class _VisualBase(nn.Module):
         return x.contiguous(memory_format=torch.channels_last) if x.is_cuda else x
 
     def forward(self, x, pool=True):
-        x = self.fc(self.features(self._nhwc(x)))
+        x = self._trunk(x)
         if not pool:
             return x.contiguous()
         if self.pool_type == "avgpool":
@@ -73,7 +89,7 @@ class _VisualBase(nn.Module):
     def forward_multiframe(self, x, pool=True):
         # vision_net.py:126-147
         B, C, T, H, W = x.shape
-        y = self.fc(self.features(self._nhwc(x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W))))
+        y = self._trunk(x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W))
         if not pool:
             if y.is_cuda:
                 return _TemporalMean.apply(y, B, T)           # [B,C,h,w]

@@ -111,15 +111,19 @@ int avsep_bn_bwd_coeffs(const double* bstats, double count, const float* gamma, 
 /* dy = p[c]*dz + q[c]*y + r[c]  (in place on dz allowed). */
 int avsep_bn_bwd_apply(const float* dz, const float* y, const float* pqr, int32_t N, int32_t C,
                        int32_t HW, float* dy, avsep_stream_t stream);
-/* z = act(scale[c]*y + shift[c]); optional residual add before the activation. */
+/* z = act(scale[c]*y + shift[c] [+ res_scale[c]*residual + res_shift[c]]): BatchNorm + residual + ReLU of a
+ * ResNet BasicBlock in one pass (the residual carries its own folded BN when it comes from a downsample conv;
+ * res_scale/res_shift NULL -> plain residual add). */
 int avsep_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
-                     int32_t act, int32_t N, int32_t C, int32_t HW, float* z, avsep_stream_t stream);
-/* Gradient through z = act(scale*y+shift [+res]):  dz_pre = act'(.)*dz (+ add);  also
- * accumulates bstats (sum dz_pre, sum dz_pre*xhat) when bstats != NULL.                  */
+                     const float* res_scale, const float* res_shift, int32_t act, int32_t N, int32_t C,
+                     int32_t HW, float* z, avsep_stream_t stream);
+/* Gradient through that z:  dz_pre = act'(pre)*dz (+ add);  also accumulates
+ * bstats (sum dz_pre, sum dz_pre*xhat(y)) when bstats != NULL.                            */
 int avsep_affine_act_bwd(const float* dz, const float* y, const float* scale, const float* shift,
-                         const float* residual, const float* add, const float* mean,
-                         const float* invstd, int32_t act, int32_t N, int32_t C, int32_t HW,
-                         float* dz_pre, double* bstats, avsep_stream_t stream);
+                         const float* residual, const float* res_scale, const float* res_shift,
+                         const float* add, const float* mean, const float* invstd, int32_t act,
+                         int32_t N, int32_t C, int32_t HW, float* dz_pre, double* bstats,
+                         avsep_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * U-Net decoder glue: ReLU + bilinear x2 (align_corners=True) of the concat
@@ -225,8 +229,9 @@ int avsep_istft(const float* mag, const float* phase, int32_t R, int32_t n_fft, 
 /* ---------------------------------------------------------------------------
  * Misc per-frame visual ops and the optimizer.
  * ------------------------------------------------------------------------- */
-int avsep_maxpool3x3s2_fwd(const float* x, int32_t NC, int32_t H, int32_t W, float* y, int32_t* idx,
-                           avsep_stream_t stream);   /* nn.MaxPool2d(3,2,1), resnet stem */
+/* nn.MaxPool2d(3,2,1) of act(scale[c]*x + shift[c]) (the ResNet stem's BN + ReLU folded in; scale NULL = plain). */
+int avsep_maxpool3x3s2_fwd(const float* x, const float* scale, const float* shift, int32_t act, int32_t C,
+                           int32_t NC, int32_t H, int32_t W, float* y, int32_t* idx, avsep_stream_t stream);
 int avsep_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int32_t NC, int32_t H, int32_t W,
                            float* dx, avsep_stream_t stream);
 /* y[b,c,hw] = mean_t x[b*T+t,c,hw]  (vision_net.py:134-135) and its transpose. */

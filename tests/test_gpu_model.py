@@ -413,3 +413,56 @@ def test_eval_path_vs_oracle(dev):
             assert np.abs(out["pred_wavs"][n, b].cpu().numpy() - wav).max() < 2e-4
             assert abs(out["si_sdr"][b, n].item() - OST.si_sdr(wav, ref)) < 1e-2
             assert abs(out["sdr"][b, n].item() - OST.sdr_plain(wav, ref)) < 1e-2
+
+
+@pytest.mark.parametrize("B,T,HW,dilate,arch", [(2, 2, 64, 16, "resnet18dilated"), (1, 3, 224, 16, "resnet18dilated"),
+                                                (2, 1, 96, 8, "resnet18dilated"), (2, 1, 64, 16, "resnet18fc")])
+def test_visual_trunk_hip_backend(dev, B, T, HW, dilate, arch):
+    """The ResNet-18 (dilated) trunk + fc conv on the HIP kernels (models/vision_hip.py) against the oracle's
+    VisualNet: features, every parameter gradient and the BatchNorm running statistics after one train-mode pass,
+    then the eval-mode features.  224x224 frames reach the halo-patch 3x3 kernels; the small cases the generic path.
+    The reference for the gradients is the oracle in float64: through 20 conv layers with tiny-batch BatchNorm a
+    single ReLU / max-pool decision flip moves the stem-side gradients by ~5e-3 of their max (measured against
+    float64: this path <= 6.4e-3, the oracle itself in float32 on the CPU <= 4.7e-2), so the bound is 1.5e-2 there,
+    while everything up to the first flip (layers 2-4, fc) agrees to ~1e-5."""
+    P = _pkg()
+    import oracle as O
+    import oracle.nets as ON
+    torch.manual_seed(5)
+    if arch == "resnet18dilated":
+        onet = ON.VisualNet(fc_dim=16, pool_type="maxpool", dilate_scale=dilate)
+        net = P.models.ResnetDilated(None, fc_dim=16, pool_type="maxpool", dilate_scale=dilate)
+    else:
+        onet = ON.VisualNet(fc_dim=16, pool_type="maxpool", dilate_scale=0)
+        net = P.models.ResnetFC(None, fc_dim=16, pool_type="maxpool")
+    assert list(net.state_dict().keys()) == list(onet.state_dict().keys())
+    net.load_state_dict(onet.state_dict())
+    net = net.to(dev)
+    net.backend = "hip"
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(B, 3, T, HW, HW, generator=gen)
+    import copy
+    o64 = copy.deepcopy(onet).double()
+    onet.train(); net.train(); o64.train()
+    yo = onet.forward_multiframe(x, pool=False)
+    cot = torch.randn(yo.shape, generator=gen)
+    y64 = o64.forward_multiframe(x.double(), pool=False)
+    (y64 * cot.double()).sum().backward()
+    y = net.forward_multiframe(x.to(dev), pool=False)
+    (y * cot.to(dev)).sum().backward()
+    assert_close(y, yo, 2e-4, "features")
+    og = dict(o64.named_parameters())
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        assert_close(p.grad, og[k].grad.float(), 1.5e-2, "grad " + k)
+    assert_close(net.fc.weight.grad, og["fc.weight"].grad.float(), 1e-4, "grad fc.weight (before any flip)")
+    ob = dict(onet.named_buffers())
+    for k, b in net.named_buffers():
+        if b.dtype.is_floating_point:
+            assert_close(b, ob[k], 1e-4, "buffer " + k)
+        else:
+            assert int(b) == int(ob[k]), k
+    onet.eval(); net.eval()
+    with torch.no_grad():
+        assert_close(net.forward_multiframe(x.to(dev), pool=True), onet.forward_multiframe(x, pool=True), 3e-4, "eval")
+        assert_close(net(x[:, :, 0].to(dev), pool=False), onet(x[:, :, 0], pool=False), 3e-4, "eval single frame")
