@@ -1,0 +1,48 @@
+"""Checkpoint files with the reference's names and keys (reference: main.py:506-533, 606-621,
+780-797).
+
+``checkpoint(nets, history, itera, args)`` writes ``{ckpt}/sound_latest.pth``, ``frame_latest.pth`` and
+``history_latest.pth`` (plain ``state_dict()``s / the history dict, loadable by the reference) and the ``*_best.pth``
+pair when ``-history['val_ao']['si_sdr'][-1]`` improves on ``args.best_err``.  The reference forgets the optimizer
+and the iteration counter, so a resumed run restarts the momentum; ``optimizer`` (a FlatSGD) adds
+``optim_latest.pth`` for that — an extra file the reference ignores.
+"""
+import os
+
+import torch
+
+
+def _cpu_state(net):
+    return {k: v.detach().cpu() for k, v in net.state_dict().items()}
+
+
+def checkpoint(nets, history, itera, args, optimizer=None):
+    print("Saving checkpoints at {} iterations.".format(itera))
+    net_sound, net_frame = nets
+    os.makedirs(args.ckpt, exist_ok=True)
+    path = lambda what, suffix: os.path.join(args.ckpt, "{}_{}".format(what, suffix))   # noqa: E731
+    torch.save(history, path("history", "latest.pth"))
+    torch.save(_cpu_state(net_sound), path("sound", "latest.pth"))
+    torch.save(_cpu_state(net_frame), path("frame", "latest.pth"))
+    if optimizer is not None:
+        torch.save({"itera": itera, "state": optimizer.state_dict()}, path("optim", "latest.pth"))
+    cur_err = -history["val_ao"]["si_sdr"][-1]
+    if cur_err < args.best_err:
+        args.best_err = cur_err
+        torch.save(_cpu_state(net_sound), path("sound", "best.pth"))
+        torch.save(_cpu_state(net_frame), path("frame", "best.pth"))
+
+
+def resume_paths(args, best=False):
+    """The weight paths the reference derives for --resume ('latest') and for eval mode ('best'), main.py:780-791."""
+    suffix = "best.pth" if best else "latest.pth"
+    return os.path.join(args.ckpt, "sound_" + suffix), os.path.join(args.ckpt, "frame_" + suffix)
+
+
+def load_optimizer(optimizer, args):
+    p = os.path.join(args.ckpt, "optim_latest.pth")
+    if not os.path.exists(p):
+        return 0
+    blob = torch.load(p, map_location="cpu")
+    optimizer.load_state_dict(blob["state"])
+    return int(blob["itera"])

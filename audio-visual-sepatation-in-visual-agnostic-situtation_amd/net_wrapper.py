@@ -212,6 +212,19 @@ class FlatSGD:
                 gv.copy_(p.grad)
             p.grad = gv
 
+    def state_dict(self):
+        """Momentum buffers + per-group lr / started flags (what torch.optim.SGD.state_dict carries, flat)."""
+        return {"momentum_buffer": self.flat_buf.detach().cpu(),
+                "groups": [{"name": g["name"], "lr": g["lr"], "started": bool(g.get("started", False)),
+                            "range": list(g["range"])} for g in self.param_groups]}
+
+    def load_state_dict(self, state):
+        if [g["range"] for g in state["groups"]] != [list(g["range"]) for g in self.param_groups]:
+            raise ValueError("optimizer state does not match the parameter groups")
+        self.flat_buf.copy_(state["momentum_buffer"])
+        for g, s in zip(self.param_groups, state["groups"]):
+            g["lr"], g["started"] = s["lr"], s["started"]
+
     def step(self, only=None):
         """`only`: names of the groups that took part in this step's graph.  torch.optim.SGD skips a
         parameter whose .grad is None (no weight decay, no momentum update); with the reference's

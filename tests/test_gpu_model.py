@@ -466,3 +466,82 @@ def test_visual_trunk_hip_backend(dev, B, T, HW, dilate, arch):
     with torch.no_grad():
         assert_close(net.forward_multiframe(x.to(dev), pool=True), onet.forward_multiframe(x, pool=True), 3e-4, "eval")
         assert_close(net(x[:, :, 0].to(dev), pool=False), onet(x[:, :, 0], pool=False), 3e-4, "eval single frame")
+
+
+@pytest.mark.parametrize("ftype", ["hidsep", "MixVis"])
+def test_inference_wrapper_vs_oracle(dev, ftype):
+    """inference.py:29-160: AO, AV (two single frames, 5-D clips cut to the first frame), duet (one frame list, no
+    img_activation) and MixVis forwards of the inference wrapper against the oracle restatement; eval-mode nets."""
+    P = _pkg()
+    from oracle import nets as O, inference as OI
+    torch.manual_seed(3)
+    gen = torch.Generator().manual_seed(3)
+    osnd = O.Unet(fc_dim=2, num_downs=5, ngf=8, fusion_type=ftype, att_type="sig")
+    O.wide_init(osnd, gen)
+    ofrm = O.VisualNet(fc_dim=32, pool_type="maxpool", dilate_scale=16)
+    snd = P.models.Unet(fc_dim=2, num_downs=5, ngf=8, fusion_type=ftype, att_type="sig")
+    frm = P.models.ResnetDilated(None, fc_dim=32, pool_type="maxpool")
+    snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict())
+    snd, frm = snd.to(dev).eval(), frm.to(dev).eval()
+    osnd.eval(); ofrm.eval()
+    args = _args(fusion_type=ftype)
+    wrap = P.inference.NetWrapper((snd, frm))
+    mag = torch.rand(2, 1, 128, 64, generator=gen) ** 2
+    phase = torch.rand(2, 1, 128, 64, generator=gen)
+    clips = [torch.randn(2, 3, 2, 64, 64, generator=gen) for _ in range(2)]
+
+    def cmp(out, ref, keys):
+        for n in range(2):
+            assert_close(out["pred_masks"][n], ref["pred_masks"][n], 3e-4, f"mask {n}")
+        assert_close(out["mag_mix"], ref["mag_mix"], 1e-5, "warped mixture")
+        for k in keys:
+            assert_close(out[k], ref[k], 3e-4, k)
+    with torch.no_grad():
+        if ftype == "MixVis":
+            out = wrap((mag.to(dev), phase.to(dev)), [c.to(dev) for c in clips], args, True)
+            cmp(out, OI.forward((osnd, ofrm), (mag, phase), [c.clone() for c in clips], args, True), ["maps"])
+            return
+        snd.ao_draws = osnd.levels()[-1].fusion.ao_draws = torch.tensor([True, False])
+        out = wrap((mag.to(dev), phase.to(dev)), None, args, False)
+        cmp(out, OI.forward((osnd, ofrm), (mag, phase), None, args, False), [])
+        assert out["phase_mix"].shape == phase.shape
+        out = wrap((mag.to(dev), phase.to(dev)), [c.to(dev) for c in clips], args, True)
+        cmp(out, OI.forward((osnd, ofrm), (mag, phase), [c.clone() for c in clips], args, True), ["maps", "match_loss"])
+        duet = [torch.randn(2, 3, 64, 128, generator=gen)]
+        out = wrap((mag.to(dev), phase.to(dev)), [duet[0].to(dev)], args, True)
+        cmp(out, OI.forward((osnd, ofrm), (mag, phase), duet, args, True), ["maps", "match_loss"])
+
+
+def test_checkpoint_resume_on_gpu(dev, tmp_path):
+    """checkpoint() -> rebuild through ModelBuilder(weights=...) + optimizer state: the resumed run takes the same
+    next step as the uninterrupted one (the reference drops the momentum; optim_latest.pth is this build's extra)."""
+    P = _pkg()
+    a = _args()
+    a.ckpt, a.best_err = str(tmp_path), float("inf")
+    mb = P.ModelBuilder()
+
+    def make(ws="", wf=""):
+        torch.manual_seed(11)
+        snd = mb.build_sound(arch="unet5", fc_dim=2, weights=ws, fusion_type="hidsep", att_type="sig").to(dev)
+        frm = mb.build_frame(arch="resnet18dilated", fc_dim=256, pool_type="maxpool", weights=wf).to(dev)
+        wrap = P.NetWrapper((snd, frm), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
+        return snd, frm, wrap, P.create_optimizer((snd, frm), a)
+    gen = torch.Generator().manual_seed(2)
+    srcs = [torch.rand(2, 1, 64, 64, generator=gen) ** 2 for _ in range(2)]
+    frames = [torch.randn(2, 3, 1, 64, 64, generator=gen) for _ in range(2)]
+
+    def batch():
+        return {"mag_mix": (srcs[0] + srcs[1]).to(dev), "mags": [s.clone().to(dev) for s in srcs],
+                "frames": [f.to(dev) for f in frames]}
+    snd, frm, wrap, opt = make()
+    for _ in range(2):
+        P.train_step(wrap, batch(), opt, True, a)
+    P.checkpoint.checkpoint((snd, frm), {"val_ao": {"si_sdr": [1.5]}}, 2, a, optimizer=opt)
+    e3, _ = P.train_step(wrap, batch(), opt, True, a)
+    ws, wf = P.checkpoint.resume_paths(a)
+    snd2, frm2, wrap2, opt2 = make(ws, wf)
+    assert P.checkpoint.load_optimizer(opt2, a) == 2
+    e3b, _ = P.train_step(wrap2, batch(), opt2, True, a)
+    assert abs(e3 - e3b) < 1e-6, (e3, e3b)
+    for (k, p), (_, q) in zip(snd.named_parameters(), snd2.named_parameters()):
+        assert_close(q, p, 1e-4, k)     # atomics-order noise only (a dropped momentum buffer shows as ~1e-1)

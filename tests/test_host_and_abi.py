@@ -101,3 +101,33 @@ def test_synth_batch_contract():
     assert b["audios"][0].abs().max() <= 0.5 + 1e-6                 # clipped to +-1 then divided by N=2
     b2 = P.synth.make_batch(2, 2, 3, 32, aud_len=4096, seed=7)
     assert torch.equal(b["audio_mix"], b2["audio_mix"])
+
+
+def test_checkpoint_files_match_the_reference_names(tmp_path):
+    """main.py:506-533: sound_/frame_/history_ latest + best files, plain state_dicts with the reference's keys;
+    the oracle nets (reference key names, pinned by the goldens) load them strictly."""
+    import argparse
+    import os
+    import torch
+    import avsep_amd as P
+    from oracle import nets as O
+    mb = P.ModelBuilder()
+    snd = mb.build_sound(arch="unet5", fc_dim=2, fusion_type="hidsep", att_type="sig")
+    frm = mb.build_frame(arch="resnet18dilated", fc_dim=16, pool_type="maxpool")
+    a = argparse.Namespace(ckpt=str(tmp_path / "ck"), best_err=float("inf"))
+    hist = {"val_ao": {"si_sdr": [2.0]}}
+    P.checkpoint.checkpoint((snd, frm), hist, 10, a)
+    names = sorted(os.listdir(a.ckpt))
+    assert names == ["frame_best.pth", "frame_latest.pth", "history_latest.pth", "sound_best.pth", "sound_latest.pth"]
+    assert a.best_err == -2.0
+    hist["val_ao"]["si_sdr"].append(1.0)                      # worse: best files untouched
+    before = os.path.getmtime(os.path.join(a.ckpt, "sound_best.pth"))
+    P.checkpoint.checkpoint((snd, frm), hist, 20, a)
+    assert os.path.getmtime(os.path.join(a.ckpt, "sound_best.pth")) == before and a.best_err == -2.0
+    osnd = O.Unet(fc_dim=2, num_downs=5, ngf=64, fusion_type="hidsep", att_type="sig")
+    ofrm = O.VisualNet(fc_dim=16, pool_type="maxpool", dilate_scale=16)
+    osnd.load_state_dict(torch.load(os.path.join(a.ckpt, "sound_latest.pth")), strict=True)
+    ofrm.load_state_dict(torch.load(os.path.join(a.ckpt, "frame_latest.pth")), strict=True)
+    assert torch.load(os.path.join(a.ckpt, "history_latest.pth")) == hist
+    assert P.checkpoint.resume_paths(a, best=True) == (os.path.join(a.ckpt, "sound_best.pth"),
+                                                         os.path.join(a.ckpt, "frame_best.pth"))
