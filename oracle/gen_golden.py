@@ -440,10 +440,80 @@ def gen_sopp(ref_main, att, saud):
     save("sopp", out)
 
 
+def synthetic_raw_audio(path, center_t, n):
+    """Deterministic stand-in for librosa.load in the dataset fixture (consumes nothing from `random`)."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(("%s|%.6f" % (path, center_t)).encode()) & 0x7fffffff)
+    return (rs.rand(n).astype(np.float32) - 0.5) * 2.4          # exceeds +-1 so the clip matters
+
+
+def gen_dataset(ref_main):
+    """The reference's MUSICMixDataset (dataset/music.py, dataset/base.py) on a synthetic 6-column list: which clips,
+    centre times, gains (through an audio checksum), frame files, ids and labels it draws per index.  Decoding is
+    replaced on both sides by `synthetic_raw_audio` / the list of frame paths, so only the sampling rules are pinned."""
+    import json
+    import random
+    from dataset import MUSICMixDataset as RefDS
+    from avsep_amd import dataset as PD
+    from avsep_amd.arguments import ArgParser
+    rs = random.Random(77)
+    rows = []
+    for c in PD.MUSIC11_CLASSES:
+        for k in range(3):
+            vid = "".join(rs.choice("abcdefghijklmnopqrstuvwxyzABCDEFGH0123456789_-") for _ in range(11))
+            fps = rs.choice([24.0, 25.0, 29.97, 30.0])
+            secs = round(rs.uniform(9.0, 240.0), 3)
+            nf = int(secs * fps) - rs.randint(0, 40)
+            rows.append([f"./data/audio/{c}/{vid}.wav", f"./data/frames/{c}/{vid}.mp4", str(nf), str(fps), str(secs), c])
+    os.makedirs(OUT, exist_ok=True)
+    lst = os.path.join(OUT, "dataset_list.csv")
+    with open(lst, "w") as f:
+        f.write("\n".join(",".join(r) for r in rows) + "\n\nshort\n")     # + rows the reader must skip
+    cases = []
+    for split, extra, kw in [("train", [], {}), ("val", [], {}), ("train", ["--one_frame"], {"seed": 10}),
+                             ("train", ["--rate_dc", "0.3", "--rate_sc", "0.4", "--rate_sv", "1.0"], {}),
+                             ("val", [], {"random_sample": True})]:
+        argv = ["--num_frames", "3", "--stride_frames", "8", "--train_repeat", "2", "--val_repeat", "3"] + extra
+        a = ArgParser().parse_train_arguments(argv)
+        params = vars(a)
+
+        class Ref(RefDS):
+            def _load_audio_file(self, path, center_t):
+                n = int((self.margin * 2 + self.audSec) * self.audRate)
+                return synthetic_raw_audio(path, center_t, n), self.audRate
+
+            def _load_frames(self, paths):
+                self.seen.append(list(paths))
+                return torch.zeros(1)
+
+        class Mine(PD.MUSICMixDataset):
+            _load_audio_file = Ref._load_audio_file
+            _load_frames = Ref._load_frames
+        ref, mine = Ref(lst, dict(params), split=split, **kw), Mine(lst, dict(params), split=split, **kw)
+        assert ref.list_samples == mine.list_samples and len(ref) == len(mine)
+        items = []
+        for index in [0, 1, 5, len(ref) // 2, len(ref) - 1]:
+            ref.seen, mine.seen = [], []
+            r, m = ref[index], mine[index]
+            rec = {"index": index, "infos": [list(i) for i in r["infos"]], "id": r["id"], "class": r["class"].tolist(),
+                   "frame_paths": ref.seen, "audio_sum": [float(a.double().sum()) for a in r["audios"]],
+                   "audio_abs": [float(a.double().abs().sum()) for a in r["audios"]],
+                   "mix_abs": float(r["audio_mix"].double().abs().sum())}
+            assert [list(i) for i in m["infos"]] == rec["infos"] and m["id"] == rec["id"] and mine.seen == ref.seen
+            for x, y in zip(m["audios"] + [m["audio_mix"]], r["audios"] + [r["audio_mix"]]):
+                assert torch.equal(x, torch.as_tensor(y))
+            items.append(rec)
+        cases.append({"split": split, "argv": argv, "kw": kw, "len": len(ref), "first_rows": ref.list_samples[:3],
+                      "items": items})
+    with open(os.path.join(OUT, "dataset.json"), "w") as f:
+        json.dump({"cases": cases}, f, indent=0)
+    print("wrote dataset.json + dataset_list.csv (%d cases)" % len(cases))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ref_main, att, saud = import_reference()
-    which = sys.argv[1:] or ["prepare", "fusion", "unet", "criterion", "synth", "step", "sopp"]
+    which = sys.argv[1:] or ["prepare", "fusion", "unet", "criterion", "synth", "step", "sopp", "dataset"]
     for w in which:
         fn = globals()["gen_" + w]
         fn(ref_main, att, saud) if w == "sopp" else fn(ref_main)
