@@ -536,6 +536,12 @@ bool smallco_applicable(const avsep_conv_desc* d);
 int smallco_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* bias, float* y, hipStream_t st);
 size_t smallco_wgrad_workspace_floats(const avsep_conv_desc* d);
 int smallco_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st);
+bool head_applicable(const avsep_conv_desc* d);
+int head_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* bias, float* y, hipStream_t st);
+size_t head_wgrad_workspace_floats(const avsep_conv_desc* d);
+int head_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st);
+int head_dgrad(const avsep_conv_desc* d, const float* w, const float* dy, float* g0, float* g1, const float* mean1,
+               const float* invstd1, double* bstats1, int acc0, hipStream_t st);
 bool smallci_applicable(const avsep_conv_desc* d);
 int smallci_dgrad(const avsep_conv_desc* d, const float* w_oihw, const float* dy, float* dx, hipStream_t st);
 // conv3x3.hip: LDS-halo-patch kernel for 3x3 / stride 1 / pad 1 (forward, and dgrad through flipped weights)
@@ -629,7 +635,7 @@ static SplitPlan splitk_plan(long long tiles, int K) {
   return p;
 }
 static bool fwd_uses_igemm(const avsep_conv_desc* d, const double* stats) {
-  return !((!stats && smallco_applicable(d)) || c3_applicable(d, 0));
+  return !((!stats && (smallco_applicable(d) || head_applicable(d))) || c3_applicable(d, 0));
 }
 static SplitPlan fwd_split(const avsep_conv_desc* d) {
   long long ncols = (long long)d->N * d->Ho * d->Wo;
@@ -663,6 +669,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   if (rc) return rc;
   if (!w_packed || !y) return AVSEP_ERR_ARG;
   if (!stats && smallco_applicable(d)) return smallco_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
+  if (!stats && head_applicable(d)) return head_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
   if (c3_applicable(d, 0)) return c3_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.wp = w_packed; a.wp_ld = packed_ld(d, 0); a.out = y; a.bias = bias; a.stats = stats;
@@ -764,6 +771,7 @@ static WgradPlan wgrad_plan(const avsep_conv_desc* d) {
 extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (check_desc(d)) return 0;
   if (smallco_applicable(d)) return smallco_wgrad_workspace_floats(d) * sizeof(float);
+  if (head_applicable(d)) return head_wgrad_workspace_floats(d) * sizeof(float);
   if (w3_applicable(d)) return w3_workspace_floats(d) * sizeof(float);
   WgradPlan p = wgrad_plan(d);
   if (p.splits <= 1) return 0;
@@ -779,6 +787,7 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   size_t need = avsep_conv2d_wgrad_workspace_bytes(d);
   if (need > workspace_bytes || (need && !workspace)) return AVSEP_ERR_WORKSPACE;
   if (smallco_applicable(d)) return smallco_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
+  if (head_applicable(d)) return head_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
   if (w3_applicable(d)) {
     int rc3 = w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
     if (rc3) return rc3;
@@ -817,4 +826,22 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
     AVSEP_LAUNCH_CHECK();
   }
   return AVSEP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fused decoder head (head.hip): dgrad of a conv over the virtual up2x(relu(affine(cat))) input, taken straight to
+// the two low-res sources
+// ---------------------------------------------------------------------------
+extern "C" int32_t avsep_conv2d_head_applicable(const avsep_conv_desc* d) {
+  return (check_desc(d) == AVSEP_OK && head_applicable(d)) ? 1 : 0;
+}
+extern "C" int avsep_conv2d_dgrad_up2x(const avsep_conv_desc* d, const float* w, const float* dy, float* g0, float* g1,
+                                       const float* mean1, const float* invstd1, double* bstats1, int32_t acc0,
+                                       avsep_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!w || !dy || (!g0 && !g1)) return AVSEP_ERR_ARG;
+  if (bstats1 && (!mean1 || !invstd1 || !g1)) return AVSEP_ERR_ARG;
+  if (!head_applicable(d)) return AVSEP_ERR_ARG;   // unsupported geometry: use avsep_conv2d_dgrad + avsep_relu_up2x_bwd
+  return head_dgrad(d, w, dy, g0, g1, mean1, invstd1, bstats1, acc0, (hipStream_t)stream);
 }

@@ -1,0 +1,450 @@
+// Fused decoder head: the U-Net's outermost up path (audio_net.py:72-76: ReLU -> bilinear x2 (align_corners) ->
+// conv 3x3 p1 -> num_mix logits) on the concat of the skip tensor and the inner block's BatchNorm'd output.
+//
+// The hi-res input U = up2x(relu(affine(cat(x0, x1)))) has 128 channels at 256x256 (33.5 MB per sample) but feeds
+// only <= 4 output channels: materialising it costs a 1 GB write + two 1 GB reads per pass at batch 32, and its
+// gradient the same again.  These three kernels never materialise U or dU: every wave rebuilds the rows of U it
+// needs from the LOW-RES sources in registers while it sweeps down the image.
+//
+// Register layout (no LDS, no barriers in the sweeps): lane q owns low-res columns 2q, 2q+1 = hi-res columns
+// 4q..4q+3 (W <= 256 fits one wave).  Because the x2 align_corners map is monotone with slope < 1/2, hi-res column
+// 4q+j always interpolates a STATIC pair of the four low-res values L0..L3 = columns 2q-1..2q+2:
+//   j=-1,0 -> (L0,L1)   j=1,2 -> (L1,L2)   j=3,4 -> (L2,L3)          (same for rows: 2r+1, 2r+2 -> (r, r+1))
+// so a lane builds the six hi-res columns 4q-1..4q+4 (its 3x3 halo included) from its own float2 plus one value
+// from each neighbour lane, with per-lane constant coefficients.  M = Cout <= 4 is far too small for an MFMA
+// tile: the FMAs run on the vector ALU, weights come through the scalar unit (wave-uniform addresses).
+#include "common.h"
+
+#define HD_MAXCO 4
+
+struct HeadArgs {
+  const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
+  int N, C0, C1, Hl, Wl;   // low-res geometry; hi-res is 2*Hl x 2*Wl
+  float rh, rw;            // (L-1)/(2L-1) per axis
+};
+
+// Coefficients of hi-res index o (axis of low-res length L, ratio r) on the static low-res pair (lo, lo+1).
+// The reference value is (1-l)*v[i0] + l*v[i1] with i0 = floor(r*o), i1 = min(i0+1, L-1) (float arithmetic as in
+// the unfused kernels); a term that falls outside the pair (only possible with weight ~0 from float rounding at the
+// last index) is dropped.  o outside [0, 2L) is the conv's zero padding: both coefficients 0.
+__device__ __forceinline__ void lerp_pair(int o, int lo, int L, float r, float& ca, float& cb) {
+  const float f = r * (float)o;
+  const int i0 = (int)f;
+  const float l = f - (float)i0;
+  const int i1 = i0 + (i0 < L - 1);
+  const bool in = o >= 0 && o < 2 * L;
+  ca = in ? ((i0 == lo ? 1.f - l : 0.f) + (i1 == lo ? l : 0.f)) : 0.f;
+  cb = in ? ((i0 == lo + 1 ? 1.f - l : 0.f) + (i1 == lo + 1 ? l : 0.f)) : 0.f;
+}
+
+// column coefficients of hi-res columns 4q-1+k (k = 0..5) on their static pair; plain register arrays
+#define HEAD_LANE_COEFFS(a, lane, ca, cb)                                                          \
+  float ca[6], cb[6];                                                                              \
+  _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) {                                              \
+    float ca_, cb_;                                                                                \
+    lerp_pair(4 * (lane) - 1 + k_, 2 * (lane) - 1 + (k_ >> 1), (a).Wl, (a).rw, ca_, cb_);         \
+    ca[k_] = ca_; cb[k_] = cb_;                                                                    \
+  }
+
+// Horizontally interpolated low-res row r of one channel plane: Hout[k] = hi-res column 4q-1+k (before the row lerp).
+__device__ __forceinline__ void head_hrow(const float* __restrict__ plane, int r, int Hl, int Wl, bool active,
+                                          const float (&ca)[6], const float (&cb)[6], float scv, float shv, int lane,
+                                          float (&Hout)[6]) {
+  float l1 = 0.f, l2 = 0.f;
+  if (active && r >= 0 && r < Hl) {
+    const float2 v = *reinterpret_cast<const float2*>(plane + (long long)r * Wl + 2 * lane);
+    l1 = fmaxf(fmaf(v.x, scv, shv), 0.f);
+    l2 = fmaxf(fmaf(v.y, scv, shv), 0.f);
+  }
+  float l0 = __shfl_up(l2, 1, 64), l3 = __shfl_down(l1, 1, 64);
+  if (lane == 0) l0 = 0.f;
+  if (lane == 63) l3 = 0.f;                       // (an inactive neighbour already holds 0)
+  Hout[0] = ca[0] * l0 + cb[0] * l1;
+  Hout[1] = ca[1] * l0 + cb[1] * l1;
+  Hout[2] = ca[2] * l1 + cb[2] * l2;
+  Hout[3] = ca[3] * l1 + cb[3] * l2;
+  Hout[4] = ca[4] * l2 + cb[4] * l3;
+  Hout[5] = ca[5] * l2 + cb[5] * l3;
+}
+
+struct HeadChan { const float* plane; float scv, shv; bool first; int cs; };
+__device__ __forceinline__ HeadChan head_chan(const HeadArgs& a, int n, int c) {
+  HeadChan h;
+  h.first = c < a.C0;
+  h.cs = h.first ? c : c - a.C0;
+  const float* sc = h.first ? a.sc0 : a.sc1;
+  const float* sh = h.first ? a.sh0 : a.sh1;
+  h.scv = sc ? sc[h.cs] : 1.f;
+  h.shv = sc ? sh[h.cs] : 0.f;
+  h.plane = (h.first ? a.x0 + ((long long)n * a.C0 + h.cs) * a.Hl * a.Wl
+                     : a.x1 + ((long long)n * a.C1 + h.cs) * a.Hl * a.Wl);
+  return h;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: y[n,co,h,w] = bias[co] + sum_{c,kh,kw} w[co,c,kh,kw] * U[n,c,h+kh-1,w+kw-1]
+// block = R hi-res rows of one image; its 4 waves split the channels and are summed through LDS at the end.
+// ---------------------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256, 4) void head_fwd_kernel(HeadArgs a, const float* __restrict__ wp, int wp_ld,
+                                                       const float* __restrict__ bias, float* __restrict__ y) {
+  constexpr int R = COUT <= 2 ? 4 : 2, NACC = R * 4 * COUT, NU = R + 2;
+  __shared__ float red[2][NACC][64];
+  __shared__ float rwa[NU], rwb[NU];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.y, g = blockIdx.x;
+  const int H = 2 * a.Hl, W = 2 * a.Wl, C = a.C0 + a.C1;
+  const bool active = 2 * lane < a.Wl;
+  HEAD_LANE_COEFFS(a, lane, ca, cb)
+  const int r_first = (R * g) / 2 - 1;                    // U row R*g-1 = 2*r_first+1
+  if (threadIdx.x < NU) {
+    const int u = threadIdx.x;
+    lerp_pair(R * g - 1 + u, r_first + (u >> 1), a.Hl, a.rh, rwa[u], rwb[u]);
+  }
+  __syncthreads();
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+  const int cper = (C + 3) / 4, c_end = min(C, (wave + 1) * cper);
+  for (int c = wave * cper; c < c_end; ++c) {
+    const HeadChan ch = head_chan(a, n, c);
+    float wv[COUT][9];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wv[co][t] = wp[(long long)(c * 9 + t) * wp_ld + co];
+    float Hp[6], Hc[6];
+    head_hrow(ch.plane, r_first, a.Hl, a.Wl, active, ca, cb, ch.scv, ch.shv, lane, Hp);
+#pragma unroll
+    for (int p = 0; p < NU / 2; ++p) {
+      head_hrow(ch.plane, r_first + 1 + p, a.Hl, a.Wl, active, ca, cb, ch.scv, ch.shv, lane, Hc);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int u = 2 * p + i;
+        const float wa = rwa[u], wb = rwb[u];
+        float U[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) U[k] = wa * Hp[k] + wb * Hc[k];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int r = u - kh;                           // output row R*g + r reads U row u through tap kh
+          if (r >= 0 && r < R) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+                  acc[(r * 4 + px) * COUT + co] = fmaf(wv[co][kh * 3 + kw], U[px + kw], acc[(r * 4 + px) * COUT + co]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Hp[k] = Hc[k];
+    }
+  }
+  // 4 -> 2 -> 1 waves
+  if (wave >= 2) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) red[wave - 2][i][lane] = acc[i];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] += red[wave][i][lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) red[0][i][lane] = acc[i];
+  }
+  __syncthreads();
+  if (wave == 0 && active) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int h = R * g + r;
+      if (h < H) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          const float b = bias ? bias[co] : 0.f;
+          f32x4 o;
+          o.x = acc[(r * 4 + 0) * COUT + co] + red[0][(r * 4 + 0) * COUT + co][lane] + b;
+          o.y = acc[(r * 4 + 1) * COUT + co] + red[0][(r * 4 + 1) * COUT + co][lane] + b;
+          o.z = acc[(r * 4 + 2) * COUT + co] + red[0][(r * 4 + 2) * COUT + co][lane] + b;
+          o.w = acc[(r * 4 + 3) * COUT + co] + red[0][(r * 4 + 3) * COUT + co][lane] + b;
+          *reinterpret_cast<f32x4*>(y + (((long long)n * COUT + co) * H + h) * W + 4 * lane) = o;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient: dw[co,c,kh,kw] = sum_{n,h,w} dy[n,co,h,w] * U[n,c,h+kh-1,w+kw-1]   (+ dbias = sum dy)
+// wave = (channel c, image n, segment of SR hi-res output rows); a rolling window of three dy rows meets each
+// rebuilt U row; 9*COUT accumulators per lane, wave-reduced into one partial slab per (n, segment).
+// ---------------------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256, 3) void head_wgrad_kernel(HeadArgs a, const float* __restrict__ dy,
+                                                         float* __restrict__ part, float* __restrict__ bpart, int S) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int C = a.C0 + a.C1, c = blockIdx.x * 4 + wave, n = blockIdx.y, seg = blockIdx.z;
+  if (c >= C) return;
+  const int H = 2 * a.Hl, W = 2 * a.Wl, SR = H / S, s0 = seg * SR, s1 = s0 + SR;
+  const bool active = 2 * lane < a.Wl;
+  HEAD_LANE_COEFFS(a, lane, ca, cb)
+  const HeadChan ch = head_chan(a, n, c);
+  float acc[COUT][9], bacc[COUT];
+  f32x4 Dm[COUT], D0[COUT], Dp[COUT];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    bacc[co] = 0.f;
+    Dm[co] = zero4; D0[co] = zero4;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[co][t] = 0.f;
+  }
+  auto load_dy = [&](int h, f32x4 (&D)[COUT]) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      D[co] = zero4;
+      if (active && h >= s0 && h < s1)
+        D[co] = *reinterpret_cast<const f32x4*>(dy + (((long long)n * COUT + co) * H + h) * W + 4 * lane);
+      bacc[co] += (D[co].x + D[co].y) + (D[co].z + D[co].w);
+    }
+  };
+  load_dy(s0, Dp);
+  int r = s0 / 2 - 1;
+  float Hp[6], Hc[6];
+  head_hrow(ch.plane, r, a.Hl, a.Wl, active, ca, cb, ch.scv, ch.shv, lane, Hp);
+  for (int p = 0; p <= SR / 2; ++p, ++r) {                 // pair (r, r+1) -> U rows 2r+1, 2r+2
+    head_hrow(ch.plane, r + 1, a.Hl, a.Wl, active, ca, cb, ch.scv, ch.shv, lane, Hc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ho = 2 * r + 1 + i;
+      float wa, wb;
+      lerp_pair(ho, r, a.Hl, a.rh, wa, wb);
+      float U[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) U[k] = wa * Hp[k] + wb * Hc[k];
+#pragma unroll
+      for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          // tap kh pairs U row ho with output row ho+1-kh: kh=0 -> Dp, 1 -> D0, 2 -> Dm
+          acc[co][kw] += (Dp[co].x * U[kw] + Dp[co].y * U[kw + 1]) + (Dp[co].z * U[kw + 2] + Dp[co].w * U[kw + 3]);
+          acc[co][3 + kw] += (D0[co].x * U[kw] + D0[co].y * U[kw + 1]) + (D0[co].z * U[kw + 2] + D0[co].w * U[kw + 3]);
+          acc[co][6 + kw] += (Dm[co].x * U[kw] + Dm[co].y * U[kw + 1]) + (Dm[co].z * U[kw + 2] + Dm[co].w * U[kw + 3]);
+        }
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) { Dm[co] = D0[co]; D0[co] = Dp[co]; }
+      load_dy(ho + 2, Dp);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Hp[k] = Hc[k];
+  }
+  const long long slab = ((long long)n * S + seg) * COUT * C * 9;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float v = wave_sum(acc[co][t]);
+      if (lane == 0) part[slab + ((long long)co * C + c) * 9 + t] = v;
+    }
+  if (bpart && c == 0) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      const float v = wave_sum(bacc[co]);
+      if (lane == 0) bpart[((long long)n * S + seg) * COUT + co] = v;
+    }
+  }
+}
+
+__global__ void head_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < S; ++z) s += part[(long long)z * n + i];
+  out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// data gradient straight to the low-res sources:
+//   dU[c,ho,wo] = sum_{co,kh,kw} w[co,c,kh,kw] * dy[co,ho+1-kh,wo+1-kw]
+//   g[c,r,x]    = relu'(affine(src[c,r,x])) * sum_{ho,wo} rowcoef(ho,r) * colcoef(wo,x) * dU[c,ho,wo]
+// wave = (channel c, image n, segment of low-res rows).  A lane forms dU at the six hi-res columns 4q-1..4q+4 that
+// touch its own two low-res columns (no cross-lane scatter) from a rolling 3-row window of dy (8 columns wide).
+// Source-1 channels also reduce the BatchNorm-backward sums (sum g, sum g*xhat) like relu_up2x_bwd.
+// ---------------------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256, 3) void head_dgrad_kernel(HeadArgs a, const float* __restrict__ w,
+                                                         const float* __restrict__ dy, float* __restrict__ g0,
+                                                         float* __restrict__ g1, const float* __restrict__ mean1,
+                                                         const float* __restrict__ invstd1, double* bstats1, int acc0,
+                                                         int S) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int C = a.C0 + a.C1, c = blockIdx.x * 4 + wave, n = blockIdx.y, seg = blockIdx.z;
+  if (c >= C) return;
+  const int H = 2 * a.Hl, W = 2 * a.Wl, RL = a.Hl / S, r0 = seg * RL, r1 = r0 + RL;
+  const bool active = 2 * lane < a.Wl;
+  HEAD_LANE_COEFFS(a, lane, ca, cb)
+  const HeadChan ch = head_chan(a, n, c);
+  float* g = ch.first ? g0 : g1;
+  if (!g) return;
+  const bool stats = !ch.first && bstats1;
+  const float mu = stats ? mean1[ch.cs] : 0.f, is = stats ? invstd1[ch.cs] : 1.f;
+  float wv[COUT][9];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[co][t] = w[((long long)co * C + c) * 9 + t];
+  float Em[COUT][8], E0[COUT][8], Ep[COUT][8];
+  auto load_e = [&](int h, float (&E)[COUT][8]) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) E[co][e] = 0.f;
+      if (active && h >= 0 && h < H) {
+        const float* row = dy + (((long long)n * COUT + co) * H + h) * W + 4 * lane;
+        const f32x4 m = *reinterpret_cast<const f32x4*>(row);
+        E[co][2] = m.x; E[co][3] = m.y; E[co][4] = m.z; E[co][5] = m.w;
+        if (lane > 0) { const float2 l = *reinterpret_cast<const float2*>(row - 2); E[co][0] = l.x; E[co][1] = l.y; }
+        if (4 * lane + 4 < W) { const float2 h2 = *reinterpret_cast<const float2*>(row + 4); E[co][6] = h2.x; E[co][7] = h2.y; }
+      }
+    }
+  };
+  load_e(2 * r0 - 2, Em);
+  load_e(2 * r0 - 1, E0);
+  load_e(2 * r0, Ep);
+  float Glo[2] = {0.f, 0.f}, Ghi[2] = {0.f, 0.f}, s1 = 0.f, s2 = 0.f;
+  const long long HWl = (long long)a.Hl * a.Wl;
+  const long long pbase = ((long long)n * (ch.first ? a.C0 : a.C1) + ch.cs) * HWl;
+  for (int r = r0 - 1; r < r1; ++r) {                      // pair (r, r+1) <- U rows 2r+1, 2r+2
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ho = 2 * r + 1 + i;
+      float wa, wb;
+      lerp_pair(ho, r, a.Hl, a.rh, wa, wb);
+      float dU[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        float v = 0.f;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            v = fmaf(wv[co][kw], Ep[co][k - kw + 2], v);        // kh = 0 <- dy row ho+1
+            v = fmaf(wv[co][3 + kw], E0[co][k - kw + 2], v);    // kh = 1 <- dy row ho
+            v = fmaf(wv[co][6 + kw], Em[co][k - kw + 2], v);    // kh = 2 <- dy row ho-1
+          }
+        dU[k] = v;
+      }
+      const float T0 = (cb[0] * dU[0] + cb[1] * dU[1]) + (ca[2] * dU[2] + ca[3] * dU[3]);   // low-res column 2q
+      const float T1 = (cb[2] * dU[2] + cb[3] * dU[3]) + (ca[4] * dU[4] + ca[5] * dU[5]);   // low-res column 2q+1
+      Glo[0] = fmaf(wa, T0, Glo[0]); Glo[1] = fmaf(wa, T1, Glo[1]);
+      Ghi[0] = fmaf(wb, T0, Ghi[0]); Ghi[1] = fmaf(wb, T1, Ghi[1]);
+#pragma unroll
+      for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { Em[co][e] = E0[co][e]; E0[co][e] = Ep[co][e]; }
+      load_e(ho + 2, Ep);
+    }
+    if (r >= r0 && active) {                             // low-res row r has received both of its pairs
+      const long long o = pbase + (long long)r * a.Wl + 2 * lane;
+      const float2 v = *reinterpret_cast<const float2*>((ch.first ? a.x0 : a.x1) + o);
+      float gx = fmaf(v.x, ch.scv, ch.shv) > 0.f ? Glo[0] : 0.f;
+      float gy = fmaf(v.y, ch.scv, ch.shv) > 0.f ? Glo[1] : 0.f;
+      s1 += gx + gy;
+      s2 += gx * (v.x - mu) * is + gy * (v.y - mu) * is;
+      float2* dst = reinterpret_cast<float2*>(g + o);
+      if (acc0 && ch.first) { const float2 old = *dst; gx += old.x; gy += old.y; }
+      *dst = make_float2(gx, gy);
+    }
+    Glo[0] = Ghi[0]; Glo[1] = Ghi[1]; Ghi[0] = 0.f; Ghi[1] = 0.f;
+  }
+  if (stats) {
+    const double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+    if (lane == 0) {
+      atomicAdd(&bstats1[ch.cs], d1);
+      atomicAdd(&bstats1[a.C1 + ch.cs], d2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side (called from conv.hip)
+// ---------------------------------------------------------------------------------------------------------------
+bool head_applicable(const avsep_conv_desc* d) {
+  return d->up2x && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->Cout <= HD_MAXCO &&
+         d->act0 == AVSEP_ACT_RELU && (d->C0 == d->Cin || d->act1 == AVSEP_ACT_RELU) && d->W <= 256 &&
+         (d->W & 3) == 0 && (d->H & 3) == 0 && d->N <= 65535 && d->H / 4 <= 65535;
+}
+static HeadArgs head_args(const avsep_conv_desc* d) {
+  HeadArgs a{};
+  a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
+  a.N = d->N; a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.Hl = d->H / 2; a.Wl = d->W / 2;
+  a.rh = (float)(a.Hl - 1) / (float)(d->H - 1);
+  a.rw = (float)(a.Wl - 1) / (float)(d->W - 1);
+  return a;
+}
+static int head_segments(int rows, int min_rows, int max_s) {   // power-of-two split with even segments
+  int S = 1;
+  while (S < max_s && rows % (4 * S) == 0 && rows / (2 * S) >= min_rows) S *= 2;
+  return S;
+}
+
+int head_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* bias, float* y, hipStream_t st) {
+  HeadArgs a = head_args(d);
+  const int R = d->Cout <= 2 ? 4 : 2;
+  dim3 grid(cdiv(d->H, R), d->N);
+  switch (d->Cout) {
+    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(256), 0, st, a, wp, wp_ld, bias, y); break;
+    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(256), 0, st, a, wp, wp_ld, bias, y); break;
+    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, grid, dim3(256), 0, st, a, wp, wp_ld, bias, y); break;
+    default: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, dim3(256), 0, st, a, wp, wp_ld, bias, y); break;
+  }
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+size_t head_wgrad_workspace_floats(const avsep_conv_desc* d) {
+  const int S = head_segments(d->H, 32, 8);
+  return (size_t)d->N * S * d->Cout * d->Cin * 9 + (size_t)d->N * S * d->Cout;
+}
+int head_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st) {
+  HeadArgs a = head_args(d);
+  const int S = head_segments(d->H, 32, 8);
+  float* part = ws;
+  float* bpart = ws + (size_t)d->N * S * d->Cout * d->Cin * 9;
+  dim3 grid(cdiv(d->Cin, 4), d->N, S);
+  switch (d->Cout) {
+    case 1: hipLaunchKernelGGL(head_wgrad_kernel<1>, grid, dim3(256), 0, st, a, dy, part, dbias ? bpart : nullptr, S); break;
+    case 2: hipLaunchKernelGGL(head_wgrad_kernel<2>, grid, dim3(256), 0, st, a, dy, part, dbias ? bpart : nullptr, S); break;
+    case 3: hipLaunchKernelGGL(head_wgrad_kernel<3>, grid, dim3(256), 0, st, a, dy, part, dbias ? bpart : nullptr, S); break;
+    default: hipLaunchKernelGGL(head_wgrad_kernel<4>, grid, dim3(256), 0, st, a, dy, part, dbias ? bpart : nullptr, S); break;
+  }
+  AVSEP_LAUNCH_CHECK();
+  const int nw = d->Cout * d->Cin * 9;
+  hipLaunchKernelGGL(head_reduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, st, part, dw, nw, d->N * S);
+  AVSEP_LAUNCH_CHECK();
+  if (dbias) {
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(64), 0, st, bpart, dbias, d->Cout, d->N * S);
+    AVSEP_LAUNCH_CHECK();
+  }
+  return AVSEP_OK;
+}
+
+int head_dgrad(const avsep_conv_desc* d, const float* w, const float* dy, float* g0, float* g1, const float* mean1,
+               const float* invstd1, double* bstats1, int acc0, hipStream_t st) {
+  HeadArgs a = head_args(d);
+  const int S = head_segments(a.Hl, 16, 4);
+  dim3 grid(cdiv(d->Cin, 4), d->N, S);
+  switch (d->Cout) {
+    case 1: hipLaunchKernelGGL(head_dgrad_kernel<1>, grid, dim3(256), 0, st, a, w, dy, g0, g1, mean1, invstd1, bstats1, acc0, S); break;
+    case 2: hipLaunchKernelGGL(head_dgrad_kernel<2>, grid, dim3(256), 0, st, a, w, dy, g0, g1, mean1, invstd1, bstats1, acc0, S); break;
+    case 3: hipLaunchKernelGGL(head_dgrad_kernel<3>, grid, dim3(256), 0, st, a, w, dy, g0, g1, mean1, invstd1, bstats1, acc0, S); break;
+    default: hipLaunchKernelGGL(head_dgrad_kernel<4>, grid, dim3(256), 0, st, a, w, dy, g0, g1, mean1, invstd1, bstats1, acc0, S); break;
+  }
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}

@@ -66,6 +66,19 @@ class Conv:
         call("avsep_conv2d_dgrad", self.ref, ptr(w_packed_d), ptr(dy), ptr(dx), ptr(ws), nbytes)
         return dx
 
+    def head_applicable(self):
+        """True when this (up2x, Cout <= 4) conv takes the fused decoder-head kernels (csrc/head.hip)."""
+        return bool(lib.load().avsep_conv2d_head_applicable(self.ref))
+
+    def dgrad_up2x(self, w, dy, mean1=None, invstd1=None, bstats1=None, g0_acc=None):
+        """Gradient wrt the two LOW-RES sources of an up2x conv (dgrad + transposed bilinear + ReLU mask fused)."""
+        x0, x1 = self.keep[0], self.keep[1]
+        g0 = g0_acc if g0_acc is not None else torch.empty_like(x0)
+        g1 = torch.empty_like(x1) if x1 is not None else None
+        call("avsep_conv2d_dgrad_up2x", self.ref, ptr(w), ptr(dy), ptr(g0), ptr(g1), ptr(mean1), ptr(invstd1),
+             ptr(bstats1), int(g0_acc is not None))
+        return g0, g1
+
     def wgrad(self, dy, want_bias=False):
         dw = _f32((self.Cout, self.Cin, self.KH, self.KW), self.like)
         db = _f32((self.Cout,), self.like) if want_bias else None

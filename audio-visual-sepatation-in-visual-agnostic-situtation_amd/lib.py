@@ -47,6 +47,8 @@ SIGNATURES = {
     "avsep_conv2d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _Z, _P]),
     "avsep_conv2d_dgrad_workspace_bytes": (_Z, [_CD]),
     "avsep_conv2d_dgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
+    "avsep_conv2d_head_applicable": (C.c_int32, [_CD]),
+    "avsep_conv2d_dgrad_up2x": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "avsep_conv2d_wgrad_workspace_bytes": (_Z, [_CD]),
     "avsep_conv2d_wgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
     "avsep_channel_stats": (C.c_int, [_P, _I, _I, _I, _P, _P]),

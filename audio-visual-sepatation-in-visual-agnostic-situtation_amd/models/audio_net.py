@@ -88,6 +88,7 @@ class Unet(nn.Module):
         self.extra_size = extra_size
         self.fusion_type, self.att_type = fusion_type, att_type
         self.fuse_upsample = fuse_upsample
+        self.fuse_head = True    # decoder head (<= 4 output channels) on the fused kernels of csrc/head.hip
         if extra_size is None:
             self.fusion = fusion_net.get_fusion_net(fusion_type)(att_type=att_type)
             lvl = _Level(ngf * 8, ngf * 8, ngf * 8, ngf * 16, "inner", None)
@@ -235,11 +236,15 @@ def _decode(net, E, vs, draws, training):
             cat = K.Cat(E["yd"][i], D["yu"][i + 1], sc0=dbn[0] if dbn is not None else None,
                         sh0=dbn[1] if dbn is not None else None, sc1=ubn[0], sh1=ubn[1])
             fused = net.fuse_upsample
-        if fused:   # upsample folded into the conv's operand staging: nothing materialised
+        cv = None
+        if i < L - 1:   # upsample folded into the conv's operand staging: nothing materialised
             cv = K.Conv(cat.keep[0], w.shape[0], 3, 1, 1, x1=cat.keep[1], sc0=cat.keep[2], sh0=cat.keep[3],
                         act0=ACT_RELU, sc1=cat.keep[4], sh1=cat.keep[5], act1=ACT_RELU, up2x=True)
-        else:
+            cv.head = cv.head_applicable() and net.fuse_head     # few-output-channel head: always worth fusing
+            fused = fused or cv.head
+        if not fused:
             cv = K.Conv(cat.fwd(), w.shape[0], 3, 1, 1)
+            cv.head = False
         st = K.zeros_stats(w.shape[0], x) if (l.up_bn is not None and training) else None
         bias = l.up_conv.bias.detach() if l.up_conv.bias is not None else None
         y = cv.fwd(cv.pack(w, 0), bias, st)
@@ -261,6 +266,13 @@ def _decode_bwd(net, E, D, dlogits, dsecond, has_vis, grads, Gd):
         dw, db = cv.wgrad(g, want_bias=l.up_conv.bias is not None)
         _acc(grads, l.up_conv.weight, dw)
         _acc(grads, l.up_conv.bias, db)
+        if cv.head:                                        # fused head: straight to the low-res sources
+            ubn = D["ubn"][i + 1]
+            bst = K.zeros_stats(ubn.shape[1], x)
+            Gd[i], dz = cv.dgrad_up2x(w, g, mean1=ubn[2], invstd1=ubn[3], bstats1=bst, g0_acc=Gd[i])
+            yu = D["yu"][i + 1]
+            g = K.bn_bwd_apply_(dz, yu, _bn_back(grads, lv[i + 1].up_bn, ubn, bst, yu.numel() // yu.shape[1]))
+            continue
         dU = cv.dgrad(cv.pack(w, 1), g)                    # wrt the (virtual) upsampled input
         if i == L - 1:
             if net.extra_size is None:

@@ -270,3 +270,64 @@ def test_pool_and_mean(dev):
     assert_close(K.temporal_mean(f.to(dev), 2, 3), f.view(2, 3, 4, 3, 3).mean(1), 1e-6, "tmean")
     d = torch.randn(2, 4, 3, 3, generator=g)
     assert_close(K.temporal_mean_bwd(d.to(dev), 2, 3), (d / 3).repeat_interleave(3, 0), 1e-6, "tmean bwd")
+
+
+@pytest.mark.parametrize("N,C0,C1,Hl,Wl,Cout,affine", [(2, 8, 8, 32, 32, 2, True), (2, 5, 3, 24, 20, 2, True),
+                                                        (1, 4, 4, 128, 128, 2, False), (2, 6, 2, 16, 64, 1, True),
+                                                        (2, 3, 5, 8, 16, 3, True), (1, 4, 4, 12, 8, 4, False),
+                                                        (2, 8, 0, 16, 16, 2, True)])
+def test_fused_decoder_head_matches_unfused(dev, N, C0, C1, Hl, Wl, Cout, affine):
+    """csrc/head.hip (fwd / wgrad / dgrad straight to the low-res sources) against the unfused launch sequence
+    relu_up2x_fwd -> conv3x3 -> (dgrad -> relu_up2x_bwd), and against torch on the CPU for the forward."""
+    import avsep_amd  # noqa: F401
+    from avsep_amd import kernels as K
+    from avsep_amd.lib import ACT_RELU
+    g = torch.Generator().manual_seed(N * 100 + C0 * 10 + Cout)
+    x0 = torch.randn(N, C0, Hl, Wl, generator=g)
+    x1 = torch.randn(N, C1, Hl, Wl, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(N, Cout, 2 * Hl, 2 * Wl, generator=g)
+    sc0 = sh0 = sc1 = sh1 = None
+    if affine:
+        sc0, sh0 = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g) * 0.3
+        if C1:
+            sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g) * 0.3
+    d = lambda t: None if t is None else t.to(dev)   # noqa: E731
+    X0, X1, W_, B_, DY = d(x0), d(x1), d(w), d(b), d(dy)
+    S0, H0, S1, H1 = d(sc0), d(sh0), d(sc1), d(sh1)
+    cv = K.Conv(X0, Cout, 3, 1, 1, x1=X1, sc0=S0, sh0=H0, act0=ACT_RELU, sc1=S1, sh1=H1, act1=ACT_RELU, up2x=True)
+    assert cv.head_applicable()
+    y = cv.fwd(cv.pack(W_, 0), B_, None)
+    # CPU reference of the forward
+    a0 = x0 * sc0.view(1, -1, 1, 1) + sh0.view(1, -1, 1, 1) if affine else x0
+    parts = [a0]
+    if C1:
+        parts.append(x1 * sc1.view(1, -1, 1, 1) + sh1.view(1, -1, 1, 1) if affine else x1)
+    U = torch.nn.functional.interpolate(torch.relu(torch.cat(parts, 1)), scale_factor=2, mode="bilinear", align_corners=True)
+    assert_close(y, torch.nn.functional.conv2d(U, w, b, padding=1), 2e-5, "fused head forward vs torch")
+    # unfused sequence on the GPU
+    cat = K.Cat(X0, X1, sc0=S0, sh0=H0, sc1=S1, sh1=H1)
+    Um = cat.fwd()
+    cu = K.Conv(Um, Cout, 3, 1, 1)
+    assert_close(y, cu.fwd(cu.pack(W_, 0), B_, None), 2e-5, "forward vs unfused")
+    dw, db = cv.wgrad(DY, want_bias=True)
+    dwu, dbu = cu.wgrad(DY, want_bias=True)
+    assert_close(dw, dwu, 5e-5, "dw")
+    assert_close(db, dbu, 5e-5, "db")
+    dU = cu.dgrad(cu.pack(W_, 1), DY)
+    mean1 = invstd1 = None
+    bst = bstu = None
+    if C1:
+        mean1, invstd1 = d(torch.randn(C1, generator=g) * 0.1), d(torch.rand(C1, generator=g) + 0.5)
+        bst, bstu = K.zeros_stats(C1, X0), K.zeros_stats(C1, X0)
+    g0u, g1u = cat.bwd(dU, mean1=mean1, invstd1=invstd1, bstats1=bstu)
+    g0, g1 = cv.dgrad_up2x(W_, DY, mean1=mean1, invstd1=invstd1, bstats1=bst)
+    assert_close(g0, g0u, 5e-5, "g0")
+    if C1:
+        assert_close(g1, g1u, 5e-5, "g1")
+        assert_close(bst.float(), bstu.float(), 1e-4, "BatchNorm-backward sums")
+    # accumulation into an existing source-0 gradient (second pass of the shared-encoder AV step)
+    base = torch.randn(N, C0, Hl, Wl, generator=g).to(dev)
+    acc, _ = cv.dgrad_up2x(W_, DY, g0_acc=base.clone())
+    assert_close(acc, base + g0u, 5e-5, "g0 accumulate")
