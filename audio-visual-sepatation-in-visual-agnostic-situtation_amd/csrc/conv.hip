@@ -551,6 +551,11 @@ int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
 int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st);
 int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
 bool w3_applicable(const avsep_conv_desc* d);
+bool c4_applicable(const avsep_conv_desc* d, int mode);
+size_t c4_packed_floats(const avsep_conv_desc* d, int mode);
+int c4_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
+int c4_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st);
+int c4_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
 size_t w3_workspace_floats(const avsep_conv_desc* d);
 int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 static int check_desc(const avsep_conv_desc* d, bool fwd_only = false) {
@@ -593,6 +598,7 @@ extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
   if (!d || (mode != 0 && mode != 1)) return 0;
   if (mode == 1 && smallci_applicable(d)) return (size_t)d->Cout * d->Cin * d->KH * d->KW;   // OIHW as is
   if (c3_applicable(d, mode)) return c3_packed_floats(d, mode);
+  if (c4_applicable(d, mode)) return c4_packed_floats(d, mode);
   return (size_t)packed_rows(d, mode) * packed_ld(d, mode);
 }
 
@@ -606,6 +612,7 @@ extern "C" int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w,
     return AVSEP_OK;
   }
   if (c3_applicable(d, mode)) return c3_pack(d, w, packed, mode, (hipStream_t)stream);
+  if (c4_applicable(d, mode)) return c4_pack(d, w, packed, mode, (hipStream_t)stream);
   int rows = packed_rows(d, mode), ld = packed_ld(d, mode);
   long long total = (long long)rows * ld;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed,
@@ -635,7 +642,7 @@ static SplitPlan splitk_plan(long long tiles, int K) {
   return p;
 }
 static bool fwd_uses_igemm(const avsep_conv_desc* d, const double* stats) {
-  return !((!stats && (smallco_applicable(d) || head_applicable(d))) || c3_applicable(d, 0));
+  return !((!stats && (smallco_applicable(d) || head_applicable(d))) || c3_applicable(d, 0) || c4_applicable(d, 0));
 }
 static SplitPlan fwd_split(const avsep_conv_desc* d) {
   long long ncols = (long long)d->N * d->Ho * d->Wo;
@@ -658,7 +665,7 @@ extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cout * d->Ho * d->Wo * sizeof(float) : 0;
 }
 extern "C" size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d) {
-  if (check_desc(d) || c3_applicable(d, 1) || smallci_applicable(d)) return 0;
+  if (check_desc(d) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1)) return 0;
   SplitPlan p = dgrad_split(d);
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cin * d->H * d->W * sizeof(float) : 0;
 }
@@ -671,6 +678,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   if (!stats && smallco_applicable(d)) return smallco_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
   if (!stats && head_applicable(d)) return head_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
   if (c3_applicable(d, 0)) return c3_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
+  if (c4_applicable(d, 0)) return c4_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.wp = w_packed; a.wp_ld = packed_ld(d, 0); a.out = y; a.bias = bias; a.stats = stats;
   a.M = d->Cout; a.K = d->Cin * d->KH * d->KW;
@@ -712,6 +720,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
   if (smallci_applicable(d)) return smallci_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c3_applicable(d, 1)) return c3_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
+  if (c4_applicable(d, 1)) return c4_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.wp = w_packed_dgrad; a.wp_ld = packed_ld(d, 1); a.dy = dy; a.out = dx;
   a.M = d->Cin;

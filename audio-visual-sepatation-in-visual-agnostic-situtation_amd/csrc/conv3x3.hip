@@ -23,10 +23,14 @@ struct C3Args {
   const float* bias;
   double* stats;
   int tilesX, tilesY, gridM;
+  // generalised geometry (3x3/s1/p1: Ho = H, Wo = W, pad 1, unit store stride):
+  int Ho, Wo;            // output tile space
+  int padh, padw;        // patch origin = tile origin * S - pad
+  int os, ooh, oow;      // store position = (oh*os + ooh, ow*os + oow) in an [OHs x OWs] plane
+  int OHs, OWs;
 };
 
-constexpr int C3_CK = 4;            // input channels per K-tile
-constexpr int C3_KT = C3_CK * 9;    // 36 GEMM-K rows per K-tile
+constexpr int C3_CK = 4;            // input channels per K-tile of the 3x3 path (host-side packing constant)
 
 __device__ __forceinline__ float c3_src(const C3Args& a, int n, int c, int hs, int ws) {
   float v;
@@ -43,9 +47,14 @@ __device__ __forceinline__ float c3_src(const C3Args& a, int n, int c, int hs, i
   return v;
 }
 
-template <int TH, int TW, int BM, bool UP2X>
+// KS x KS taps, stride S (1 or 2), dilation DIL, CK input channels per K-tile.  With S == 2 the patch columns are
+// stored de-interleaved (even columns, then odd columns) so that the 32 pixels of an MFMA column tile still read
+// consecutive LDS words (a stride-2 read would be a 2-way bank conflict on ds_read_b32).
+template <int TH, int TW, int BM, bool UP2X, int KS = 3, int S = 1, int DIL = 1, int CK = 4>
 __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
-  constexpr int PH = TH + 2, PW = TW + 2, PS = PH * PW;   // patch per channel
+  constexpr int NT = KS * KS, C3_KT = CK * NT, C3_CK = CK;
+  constexpr int PH = (TH - 1) * S + (KS - 1) * DIL + 1, PWR = (TW - 1) * S + (KS - 1) * DIL + 1;
+  constexpr int PW = (S == 2) ? (PWR + 1) / 2 * 2 : PWR, PWH = PW / 2, PS = PH * PW;   // patch per channel
   constexpr int LDA = BM + 4;
   constexpr int NPATCH = C3_CK * PS;
   constexpr int PE = (NPATCH + 255) / 256;                // patch elements per thread
@@ -89,12 +98,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
   const float* pptr[PE][NRAW];      // element source pointers for the current K-tile (source 0 first)
   long long poff1[PE][NRAW];        // offsets of the same elements inside source 1 (its channel 0 + cc)
   int p_cc[PE];
+  int p_lds[S == 2 ? PE : 1];       // LDS slot of the element (identity for S == 1)
   unsigned pok = 0;
 #pragma unroll
   for (int e = 0; e < PE; ++e) {
     int idx = min(tid + 256 * e, NPATCH - 1);
     int cc = idx / PS, r = (idx % PS) / PW, col = idx % PW;
-    int gh = h0 - 1 + r, gw = w0 - 1 + col;
+    int gh = h0 * S - a.padh + r, gw = w0 * S - a.padw + col;
+    if constexpr (S == 2) p_lds[e] = cc * PS + r * PW + (col & 1) * PWH + (col >> 1);
     bool ok = (PE * 256 == NPATCH || tid + 256 * e < NPATCH) && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
     int ghc = min(max(gh, 0), a.H - 1), gwc = min(max(gw, 0), a.W - 1);
     long long o[NRAW];
@@ -183,7 +194,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
         }
         v = (1.f - plh[e]) * ((1.f - plw[e]) * q[0] + plw[e] * q[1]) + plh[e] * ((1.f - plw[e]) * q[2] + plw[e] * q[3]);
       }
-      if (PE * 256 == NPATCH || tid + 256 * e < NPATCH) Ps[buf][tid + 256 * e] = ((pok >> e) & 1u) ? v : 0.f;
+      if (PE * 256 == NPATCH || tid + 256 * e < NPATCH) {
+        if constexpr (S == 2) Ps[buf][p_lds[e]] = ((pok >> e) & 1u) ? v : 0.f;
+        else Ps[buf][tid + 256 * e] = ((pok >> e) & 1u) ? v : 0.f;
+      }
     }
   };
 
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     int p = wn * 64 + j * 32 + li;
-    lb[j] = (p / TW) * PW + (p % TW) + lk * PS;
+    lb[j] = (p / TW) * S * PW + (p % TW) + lk * PS;        // S == 2: the column index is halved by the de-interleave
   }
   const int nK = a.Cin / C3_CK;
   issue(0);
@@ -214,8 +228,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
     // so the LDS latency hides behind 4 x 64 MFMA cycles instead of stalling the wave every step
     float av[2][TM], bv[2][2];
     auto read_ops = [&](int k2, int slot) __attribute__((always_inline)) {
-      const int cp = k2 / 9, tap = k2 % 9;                          // compile-time after unrolling
-      const int koff = (2 * cp) * PS + (tap / 3) * PW + (tap % 3);
+      const int cp = k2 / NT, tap = k2 % NT, kh = tap / KS, kw = tap % KS;   // compile-time after unrolling
+      const int koff = (2 * cp) * PS + kh * DIL * PW + (S == 2 ? (kw & 1) * PWH + (kw >> 1) : kw * DIL);
 #pragma unroll
       for (int i = 0; i < TM; ++i) av[slot][i] = As[buf][2 * k2 + lk][wm * WTM + i * 32 + li];
 #pragma unroll
@@ -239,15 +253,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
   }
 
   // ---- epilogue (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
-  const long long HW = (long long)a.H * a.W;
+  const long long HW = (long long)a.OHs * a.OWs;
   long long cbase[2];
   bool cok[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     int p = wn * 64 + j * 32 + li;
     int gh = h0 + p / TW, gw = w0 + p % TW;
-    cok[j] = gh < a.H && gw < a.W;
-    cbase[j] = (long long)n * a.Cout * HW + (long long)gh * a.W + gw;
+    cok[j] = gh < a.Ho && gw < a.Wo;
+    cbase[j] = (long long)n * a.Cout * HW + (long long)(gh * a.os + a.ooh) * a.OWs + (gw * a.os + a.oow);
   }
   const bool want_stats = a.stats != nullptr;
   float* s_sum = &As[0][0][0];   // [2][BM] per-wave-column partial sums (operand tiles are dead now)
@@ -333,6 +347,7 @@ int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
 }
 
 static int c3_launch(C3Args& a, hipStream_t st) {
+  a.Ho = a.H; a.Wo = a.W; a.padh = a.padw = 1; a.os = 1; a.ooh = a.oow = 0; a.OHs = a.H; a.OWs = a.W;
   const bool wide = a.W >= 32;
   a.tilesX = cdiv(a.W, wide ? 32 : 16);
   a.tilesY = cdiv(a.H, wide ? 4 : 8);
@@ -373,6 +388,101 @@ int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
   a.C0 = d->Cout; a.C1 = 0; a.Hs = d->H; a.Ws = d->W;
   a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
   return c3_launch(a, st);
+}
+
+// ===========================================================================
+// 4x4 / stride 2 / pad 1 (the U-Net encoder's down convs, audio_net.py:57-58,170-171) on the same kernel.
+//   forward : KS = 4, S = 2, one channel pair per K-tile (32 K rows), de-interleaved patch columns.
+//   dgrad   : the transposed conv splits into the 4 parity classes (ph, pw) of the input pixel; class (ph, pw)
+//             is a 2x2-tap stride-1 conv over dY (taps kh = 3-2*th | 2-2*th, pad = 1 | 0 for ph = 0 | 1; same
+//             for columns) whose outputs are stored at (2a+ph, 2b+pw): 4 launches of the KS = 2 instantiation,
+//             no MFMA work on structural zeros.
+// ===========================================================================
+// packed operand rows r = ((cpair*NT + tap)*2 + parity), column = GEMM M index
+//   mode 0 (forward, NT = 16): in-channel 2*cpair+parity, w[co][ci][tap],                       column co
+//   mode 1 (dgrad,  NT = 4, class cls = 2*ph+pw at row offset cls*Cout*4): "in"-channel = co,   column ci,
+//           tap (th, tw) -> (kh, kw) = (ph ? 2-2*th : 3-2*th, pw ? 2-2*tw : 3-2*tw)
+__global__ void c4_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int rows, int ld,
+                               int mode) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * ld) return;
+  int row = (int)(i / ld), col = (int)(i % ld);
+  float v = 0.f;
+  if (mode == 0) {
+    int parity = row & 1, q = row >> 1, tap = q % 16, ch = 2 * (q / 16) + parity;
+    if (ch < Cin && col < Cout) v = w[((long long)col * Cin + ch) * 16 + tap];
+  } else {
+    int per = Cout * 4, cls = row / per, rr = row % per;
+    int parity = rr & 1, q = rr >> 1, tap = q % 4, ch = 2 * (q / 4) + parity;
+    int ph = cls >> 1, pw = cls & 1, th = tap >> 1, tw = tap & 1;
+    int kh = ph ? 2 - 2 * th : 3 - 2 * th, kw = pw ? 2 - 2 * tw : 3 - 2 * tw;
+    if (ch < Cout && col < Cin) v = w[((long long)ch * Cin + col) * 16 + kh * 4 + kw];
+  }
+  out[i] = v;
+}
+
+// forward: Cin, C0 even, Wo >= 16; dgrad: Cout % 4 == 0, even H and W (all four classes have the same extent)
+bool c4_applicable(const avsep_conv_desc* d, int mode) {
+  if (!(d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->dil == 1) || d->up2x) return false;
+  if (d->Wo < 16 || d->Ho < 4 || d->N > 65535) return false;
+  if (mode == 0) return d->Cin % 2 == 0 && d->C0 % 2 == 0 && d->Cout >= 32;
+  return d->Cout % 4 == 0 && d->Cin >= 32 && (d->H & 1) == 0 && (d->W & 1) == 0;
+}
+size_t c4_packed_floats(const avsep_conv_desc* d, int mode) {
+  int rows = (mode == 0 ? d->Cin : d->Cout) * 16, ld = roundup(mode == 0 ? d->Cout : d->Cin, 128);
+  return (size_t)rows * ld;
+}
+int c4_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st) {
+  int rows = (mode == 0 ? d->Cin : d->Cout) * 16, ld = roundup(mode == 0 ? d->Cout : d->Cin, 128);
+  long long total = (long long)rows * ld;
+  hipLaunchKernelGGL(c4_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, packed, d->Cout, d->Cin, rows, ld, mode);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// tile choice shared by the forward and the dgrad classes; KS_/S_/CK_ select the instantiation
+template <int KS_, int S_, int CK_>
+static int c4_launch(C3Args& a, hipStream_t st) {
+  const bool wide = a.Wo >= 32;
+  a.tilesX = cdiv(a.Wo, wide ? 32 : 16);
+  a.tilesY = cdiv(a.Ho, wide ? 4 : 8);
+  const bool narrow = a.Cout <= 64 || (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * a.N < 384;
+  a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
+  dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
+  if (wide && !narrow) hipLaunchKernelGGL((conv3x3_kernel<4, 32, 128, false, KS_, S_, 1, CK_>), grid, dim3(256), 0, st, a);
+  else if (wide) hipLaunchKernelGGL((conv3x3_kernel<4, 32, 64, false, KS_, S_, 1, CK_>), grid, dim3(256), 0, st, a);
+  else if (!narrow) hipLaunchKernelGGL((conv3x3_kernel<8, 16, 128, false, KS_, S_, 1, CK_>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv3x3_kernel<8, 16, 64, false, KS_, S_, 1, CK_>), grid, dim3(256), 0, st, a);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+int c4_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st) {
+  C3Args a{};
+  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = 0;
+  a.Hs = d->H; a.Ws = d->W;
+  a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
+  a.wp = wp; a.wp_ld = roundup(d->Cout, 128); a.out = y; a.bias = bias; a.stats = stats;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.padh = a.padw = 1; a.os = 1; a.ooh = a.oow = 0; a.OHs = d->Ho; a.OWs = d->Wo;
+  return c4_launch<4, 2, 2>(a, st);
+}
+
+// dX[N,Cin,H,W] from dY[N,Cout,Ho,Wo]: four 2x2-tap stride-1 convs over dY, one per input-pixel parity class
+int c4_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st) {
+  const int ld = roundup(d->Cin, 128);
+  for (int cls = 0; cls < 4; ++cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    C3Args a{};
+    a.N = d->N; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
+    a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
+    a.x0 = dy; a.wp = wp + (size_t)cls * d->Cout * 4 * ld; a.wp_ld = ld; a.out = dx;
+    a.Ho = d->H / 2; a.Wo = d->W / 2; a.padh = ph ? 0 : 1; a.padw = pw ? 0 : 1;
+    a.os = 2; a.ooh = ph; a.oow = pw; a.OHs = d->H; a.OWs = d->W;
+    int rc = c4_launch<2, 1, 4>(a, st);
+    if (rc) return rc;
+  }
+  return AVSEP_OK;
 }
 
 // ===========================================================================

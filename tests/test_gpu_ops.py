@@ -33,6 +33,11 @@ CONV_CASES = [
     (1, 20, 12, 16, 2, 3, 1, 1, 1),        # Cout = 2 (last U-Net conv) -> direct small-Cout kernels
     (2, 37, 21, 144, 2, 3, 1, 1, 1),       # same path: ragged H, W > one 128 tile, Cin not a multiple of the chunk
     (2, 16, 10, 10, 3, 3, 1, 1, 1),        # W % 16 != 0 -> falls back to the MFMA path
+    (2, 8, 64, 64, 40, 4, 2, 1, 1),        # 4x4 s2 on the halo-patch kernel: 4x32 tiles, 64-row M tiles; dgrad: 4 parity classes
+    (2, 34, 40, 72, 36, 4, 2, 1, 1),       # same, ragged tiles (Ho = 20, Wo = 36), Cin = 34 (17 channel pairs)
+    (24, 6, 64, 64, 136, 4, 2, 1, 1),      # 128-row M tiles (>= 384 workgroups), second M tile ragged
+    (96, 4, 32, 32, 136, 4, 2, 1, 1),      # 8x16 tiles x 128 rows
+    (3, 32, 34, 32, 64, 4, 2, 1, 1),       # 8x16 tiles x 64 rows, Ho = 17
 ]
 
 
@@ -331,3 +336,28 @@ def test_fused_decoder_head_matches_unfused(dev, N, C0, C1, Hl, Wl, Cout, affine
     base = torch.randn(N, C0, Hl, Wl, generator=g).to(dev)
     acc, _ = cv.dgrad_up2x(W_, DY, g0_acc=base.clone())
     assert_close(acc, base + g0u, 5e-5, "g0 accumulate")
+
+
+def test_down_conv_virtual_input(dev):
+    """4x4 s2 halo-patch forward with the folded BatchNorm affine + LeakyReLU(0.2) of the previous encoder level
+    (audio_net.py:57-58) and the BatchNorm statistics epilogue; dgrad / wgrad of the same descriptor."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(12)
+    N, Cin, H, W, Cout = 3, 16, 48, 64, 48
+    x = torch.randn(N, Cin, H, W, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.5
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.06
+    v = F.leaky_relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(v, wr, None, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    t = lambda z: z.to(dev)   # noqa: E731
+    cv = K.Conv(t(x), Cout, 4, 2, 1, sc0=t(sc), sh0=t(sh), act0=2)
+    st = K.zeros_stats(Cout, t(x))
+    y = cv.fwd(cv.pack(t(w), 0), None, st)
+    assert_close(y, y_ref, 2e-5, "fwd")
+    st_ref = torch.cat([y_ref.detach().double().sum((0, 2, 3)), (y_ref.detach().double() ** 2).sum((0, 2, 3))])
+    assert_close(st, st_ref, 1e-5, "stats")
+    assert_close(cv.dgrad(cv.pack(t(w), 1), t(dy)), v.grad, 2e-5, "dgrad (wrt the activated input)")
+    assert_close(cv.wgrad(t(dy))[0], wr.grad, 2e-5, "wgrad")
