@@ -329,8 +329,9 @@ __global__ void c3_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // ---------------------------------------------------------------------------
 // forward: needs Cin % 4 == 0 and the source split on a chunk boundary; dgrad: Cout % 4 == 0
 bool c3_applicable(const avsep_conv_desc* d, int mode) {
-  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1)) return false;
-  if (d->W < 16 || d->H < 4 || d->N > 65535) return false;
+  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil)) return false;
+  if (d->dil == 2 && d->up2x) return false;
+  if (d->W < 12 || d->H < 4 || d->N > 65535) return false;   // 14x14 maps (ResNet layer3/4) take the 8x16 tiles
   if (mode == 0) return d->Cin % C3_CK == 0 && d->C0 % C3_CK == 0 && d->Cout > 4;
   return d->Cout % C3_CK == 0 && d->Cin >= 32;
 }
@@ -346,8 +347,8 @@ int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
   return AVSEP_OK;
 }
 
-static int c3_launch(C3Args& a, hipStream_t st) {
-  a.Ho = a.H; a.Wo = a.W; a.padh = a.padw = 1; a.os = 1; a.ooh = a.oow = 0; a.OHs = a.H; a.OWs = a.W;
+static int c3_launch(C3Args& a, hipStream_t st, int dil = 1) {
+  a.Ho = a.H; a.Wo = a.W; a.padh = a.padw = dil; a.os = 1; a.ooh = a.oow = 0; a.OHs = a.H; a.OWs = a.W;
   const bool wide = a.W >= 32;
   a.tilesX = cdiv(a.W, wide ? 32 : 16);
   a.tilesY = cdiv(a.H, wide ? 4 : 8);
@@ -355,10 +356,11 @@ static int c3_launch(C3Args& a, hipStream_t st) {
   const bool narrow = a.Cout <= 64 || (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * a.N < 384;
   a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
-#define C3_LAUNCH(TH_, TW_, BM_)                                                                        \
-  do {                                                                                                \
-    if (a.up2x) hipLaunchKernelGGL((conv3x3_kernel<TH_, TW_, BM_, true>), grid, dim3(256), 0, st, a);  \
-    else hipLaunchKernelGGL((conv3x3_kernel<TH_, TW_, BM_, false>), grid, dim3(256), 0, st, a);       \
+#define C3_LAUNCH(TH_, TW_, BM_)                                                                               \
+  do {                                                                                                       \
+    if (a.up2x) hipLaunchKernelGGL((conv3x3_kernel<TH_, TW_, BM_, true>), grid, dim3(256), 0, st, a);         \
+    else if (dil == 2) hipLaunchKernelGGL((conv3x3_kernel<TH_, TW_, BM_, false, 3, 1, 2>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((conv3x3_kernel<TH_, TW_, BM_, false>), grid, dim3(256), 0, st, a);              \
   } while (0)
   if (wide && !narrow) C3_LAUNCH(4, 32, 128);
   else if (wide) C3_LAUNCH(4, 32, 64);
@@ -378,7 +380,7 @@ int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
   a.rw = (d->up2x && d->W > 1) ? (float)(a.Ws - 1) / (float)(d->W - 1) : 0.f;
   a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
   a.wp = wp; a.wp_ld = roundup(d->Cout, 128); a.out = y; a.bias = bias; a.stats = stats;
-  return c3_launch(a, st);
+  return c3_launch(a, st, d->dil);
 }
 
 // dX[N,Cin,H,W] = conv3x3(dY[N,Cout,H,W], flipped/transposed weights)
@@ -387,7 +389,7 @@ int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
   a.N = d->N; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
   a.C0 = d->Cout; a.C1 = 0; a.Hs = d->H; a.Ws = d->W;
   a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
-  return c3_launch(a, st);
+  return c3_launch(a, st, d->dil);      // the flipped-weight identity holds for any dilation with pad == dil
 }
 
 // ===========================================================================

@@ -33,6 +33,9 @@ CONV_CASES = [
     (1, 20, 12, 16, 2, 3, 1, 1, 1),        # Cout = 2 (last U-Net conv) -> direct small-Cout kernels
     (2, 37, 21, 144, 2, 3, 1, 1, 1),       # same path: ragged H, W > one 128 tile, Cin not a multiple of the chunk
     (2, 16, 10, 10, 3, 3, 1, 1, 1),        # W % 16 != 0 -> falls back to the MFMA path
+    (3, 32, 14, 14, 40, 3, 1, 2, 2),       # dilated 3x3 (ResNet layer4) on the halo-patch kernel, 14x14 map
+    (2, 36, 20, 40, 136, 3, 1, 2, 2),      # dilated, 4x32 tiles
+    (3, 32, 14, 14, 48, 3, 1, 1, 1),       # 14x14 map, undilated
     (2, 8, 64, 64, 40, 4, 2, 1, 1),        # 4x4 s2 on the halo-patch kernel: 4x32 tiles, 64-row M tiles; dgrad: 4 parity classes
     (2, 34, 40, 72, 36, 4, 2, 1, 1),       # same, ragged tiles (Ho = 20, Wo = 36), Cin = 34 (17 channel pairs)
     (24, 6, 64, 64, 136, 4, 2, 1, 1),      # 128-row M tiles (>= 384 workgroups), second M tile ragged
