@@ -118,7 +118,8 @@ def pmc_traffic(family):
     row = table.get("kernels", {}).get(family)
     if row is None:
         return None
-    return {"traffic_bytes_per_launch": row["traffic_bytes_per_launch"], "source": "profiles/pmc_traffic.json: " + table.get("command", "")}
+    return {"traffic_bytes_per_step": row.get("traffic_bytes_per_step"),
+            "source": "profiles/pmc_traffic.json: " + table.get("command", "")}
 
 
 def cpu_baseline(P, seed):
@@ -240,7 +241,9 @@ def main():
                          "frac": d_ach / PEAK_F32_MFMA_TFLOPS,
                          # HBM bytes per launch from rocprofv3 PMC passes of this same command (2*FETCH_SIZE + WRITE_SIZE,
                          # the gfx950 correction of MI355X_MICROARCH.md); measured offline, see profiles/summarise_pmc.py
-                         "traffic": traffic["traffic_bytes_per_launch"] if traffic else None,
+                         # (per conv call like `achieved`: a 4x4/s2 data gradient is 4 kernel launches, one per parity class)
+                         "traffic": (traffic["traffic_bytes_per_step"] / (d_n / max(o.steps, 1))
+                                     if traffic and traffic["traffic_bytes_per_step"] else None),
                          "traffic_source": traffic["source"] if traffic else None,
                          "algorithmic_bytes_per_launch": d_bytes / max(d_n, 1), "kernel": dom,
                          "launches_per_step": d_n / max(o.steps, 1), "avg_launch_ms": d_ms / max(d_n, 1),

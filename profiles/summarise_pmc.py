@@ -2,7 +2,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
-    python profiles/summarise_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write "<the bench command>"
+    python profiles/summarise_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write "<the bench command>" <steps run>
 
 Both counters are in KiB.  Correction applied (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE tallies the
 128-byte read requests at 64 bytes, so reads = 2 * FETCH_SIZE; WRITE_SIZE is exact.  The calibration rows of the
@@ -46,7 +46,9 @@ def main():
         k = family(name)
         if k:
             fams[k][2] += len(vals); fams[k][3] += sum(vals)
-    out = {"command": sys.argv[3] if len(sys.argv) > 3 else "", "unit": "bytes per launch (average over the family's launches)",
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # train steps in each pass (warm-up + timed)
+    out = {"command": sys.argv[3] if len(sys.argv) > 3 else "", "steps_per_pass": steps,
+           "unit": "bytes per kernel launch (average over the family's launches); *_per_step = family total / steps",
            "correction": "reads = 2 * FETCH_SIZE KiB (gfx950), writes = WRITE_SIZE KiB", "kernels": {}}
     for k, (nf, sf, nw, sw) in sorted(fams.items()):
         if nf == 0 or nw == 0:
@@ -54,7 +56,8 @@ def main():
         rd, wr = 2.0 * sf / nf * 1024.0, sw / nw * 1024.0
         out["kernels"][k] = {"launches_fetch_pass": nf, "launches_write_pass": nw, "fetch_size_kib_raw": sf / nf,
                              "write_size_kib": sw / nw, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-                             "traffic_bytes_per_launch": rd + wr}
+                             "traffic_bytes_per_launch": rd + wr,
+                             "traffic_bytes_per_step": (rd + wr) * nf / steps if steps else None}
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
