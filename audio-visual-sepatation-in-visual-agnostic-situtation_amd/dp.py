@@ -15,6 +15,11 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    # one process per GPU; on a box with fewer GPUs than ranks (rehearsals of the N > 1 path on a 1-GPU box, together
+    # with AVSEP_DP_BACKEND=gloo: RCCL refuses two ranks on one device) the ranks wrap around the visible devices
+    if use_cuda:
+        local %= torch.cuda.device_count()
+    backend = backend or os.environ.get("AVSEP_DP_BACKEND") or None
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
