@@ -13,9 +13,15 @@
 // so a lane builds the six hi-res columns 4q-1..4q+4 (its 3x3 halo included) from its own float2 plus one value
 // from each neighbour lane, with per-lane constant coefficients.  M = Cout <= 4 is far too small for an MFMA
 // tile: the FMAs run on the vector ALU, weights come through the scalar unit (wave-uniform addresses).
+#include <type_traits>
 #include "common.h"
 
 #define HD_MAXCO 4
+
+// compile-time slot ids of the rolling 3-row windows (a runtime rotation would cost a register copy per row)
+using Slot0 = std::integral_constant<int, 0>;
+using Slot1 = std::integral_constant<int, 1>;
+using Slot2 = std::integral_constant<int, 2>;
 
 struct HeadArgs {
   const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
@@ -298,58 +304,62 @@ __global__ __launch_bounds__(256, 3) void head_dgrad_kernel(HeadArgs a, const fl
   for (int co = 0; co < COUT; ++co)
 #pragma unroll
     for (int t = 0; t < 9; ++t) wv[co][t] = w[((long long)co * C + c) * 9 + t];
-  float Em[COUT][8], E0[COUT][8], Ep[COUT][8];
-  auto load_e = [&](int h, float (&E)[COUT][8]) {
+  float E[3][COUT][8];                                    // rolling window of dy rows (columns 4q-2..4q+5)
+  const int lq = min(lane, W / 4 - 1);
+  const bool has_right = 4 * lq + 4 < W;
+  auto load_e = [&](int h, auto slot) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot)::value;
+    if (h >= 0 && h < H) {                                 // wave-uniform: interior rows take no zero fills
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) E[co][e] = 0.f;
-      if (active && h >= 0 && h < H) {
-        const float* row = dy + (((long long)n * COUT + co) * H + h) * W + 4 * lane;
+      for (int co = 0; co < COUT; ++co) {
+        // lanes past the row (W < 256) read the last quad again: they never store
+        const float* row = dy + (((long long)n * COUT + co) * H + h) * W + 4 * lq;
         const f32x4 m = *reinterpret_cast<const f32x4*>(row);
-        E[co][2] = m.x; E[co][3] = m.y; E[co][4] = m.z; E[co][5] = m.w;
-        if (lane > 0) { const float2 l = *reinterpret_cast<const float2*>(row - 2); E[co][0] = l.x; E[co][1] = l.y; }
-        if (4 * lane + 4 < W) { const float2 h2 = *reinterpret_cast<const float2*>(row + 4); E[co][6] = h2.x; E[co][7] = h2.y; }
+        const float2 l = *reinterpret_cast<const float2*>(row - (lq > 0 ? 2 : 0));
+        const float2 h2 = *reinterpret_cast<const float2*>(row + (has_right ? 4 : 2));
+        E[SL][co][0] = lq > 0 ? l.x : 0.f; E[SL][co][1] = lq > 0 ? l.y : 0.f;
+        E[SL][co][2] = m.x; E[SL][co][3] = m.y; E[SL][co][4] = m.z; E[SL][co][5] = m.w;
+        E[SL][co][6] = has_right ? h2.x : 0.f; E[SL][co][7] = has_right ? h2.y : 0.f;
       }
-    }
-  };
-  load_e(2 * r0 - 2, Em);
-  load_e(2 * r0 - 1, E0);
-  load_e(2 * r0, Ep);
-  float Glo[2] = {0.f, 0.f}, Ghi[2] = {0.f, 0.f}, s1 = 0.f, s2 = 0.f;
-  const long long HWl = (long long)a.Hl * a.Wl;
-  const long long pbase = ((long long)n * (ch.first ? a.C0 : a.C1) + ch.cs) * HWl;
-  for (int r = r0 - 1; r < r1; ++r) {                      // pair (r, r+1) <- U rows 2r+1, 2r+2
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ho = 2 * r + 1 + i;
-      float wa, wb;
-      lerp_pair(ho, r, a.Hl, a.rh, wa, wb);
-      float dU[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        float v = 0.f;
-#pragma unroll
-        for (int co = 0; co < COUT; ++co)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            v = fmaf(wv[co][kw], Ep[co][k - kw + 2], v);        // kh = 0 <- dy row ho+1
-            v = fmaf(wv[co][3 + kw], E0[co][k - kw + 2], v);    // kh = 1 <- dy row ho
-            v = fmaf(wv[co][6 + kw], Em[co][k - kw + 2], v);    // kh = 2 <- dy row ho-1
-          }
-        dU[k] = v;
-      }
-      const float T0 = (cb[0] * dU[0] + cb[1] * dU[1]) + (ca[2] * dU[2] + ca[3] * dU[3]);   // low-res column 2q
-      const float T1 = (cb[2] * dU[2] + cb[3] * dU[3]) + (ca[4] * dU[4] + ca[5] * dU[5]);   // low-res column 2q+1
-      Glo[0] = fmaf(wa, T0, Glo[0]); Glo[1] = fmaf(wa, T1, Glo[1]);
-      Ghi[0] = fmaf(wb, T0, Ghi[0]); Ghi[1] = fmaf(wb, T1, Ghi[1]);
+    } else {
 #pragma unroll
       for (int co = 0; co < COUT; ++co)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { Em[co][e] = E0[co][e]; E0[co][e] = Ep[co][e]; }
-      load_e(ho + 2, Ep);
+        for (int e = 0; e < 8; ++e) E[SL][co][e] = 0.f;
     }
-    if (r >= r0 && active) {                             // low-res row r has received both of its pairs
+  };
+  float Glo[2] = {0.f, 0.f}, Ghi[2] = {0.f, 0.f}, s1 = 0.f, s2 = 0.f;
+  const long long HWl = (long long)a.Hl * a.Wl;
+  const long long pbase = ((long long)n * (ch.first ? a.C0 : a.C1) + ch.cs) * HWl;
+  // U row ho of pair (r, r+1): kh = 0 <- dy row ho+1 (slot SP), kh = 1 <- ho (S0), kh = 2 <- ho-1 (SM)
+  auto urow = [&](auto sm_, auto s0_, auto sp_, int ho, int r) __attribute__((always_inline)) {
+    constexpr int SM = decltype(sm_)::value, SZ = decltype(s0_)::value, SP = decltype(sp_)::value;
+    float wa, wb;
+    lerp_pair(ho, r, a.Hl, a.rh, wa, wb);
+    float dU[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float v = 0.f;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          v = fmaf(wv[co][kw], E[SP][co][k - kw + 2], v);
+          v = fmaf(wv[co][3 + kw], E[SZ][co][k - kw + 2], v);
+          v = fmaf(wv[co][6 + kw], E[SM][co][k - kw + 2], v);
+        }
+      dU[k] = v;
+    }
+    const float T0 = (cb[0] * dU[0] + cb[1] * dU[1]) + (ca[2] * dU[2] + ca[3] * dU[3]);   // low-res column 2q
+    const float T1 = (cb[2] * dU[2] + cb[3] * dU[3]) + (ca[4] * dU[4] + ca[5] * dU[5]);   // low-res column 2q+1
+    Glo[0] = fmaf(wa, T0, Glo[0]); Glo[1] = fmaf(wa, T1, Glo[1]);
+    Ghi[0] = fmaf(wb, T0, Ghi[0]); Ghi[1] = fmaf(wb, T1, Ghi[1]);
+    load_e(ho + 2, sm_);
+  };
+  auto pair = [&](auto a_, auto b_, auto c_, auto d_, auto e_, auto f_, int r) __attribute__((always_inline)) {
+    urow(a_, b_, c_, 2 * r + 1, r);
+    urow(d_, e_, f_, 2 * r + 2, r);
+    if (r >= r0 && r < r1 && active) {                     // low-res row r has received both of its pairs
       const long long o = pbase + (long long)r * a.Wl + 2 * lane;
       const float2 v = *reinterpret_cast<const float2*>((ch.first ? a.x0 : a.x1) + o);
       float gx = fmaf(v.x, ch.scv, ch.shv) > 0.f ? Glo[0] : 0.f;
@@ -361,6 +371,15 @@ __global__ __launch_bounds__(256, 3) void head_dgrad_kernel(HeadArgs a, const fl
       *dst = make_float2(gx, gy);
     }
     Glo[0] = Ghi[0]; Glo[1] = Ghi[1]; Ghi[0] = 0.f; Ghi[1] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  load_e(2 * r0 - 2, Slot0{});
+  load_e(2 * r0 - 1, Slot1{});
+  load_e(2 * r0, Slot2{});
+  for (int r = r0 - 1; r < r1; r += 3) {                   // pairs (r, r+1) <- U rows 2r+1, 2r+2; three per trip
+    pair(Slot0{}, Slot1{}, Slot2{}, Slot1{}, Slot2{}, Slot0{}, r);
+    pair(Slot2{}, Slot0{}, Slot1{}, Slot0{}, Slot1{}, Slot2{}, r + 1);
+    pair(Slot1{}, Slot2{}, Slot0{}, Slot2{}, Slot0{}, Slot1{}, r + 2);
   }
   if (stats) {
     const double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
