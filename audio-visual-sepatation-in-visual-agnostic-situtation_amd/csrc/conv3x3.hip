@@ -506,6 +506,7 @@ struct W3Args {
   const float* dy;
   float* out;
   int tilesX, tilesY, gridM, gridC, tiles_per_split;
+  int tapmajor;   // 1: `out` is a slab buffer [split][tap][Cout][Cin] (lanes = ci -> 128-byte stores); 0: OIHW
 };
 
 constexpr int W3_CC = 32;   // input channels per workgroup (one MFMA column tile per tap)
@@ -719,8 +720,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int co = m0 + wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (co < a.Cout && ci < a.Cin)
-          a.out[(((long long)split * a.Cout + co) * a.Cin + ci) * 9 + tap0 + j] = acc[j][r];
+        if (co < a.Cout && ci < a.Cin) {
+          // OIHW puts the 32 lanes (ci) 36 bytes apart: every 4-byte store its own memory transaction (measured
+          // 6.6x write amplification on the slabs).  Slabs are therefore tap-major; w3_reduce_kernel transposes.
+          if (a.tapmajor) a.out[(((long long)split * 9 + tap0 + j) * a.Cout + co) * a.Cin + ci] = acc[j][r];
+          else a.out[((long long)co * a.Cin + ci) * 9 + tap0 + j] = acc[j][r];
+        }
       }
     }
 }
@@ -752,12 +757,18 @@ size_t w3_workspace_floats(const avsep_conv_desc* d) {
   W3Plan p = w3_plan(d);
   return p.splits > 1 ? (size_t)p.splits * d->Cout * d->Cin * 9 : 0;
 }
-__global__ void w3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n, int S) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < S; ++z) s += ws[(long long)z * n + i];
-  out[i] = s;
+// dw[cc][tap] = sum_z ws[z][tap][cc], cc = co*Cin + ci: coalesced plane reads, 36 contiguous bytes written per thread
+__global__ void w3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long P, int S) {
+  long long cc = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cc >= P) return;
+  float s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  for (int z = 0; z < S; ++z)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] += ws[((long long)z * 9 + t) * P + cc];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) out[cc * 9 + t] = s[t];
 }
 int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st) {
   W3Plan p = w3_plan(d);
@@ -768,7 +779,7 @@ int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   a.rh = (d->up2x && d->H > 1) ? (float)(a.Hs - 1) / (float)(d->H - 1) : 0.f;
   a.rw = (d->up2x && d->W > 1) ? (float)(a.Ws - 1) / (float)(d->W - 1) : 0.f;
   a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
-  a.dy = dy; a.out = p.splits > 1 ? ws : dw;
+  a.dy = dy; a.out = p.splits > 1 ? ws : dw; a.tapmajor = p.splits > 1;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.gridM = p.gridM; a.gridC = p.gridC; a.tiles_per_split = p.tps;
   dim3 grid(p.gridM * p.gridC, p.splits);
 #define W3_LAUNCH(TH_, TW_, UP_)                                                                             \
@@ -783,8 +794,8 @@ int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
 #undef W3_LAUNCH
   AVSEP_LAUNCH_CHECK();
   if (p.splits > 1) {
-    long long n = (long long)d->Cout * d->Cin * 9;
-    hipLaunchKernelGGL(w3_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, n, p.splits);
+    long long P = (long long)d->Cout * d->Cin;
+    hipLaunchKernelGGL(w3_reduce_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, ws, dw, P, p.splits);
     AVSEP_LAUNCH_CHECK();
   }
   return AVSEP_OK;
