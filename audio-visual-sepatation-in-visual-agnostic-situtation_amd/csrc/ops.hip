@@ -322,6 +322,168 @@ __global__ __launch_bounds__(256) void relu_up2x_fwd_kernel(CatArgs a, float* __
   out[((long long)nc * Ho + ho) * Wo + wo] = v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// "static pair" forms of the x2 align-corners upsample (the same observation as csrc/head.hip): hi-res index o
+// interpolates low-res (lo, lo+1) with lo = (o-1)>>1 for every o (weights l = r*o - lo, 1-l; at the borders the
+// out-of-range partner is read as 0 or gets weight ~0), so a lane that owns low-res columns 2q, 2q+1 builds hi-res
+// columns 4q..4q+3 from (L0..L3) = columns 2q-1..2q+2: own float2 + one value from each neighbour lane.  No integer
+// index arithmetic, no gathers: ~7 VALU per output instead of ~50.  Needs a power-of-two low-res width <= 128.
+// ---------------------------------------------------------------------------------------------------------------
+// thread = (plane, low-res row pair (r, r+1), q) -> hi-res rows 2r+1, 2r+2, columns 4q..4q+3 (two 16-byte stores)
+__global__ __launch_bounds__(256) void relu_up2x_fwd_pair_kernel(CatArgs a, float* __restrict__ out, int lw) {
+  const int C = a.C0 + a.C1, nc = blockIdx.y, n = nc / C, c = nc % C;          // block-uniform
+  const int t = blockIdx.x * 256 + threadIdx.x, q = t & ((1 << lw) - 1), r = (t >> lw) - 1;
+  const bool live = r < a.H;                                                    // r = -1 .. H-1
+  const bool first = c < a.C0;
+  const int cs = first ? c : c - a.C0;
+  const float* sc = first ? a.sc0 : a.sc1;
+  const float* sh = first ? a.sh0 : a.sh1;
+  const float scv = sc ? sc[cs] : 1.f, shv = sc ? sh[cs] : 0.f;
+  const float* p = (first ? a.x0 : a.x1) + ((long long)n * (first ? a.C0 : a.C1) + cs) * a.H * a.W + 2 * q;
+  float L[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rr = r + i;
+    float l1 = 0.f, l2 = 0.f;
+    if (live && rr >= 0 && rr < a.H) {
+      const float2 v = *reinterpret_cast<const float2*>(p + (long long)rr * a.W);
+      l1 = fmaxf(fmaf(v.x, scv, shv), 0.f);
+      l2 = fmaxf(fmaf(v.y, scv, shv), 0.f);
+    }
+    const float l0 = __shfl_up(l2, 1, 64), l3 = __shfl_down(l1, 1, 64);
+    L[i][0] = q > 0 ? l0 : 0.f; L[i][1] = l1; L[i][2] = l2; L[i][3] = 2 * q + 2 < a.W ? l3 : 0.f;
+  }
+  if (!live) return;
+  const int Ho = 2 * a.H, Wo = 2 * a.W;
+  // columns 4q+j on pairs (L0,L1), (L1,L2), (L1,L2), (L2,L3)
+  float cl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    cl[j] = __fmul_rn(a.rw, (float)(4 * q + j)) - (float)(2 * q - 1 + ((j + 1) >> 1));   // product rounded first, like the reference
+    if (4 * q + j == Wo - 1) cl[j] = 0.f;                 // last column: exactly the last low-res value
+  }
+  float Hr[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    Hr[i][0] = (1.f - cl[0]) * L[i][0] + cl[0] * L[i][1];
+    Hr[i][1] = (1.f - cl[1]) * L[i][1] + cl[1] * L[i][2];
+    Hr[i][2] = (1.f - cl[2]) * L[i][1] + cl[2] * L[i][2];
+    Hr[i][3] = (1.f - cl[3]) * L[i][2] + cl[3] * L[i][3];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ho = 2 * r + 1 + i;
+    if (ho >= 0 && ho < Ho) {
+      const float l = ho == Ho - 1 ? 0.f : __fmul_rn(a.rh, (float)ho) - (float)r;
+      f32x4 v;
+      v.x = (1.f - l) * Hr[0][0] + l * Hr[1][0];
+      v.y = (1.f - l) * Hr[0][1] + l * Hr[1][1];
+      v.z = (1.f - l) * Hr[0][2] + l * Hr[1][2];
+      v.w = (1.f - l) * Hr[0][3] + l * Hr[1][3];
+      *reinterpret_cast<f32x4*>(out + ((long long)nc * Ho + ho) * Wo + 4 * q) = v;
+    }
+  }
+}
+
+// transpose: thread = (plane, chunk of UPB_R low-res rows, q) sweeps down its rows; per low-res row two new hi-res
+// rows of dout (16-byte load + one word from each neighbour lane) are reduced horizontally onto the lane's two
+// low-res columns and spread onto rows (r, r+1).  Fused ReLU mask, skip-gradient accumulation and BatchNorm-backward
+// sums as in relu_up2x_bwd_kernel.
+constexpr int UPB_R = 8;
+__global__ __launch_bounds__(256) void relu_up2x_bwd_sweep_kernel(CatArgs a, const float* __restrict__ dout,
+                                                                  float* __restrict__ g0, float* __restrict__ g1,
+                                                                  const float* __restrict__ mean1,
+                                                                  const float* __restrict__ invstd1, double* bstats1,
+                                                                  int acc0, int lw) {
+  const int C = a.C0 + a.C1, nc = blockIdx.y, n = nc / C, c = nc % C;
+  const int t = blockIdx.x * 256 + threadIdx.x, q = t & ((1 << lw) - 1), r0 = (t >> lw) * UPB_R;
+  const bool first = c < a.C0;
+  const int cs = first ? c : c - a.C0, Cs = first ? a.C0 : a.C1;
+  float* g = first ? g0 : g1;
+  const bool live = r0 < a.H && g != nullptr;
+  const float* sc = first ? a.sc0 : a.sc1;
+  const float* sh = first ? a.sh0 : a.sh1;
+  const float scv = sc ? sc[cs] : 1.f, shv = sc ? sh[cs] : 0.f;
+  const bool stats = !first && bstats1;
+  const float mu = stats ? mean1[cs] : 0.f, is = stats ? invstd1[cs] : 1.f;
+  const int Ho = 2 * a.H, Wo = 2 * a.W;
+  const float* dp = dout + (long long)nc * Ho * Wo + 4 * q;
+  const long long pbase = ((long long)n * Cs + cs) * a.H * a.W + 2 * q;
+  const float* xs = (first ? a.x0 : a.x1) + pbase;
+  // hi-res columns 4q-1+k (k = 0..5) on pairs (L0,L1) x2, (L1,L2) x2, (L2,L3) x2; this lane owns L1, L2
+  float cl[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int wo = 4 * q - 1 + k;
+    cl[k] = __fmul_rn(a.rw, (float)wo) - (float)(2 * q - 1 + (k >> 1));
+    if (wo < 0 || wo >= Wo) cl[k] = (k < 2) ? 0.f : 1.f;      // out-of-range column: drop its share of L1 / L2
+    if (wo == Wo - 1) cl[k] = 0.f;                            // last column belongs to the last low-res value alone
+  }
+  // horizontally reduced hi-res row ho -> contributions (T0, T1) to low-res columns 2q, 2q+1
+  auto hrow = [&](int ho, float& T0, float& T1) __attribute__((always_inline)) {
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+    if (live && ho >= 0 && ho < Ho) m = *reinterpret_cast<const f32x4*>(dp + (long long)ho * Wo);
+    float dl = __shfl_up(m.w, 1, 64), dr = __shfl_down(m.x, 1, 64);
+    if (q == 0) dl = 0.f;
+    if (4 * q + 4 >= Wo) dr = 0.f;
+    // column k contributes (1-cl) to its lower partner and cl to its upper partner
+    T0 = (cl[0] * dl + cl[1] * m.x) + ((1.f - cl[2]) * m.y + (1.f - cl[3]) * m.z);
+    T1 = (cl[2] * m.y + cl[3] * m.z) + ((1.f - cl[4]) * m.w + (1.f - cl[5]) * dr);
+  };
+  float s1 = 0.f, s2 = 0.f;
+  // rows 2r-1, 2r feed row r through pair (r-1, r) with weight l; rows 2r+1, 2r+2 through pair (r, r+1) with 1-l
+  float Ta0, Ta1, Tb0, Tb1;
+  hrow(2 * r0 - 1, Ta0, Ta1);
+  hrow(2 * r0, Tb0, Tb1);
+  float G0, G1;
+  {
+    const float la = __fmul_rn(a.rh, (float)(2 * r0 - 1)) - (float)(r0 - 1), lb = __fmul_rn(a.rh, (float)(2 * r0)) - (float)(r0 - 1);
+    G0 = la * Ta0 + lb * Tb0;
+    G1 = la * Ta1 + lb * Tb1;
+  }
+#pragma unroll
+  for (int i = 0; i < UPB_R; ++i) {
+    const int r = r0 + i;
+    hrow(2 * r + 1, Ta0, Ta1);
+    hrow(2 * r + 2, Tb0, Tb1);
+    const float la = __fmul_rn(a.rh, (float)(2 * r + 1)) - (float)r, lb = __fmul_rn(a.rh, (float)(2 * r + 2)) - (float)r;
+    // the last low-res row keeps the whole weight of hi-res row 2H-1 (its upper partner does not exist)
+    const float wa = (r == a.H - 1) ? 1.f : 1.f - la;
+    G0 += wa * Ta0 + (1.f - lb) * Tb0;
+    G1 += wa * Ta1 + (1.f - lb) * Tb1;
+    if (live && r < a.H) {
+      const float2 v = *reinterpret_cast<const float2*>(xs + (long long)r * a.W);
+      float gx = fmaf(v.x, scv, shv) > 0.f ? G0 : 0.f, gy = fmaf(v.y, scv, shv) > 0.f ? G1 : 0.f;
+      s1 += gx + gy;
+      s2 += gx * (v.x - mu) * is + gy * (v.y - mu) * is;
+      float2* dst = reinterpret_cast<float2*>(g + pbase + (long long)r * a.W);
+      if (acc0 && first) { const float2 old = *dst; gx += old.x; gy += old.y; }
+      *dst = make_float2(gx, gy);
+    }
+    G0 = la * Ta0 + lb * Tb0;          // share of the same two rows that belongs to row r+1
+    G1 = la * Ta1 + lb * Tb1;
+  }
+  if (stats) {
+    const double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+    __shared__ double sh2[8];
+    if ((threadIdx.x & 63) == 0) { sh2[threadIdx.x >> 6] = d1; sh2[4 + (threadIdx.x >> 6)] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&bstats1[cs], sh2[0] + sh2[1] + sh2[2] + sh2[3]);
+      atomicAdd(&bstats1[a.C1 + cs], sh2[4] + sh2[5] + sh2[6] + sh2[7]);
+    }
+  }
+}
+
+// log2 of the lanes per low-res row (W/2) when the static-pair kernels apply, else -1
+static int up2x_pair_lw(const avsep_cat_desc* d) {
+  if (d->bcast0 || d->bcast1 || d->W < 4 || d->W > 128 || (d->W & (d->W - 1)) || d->H < 2) return -1;
+  int lw = 0;
+  while ((2 << lw) < d->W) ++lw;
+  return lw;
+}
+
 static CatArgs make_cat(const avsep_cat_desc* d) {
   CatArgs a{};
   a.N = d->N; a.C0 = d->C0; a.C1 = d->C1; a.H = d->H; a.W = d->W; a.b0 = d->bcast0; a.b1 = d->bcast1;
@@ -342,6 +504,13 @@ extern "C" int avsep_relu_up2x_fwd(const avsep_cat_desc* d, float* out, avsep_st
   CatArgs a = make_cat(d);
   long long planes = (long long)d->N * (d->C0 + d->C1);
   if (planes > 0x7fffffffLL || 2 * d->H > 65535) return AVSEP_ERR_ARG;
+  const int plw = up2x_pair_lw(d);
+  if (plw >= 0 && planes <= 65535) {
+    hipLaunchKernelGGL(relu_up2x_fwd_pair_kernel, dim3(cdiv((long long)(d->H + 1) << plw, 256), (unsigned)planes), dim3(256), 0,
+                       (hipStream_t)stream, a, out, plw);
+    AVSEP_LAUNCH_CHECK();
+    return AVSEP_OK;
+  }
   if (!d->bcast0 && !d->bcast1 && d->W >= 8) {              // Wo % 4 == 0: four outputs per thread, 16-byte stores
     int l4 = 6;
     while (l4 > 2 && (1 << (l4 - 1)) >= d->W / 2) --l4;
@@ -472,6 +641,14 @@ extern "C" int avsep_relu_up2x_bwd(const avsep_cat_desc* d, const float* dout, f
   if (bstats1 && (!mean1 || !invstd1 || d->bcast1 || !g1)) return AVSEP_ERR_ARG;
   CatArgs a = make_cat(d);
   int C = d->C0 + d->C1;
+  const int plw = up2x_pair_lw(d);
+  // (small planes: one block and one pair of atomics per plane would cost more than the LDS-tiled kernel's batch slices)
+  if (plw >= 0 && d->H >= 32 && (long long)d->N * C <= 65535) {
+    hipLaunchKernelGGL(relu_up2x_bwd_sweep_kernel, dim3(cdiv((long long)cdiv(d->H, UPB_R) << plw, 256), (unsigned)(d->N * C)),
+                       dim3(256), 0, (hipStream_t)stream, a, dout, g0, g1, mean1, invstd1, bstats1, acc0, plw);
+    AVSEP_LAUNCH_CHECK();
+    return AVSEP_OK;
+  }
   int tilesX = cdiv(d->W, UB_TW), tiles = tilesX * cdiv(d->H, UB_TH);
   int chunks = min(cdiv(4096, C * tiles), d->N);   // batch slices: enough blocks to fill the chip, few atomics
   if (chunks < 1) chunks = 1;

@@ -36,6 +36,8 @@ CONV_CASES = [
     (3, 32, 14, 14, 40, 3, 1, 2, 2),       # dilated 3x3 (ResNet layer4) on the halo-patch kernel, 14x14 map
     (2, 36, 20, 40, 136, 3, 1, 2, 2),      # dilated, 4x32 tiles
     (3, 32, 14, 14, 48, 3, 1, 1, 1),       # 14x14 map, undilated
+    (2, 1, 32, 48, 24, 4, 2, 1, 1),        # first U-Net conv (Cin = 1): blocked small-Cin data gradient
+    (2, 3, 20, 16, 10, 4, 2, 1, 1),        # same kernel, Cin = 3, ragged thread blocks
     (2, 8, 64, 64, 40, 4, 2, 1, 1),        # 4x4 s2 on the halo-patch kernel: 4x32 tiles, 64-row M tiles; dgrad: 4 parity classes
     (2, 34, 40, 72, 36, 4, 2, 1, 1),       # same, ragged tiles (Ho = 20, Wo = 36), Cin = 34 (17 channel pairs)
     (24, 6, 64, 64, 136, 4, 2, 1, 1),      # 128-row M tiles (>= 384 workgroups), second M tile ragged
@@ -132,11 +134,14 @@ def test_bn_pieces(dev):
     assert_close(dy, yr.grad, 5e-5, "bn dx")
 
 
-@pytest.mark.parametrize("bcast", [False, True])
-def test_relu_up2x(dev, bcast):
+@pytest.mark.parametrize("bcast,H,W", [(False, 4, 3), (True, 4, 3), (False, 20, 12), (False, 5, 4), (False, 13, 8),
+                                       (False, 16, 32), (False, 9, 128), (False, 64, 64)])
+def test_relu_up2x(dev, bcast, H, W):
+    """W = 4..128 powers of two take the static-pair kernels (pair forward, row-sweep backward), the rest the
+    gather / LDS-tiled kernels; ragged H covers partial row chunks."""
     K = _pkg().kernels
     g = torch.Generator().manual_seed(7)
-    N, C0, C1, H, W = 2, 6, 5, 4, 3
+    N, C0, C1 = 2, 6, 5
     x0 = torch.randn(N, C0, generator=g) if bcast else torch.randn(N, C0, H, W, generator=g)
     x1 = torch.randn(N, C1, H, W, generator=g)
     sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g)
@@ -147,12 +152,17 @@ def test_relu_up2x(dev, bcast):
     out_ref.backward(dout)
     t = lambda z: z.to(dev)
     cat = K.Cat(t(x0), t(x1), sc1=t(sc1), sh1=t(sh1), bcast0=bcast)
-    assert_close(cat.fwd(), out_ref, 1e-6, "fwd")
+    # the source index r*o is a float product: at o ~ 255 its rounding (ulp 7.6e-6) shows up as ~3e-6 of the output
+    assert_close(cat.fwd(), out_ref, 5e-6, "fwd")
     mean1, invstd1 = torch.randn(C1, generator=g), torch.rand(C1, generator=g) + 0.5
     bst = K.zeros_stats(C1, t(x1))
     g0, g1 = cat.bwd(t(dout), mean1=t(mean1), invstd1=t(invstd1), bstats1=bst)
-    assert_close(g0, a0.grad.sum((2, 3)) if bcast else a0.grad, 2e-6, "g0")
-    assert_close(g1, a1.grad, 2e-6, "g1")
+    assert_close(g0, a0.grad.sum((2, 3)) if bcast else a0.grad, 1e-5, "g0")
+    assert_close(g1, a1.grad, 1e-5, "g1")
+    if not bcast:   # accumulate into an existing source-0 gradient
+        base = torch.randn(N, C0, H, W, generator=g)
+        acc, _ = cat.bwd(t(dout), g0_acc=t(base).clone())
+        assert_close(acc, base + a0.grad, 1e-5, "g0 accumulate")
     xhat = (x1 - mean1.view(1, -1, 1, 1)) * invstd1.view(1, -1, 1, 1)
     ref = torch.cat([a1.grad.double().sum((0, 2, 3)), (a1.grad.double() * xhat).sum((0, 2, 3))])
     assert_close(bst, ref, 1e-5, "bstats")
