@@ -338,8 +338,10 @@ def test_shared_encoder_pair_equals_two_passes(dev, golden):
         assert_close(a["b"][k].double(), b["b"][k].double(), 1e-6, "buffer " + k)
 
 
-def test_config1_full_size_step_vs_oracle(dev):
-    """BASELINE.json configs[0]/[1] shapes at batch 2: 65535-sample waveforms -> STFT 1022/256 -> 512x256 ->
+@pytest.mark.parametrize("log_freq,backend", [(1, "torch"), (0, "hip")])
+def test_config1_full_size_step_vs_oracle(dev, log_freq, backend):
+    """(log_freq 0 keeps the 512x256 tiles of configs[4]; backend "hip" runs the visual trunk on this library too.)
+    BASELINE.json configs[0]/[1] shapes at batch 2: 65535-sample waveforms -> STFT 1022/256 -> 512x256 ->
     log-frequency warp to 256x256, 3 frames of 224x224 per source, unet7 (64 ngf) + hidsep(sig) + resnet18dilated,
     BCE, SGD.  One AV and one AO train step of the HIP path against the CPU oracle on identical inputs and weights
     (reference weight init for the U-Net, i.e. N(0, 1e-3) convs, plus a wide-init variant): loss, match loss and the
@@ -349,10 +351,11 @@ def test_config1_full_size_step_vs_oracle(dev):
     from oracle import nets as O, step as OS, criterion as OC, stft as OST
     a = P.arguments.train_music_args()
     a.stft_pad_mode = "reflect"
+    a.log_freq = log_freq
     raw = P.synth.make_batch(2, a.num_mix, a.num_frames, 224, a.audLen, seed=77)
     mags = [torch.from_numpy(np.stack([OST.stft_mag_phase(w.numpy())[0] for w in src]))[:, None] for src in raw["audios"]]
     mix = torch.from_numpy(np.stack([OST.stft_mag_phase(w.numpy())[0] for w in raw["audio_mix"]]))[:, None]
-    for wide in (False, True):
+    for wide in ((False, True) if log_freq else (True,)):
         torch.manual_seed(11)
         gen = torch.Generator().manual_seed(11)
         osnd = O.build_sound(a.arch_sound, a.num_channels, a.fusion_type, a.att_type)
@@ -364,6 +367,7 @@ def test_config1_full_size_step_vs_oracle(dev):
         frm = mb.build_frame(arch=a.arch_frame, fc_dim=a.vis_channels, pool_type=a.img_pool)
         snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict())
         snd, frm = snd.to(dev), frm.to(dev)
+        frm.backend = backend
         wrap = P.NetWrapper((snd, frm), mb.build_criterion(a.loss, use_pit=True), mb.build_criterion(a.loss))
         opt = P.create_optimizer((snd, frm), a)
         owrap = OS.NetWrapper((osnd, ofrm), OC.build_criterion(a.loss, True), OC.build_criterion(a.loss))
