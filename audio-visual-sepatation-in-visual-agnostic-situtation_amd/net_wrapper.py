@@ -7,6 +7,8 @@ reference loader's (dataset/music.py:275-331): ``mag_mix [B,1,512,256]``, ``mags
 ``frames`` list of N ``[B,3,T,224,224]``; alternatively ``audios``/``audio_mix`` waveforms can be
 given and the STFT runs on the GPU (``attach_stft``).
 """
+import os
+
 import torch
 
 from . import kernels as K
@@ -49,6 +51,7 @@ class NetWrapper(torch.nn.Module):
     # ------------------------------------------------------------------ main.py:97-111
     def forward_ao(self, data, args):
         mags, mag_mix, log_mag_mix, gt_masks, weight = data
+        self.unet_nodes = 1          # autograd nodes owning the U-Net parameters in this step (FlatSGD.arm_early_reduce)
         feat_sound, *_ = self.net_sound(log_mag_mix, None)
         act = ACT_BY_NAME.get(args.output_activation)
         if act is None:
@@ -84,8 +87,10 @@ class NetWrapper(torch.nn.Module):
         # Both passes read the same spectrogram: the U-Net shares its encoder between them (forward_pair).
         if hasattr(self.net_sound, "forward_pair") and getattr(self, "share_encoder", True) and N == 2:
             passes = self.net_sound.forward_pair(log_mag_mix, feat_frames[::-1], feat_frames)
+            self.unet_nodes = 1 if getattr(self.net_sound, "extra_size", None) is None else 2
         else:
             passes = None
+            self.unet_nodes = 2
         for pi, reverse in enumerate((True, False)):
             vis_in = feat_frames[::-1] if reverse else feat_frames
             feat_sound, meta = passes[pi] if passes is not None else self.net_sound(log_mag_mix, vis_in)
@@ -111,6 +116,7 @@ class NetWrapper(torch.nn.Module):
         mix_frame = torch.cat(list(frames), dim=-1)                          # B x 3 x T x H x (W*S)
         feat_frame = activate(self.net_frame.forward_multiframe(mix_frame, pool=args.not_pool_vis),
                               args.img_activation)
+        self.unet_nodes = 1
         feat_sound, meta = self.net_sound(log_mag_mix, [feat_frame])
         act = ACT_BY_NAME.get(args.output_activation)
         if act is None:
@@ -164,9 +170,14 @@ class FlatSGD:
     RCCL call over xGMI (replacing DataParallel's broadcast + reduce, main.py:661) and the
     update is one fused HIP launch per group."""
 
-    def __init__(self, groups, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1):
+    def __init__(self, groups, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1, overlap=None):
         self.momentum, self.weight_decay = momentum, weight_decay
         self.world_size, self.process_group = world_size, process_group
+        # Data parallel: the first group's gradients (the U-Net: 130 MB of the 180 MB) are complete as soon as its
+        # autograd node has run, i.e. BEFORE the visual trunk's backward (~30 ms) starts: their all-reduce is issued
+        # right there (asynchronously, RCCL's own stream) and overlaps that backward; step() reduces the rest.
+        self.overlap = (os.environ.get("AVSEP_DP_OVERLAP", "1") != "0") if overlap is None else overlap
+        self._early, self._early_left, self.early_reductions = None, 0, 0
         self.param_groups = []
         params = []
         for g in groups:
@@ -194,11 +205,38 @@ class FlatSGD:
                 self._views.append((p, gv))
                 off += n
             g["range"][1] = off
+        if self.world_size > 1 and self.overlap:
+            first = self.param_groups[0]
+            self._early_total = len(first["params"])
+            for p in first["params"]:
+                p.register_post_accumulate_grad_hook(self._on_first_group_grad)
+
+    def _on_first_group_grad(self, p):
+        """Fires once per parameter of the first group after autograd accumulated into its flat view."""
+        self._early_left -= 1
+        if self._early_left == 0 and self._early is None and self._flat_views_intact():
+            import torch.distributed as dist
+            a, b = self.param_groups[0]["range"]
+            self._early = dist.all_reduce(self.flat_grad[a:b], group=self.process_group, async_op=True)
+            self.early_reductions += 1
+
+    def _flat_views_intact(self):
+        g = self.param_groups[0]
+        return all(p.grad is not None and p.grad.data_ptr() == gv.data_ptr()
+                   for p, gv in self._views[:len(g["params"])])
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
         for p, gv in self._views:
             p.grad = gv
+        self._early, self._early_left = None, 0             # disarmed until arm_early_reduce()
+
+    def arm_early_reduce(self, accumulations):
+        """Call between forward and backward: every parameter of the first group will be accumulated into exactly
+        `accumulations` times (= autograd nodes that own the U-Net's parameters in this step's graph); the
+        all-reduce of that group then starts the moment the last one lands."""
+        if self.world_size > 1 and self.overlap and accumulations > 0:
+            self._early_left = getattr(self, "_early_total", 0) * accumulations
 
     def _collect(self):
         # a caller that ran module.zero_grad(set_to_none=True) (torch default, main.py:560) left
@@ -235,8 +273,14 @@ class FlatSGD:
         scale = 1.0
         if self.world_size > 1 and active:
             import torch.distributed as dist
-            lo, hi = min(g["range"][0] for g in active), max(g["range"][1] for g in active)
-            dist.all_reduce(self.flat_grad[lo:hi], group=self.process_group)   # ONE RCCL sum over xGMI
+            rest = active
+            if self._early is not None:                     # the first group is already being reduced
+                self._early.wait()
+                self._early = None
+                rest = [g for g in active if g is not self.param_groups[0]]
+            if rest:
+                lo, hi = min(g["range"][0] for g in rest), max(g["range"][1] for g in rest)
+                dist.all_reduce(self.flat_grad[lo:hi], group=self.process_group)   # ONE RCCL sum over xGMI
             scale = 1.0 / self.world_size
         for g in active:
             a, b = g["range"]
@@ -274,6 +318,8 @@ def train_step_async(model, batch, optimizer, use_vis, step_args=None):
     optimizer.zero_grad()
     err, outputs = model.forward(batch, a, use_vis)
     err = err.mean()
+    if isinstance(optimizer, FlatSGD):
+        optimizer.arm_early_reduce(getattr(model, "unet_nodes", 0))
     err.backward()
     if isinstance(optimizer, FlatSGD):
         optimizer.step(only=None if use_vis else ("sound",))   # the visual net is not in an audio-only graph

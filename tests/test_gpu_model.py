@@ -590,3 +590,54 @@ def test_loader_to_gpu_step(dev, tmp_path):
         b = PD.to_device(host, dev)
         err, match = P.train_step(wrap, b, opt, use_vis, a)
         assert err == err and 0.0 < err < 5.0, err
+
+
+def _dp_worker(rank, world, port, out, overlap):
+    import os
+    import sys
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), AVSEP_DP_BACKEND="gloo", AVSEP_DP_OVERLAP=overlap)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import avsep_amd as P
+    import torch.distributed as dist
+    r, w, dev = P.dp.init_from_env()
+    a = _args(log_freq=0)
+    torch.manual_seed(3)                                    # identical replicas
+    snd = P.models.Unet(fc_dim=2, num_downs=5, ngf=8, fusion_type="hidsep", att_type="sig").to(dev)
+    frm = P.models.ResnetDilated(None, fc_dim=32, pool_type="maxpool").to(dev)
+    mb = P.ModelBuilder()
+    wrap = P.NetWrapper((snd, frm), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
+    opt = P.create_optimizer((snd, frm), a, world_size=w)
+    gen = torch.Generator().manual_seed(20 + rank)          # rank-local shard of the global batch
+    srcs = [torch.rand(2, 1, 64, 64, generator=gen) ** 2 for _ in range(2)]
+    frames = [torch.randn(2, 3, 1, 64, 64, generator=gen) for _ in range(2)]
+    losses = []
+    for it in range(4):
+        b = {"mag_mix": (srcs[0] + srcs[1]).to(dev), "mags": [s.clone().to(dev) for s in srcs],
+             "frames": [f.to(dev) for f in frames]}
+        err, _, _ = P.net_wrapper.train_step_async(wrap, b, opt, it % 2 == 0, a)
+        losses.append(float(err))
+    flat = torch.cat([p.detach().reshape(-1) for p in list(snd.parameters()) + list(frm.parameters())]).cpu()
+    torch.save({"losses": losses, "params": flat, "early": opt.early_reductions}, f"{out}.{overlap}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_early_allreduce(dev, tmp_path):
+    """N > 1 path on the GPU (2 ranks sharing the device over gloo; RCCL refuses two ranks on one GPU): replicas stay
+    identical, and issuing the U-Net's gradient all-reduce early (overlapping the visual backward) gives the same
+    parameters as the single all-reduce in step()."""
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for overlap in ("0", "1"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_dp_worker, args=(2, port, str(tmp_path / "r"), overlap), nprocs=2, join=True)
+        res[overlap] = [torch.load(str(tmp_path / "r") + f".{overlap}.{r}") for r in range(2)]
+        assert torch.equal(res[overlap][0]["params"], res[overlap][1]["params"]), "replicas diverged"
+    assert res["0"][0]["early"] == 0 and res["1"][0]["early"] == 4        # every AV and AO step took the early path
+    assert_close(res["1"][0]["params"], res["0"][0]["params"], 1e-5, "overlapped vs single all-reduce")
+    for x, y in zip(res["0"][0]["losses"], res["1"][0]["losses"]):
+        assert abs(x - y) < 1e-5
