@@ -374,3 +374,38 @@ def test_down_conv_virtual_input(dev):
     assert_close(st, st_ref, 1e-5, "stats")
     assert_close(cv.dgrad(cv.pack(t(w), 1), t(dy)), v.grad, 2e-5, "dgrad (wrt the activated input)")
     assert_close(cv.wgrad(t(dy))[0], wr.grad, 2e-5, "wgrad")
+
+
+def test_resnet_glue_ops(dev):
+    """The two elementwise pieces of the HIP visual trunk: max-pool 3x3/s2/p1 reading relu(scale*x+shift) on the fly
+    (stem) and the BasicBlock tail relu(bn2(y2) + bn_d(y_d)) with its backward (+ BatchNorm-backward sums)."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(21)
+    N, C, H, W = 2, 6, 11, 14
+    x = torch.randn(N, C, H, W, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
+    t = lambda z: z.to(dev)   # noqa: E731
+    v = lambda z: z.view(1, -1, 1, 1)   # noqa: E731
+    a = torch.relu(x * v(sc) + v(sh)).requires_grad_(True)
+    p_ref = F.max_pool2d(a, 3, 2, 1)
+    dp = torch.randn(p_ref.shape, generator=g)
+    p_ref.backward(dp)
+    p, idx = K.maxpool3x3s2(t(x), t(sc), t(sh), 1)
+    assert_close(p, p_ref, 1e-6, "max-pool of relu(affine(x))")
+    assert_close(K.maxpool3x3s2_bwd(t(dp), idx, H, W), a.grad, 1e-6, "max-pool backward (wrt the activated input)")
+    # block tail
+    y, r, dz = (torch.randn(N, C, H, W, generator=g) for _ in range(3))
+    rs, rh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
+    mean, inv = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    for use_rs in (False, True):
+        pre = y * v(sc) + v(sh) + (r * v(rs) + v(rh) if use_rs else r)
+        z = K.affine_act(t(y), t(sc), t(sh), t(r), 1, t(rs) if use_rs else None, t(rh) if use_rs else None)
+        assert_close(z, torch.relu(pre), 1e-6, "bn2 + residual + relu")
+        gref = dz * (pre > 0).float()
+        bst = K.zeros_stats(C, t(y))
+        d = K.affine_act_bwd_(t(dz).clone(), t(y), t(sc), t(sh), t(r), None, t(mean), t(inv), 1, bst,
+                              res_scale=t(rs) if use_rs else None, res_shift=t(rh) if use_rs else None)
+        assert_close(d, gref, 1e-6, "masked gradient")
+        xhat = (y - v(mean)) * v(inv)
+        assert_close(bst, torch.cat([gref.double().sum((0, 2, 3)), (gref.double() * xhat.double()).sum((0, 2, 3))]), 1e-5,
+                     "BatchNorm-backward sums")
