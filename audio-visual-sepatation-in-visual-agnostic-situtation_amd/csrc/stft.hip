@@ -69,23 +69,79 @@ __global__ __launch_bounds__(256) void stft_pad_kernel(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void stft_magphase_kernel(const float* __restrict__ spec, int bins, int frames,
-                                                            float* __restrict__ mag, float* __restrict__ phase) {
+// hop-transposed padded waveforms for the 1x4-conv form: XT[c][r][j] = padded_r[hop*j + c] (reflect / zero padding
+// applied on the fly, 0 past the end).  Block = (row r, 32 hops): coalesced 32*hop-sample read, LDS transpose,
+// 128-byte writes along j.
+__global__ __launch_bounds__(256) void stft_pad_t_kernel(const float* __restrict__ wav, int L, int pad, int reflect, int hop,
+                                                         int R, int NH, float* __restrict__ xt) {
+  extern __shared__ float tile[];                         // [32][hop + 1]
+  const int r = blockIdx.y, j0 = blockIdx.x * 32, Lp = L + 2 * pad, ldt = hop + 1;
+  for (int i = threadIdx.x; i < 32 * hop; i += 256) {
+    const int jj = i / hop, c = i % hop, pos = (j0 + jj) * hop + c;
+    float v = 0.f;
+    if (pos < Lp) {
+      int s = pos - pad;
+      if (s >= 0 && s < L) v = wav[(long long)r * L + s];
+      else if (reflect) {
+        if (s < 0) s = -s;
+        if (s >= L) s = 2 * (L - 1) - s;
+        if (s >= 0 && s < L) v = wav[(long long)r * L + s];
+      }
+    }
+    tile[jj * ldt + c] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * hop; i += 256) {
+    const int c = i / 32, jj = i % 32;
+    if (j0 + jj < NH) xt[((long long)c * R + r) * NH + j0 + jj] = tile[jj * ldt + c];
+  }
+}
+
+// basis [k = sample][m] -> halo-patch operand rows ((c/2 * NTAP + j) * 2 + c%2), k = hop*j + c
+__global__ void stft_basis_repack_kernel(const float* __restrict__ basis, int n_fft, int hop, int ntap, int ld,
+                                         float* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)hop * ntap * ld) return;
+  const int row = (int)(i / ld), col = (int)(i % ld);
+  const int par = row & 1, q = row >> 1, j = q % ntap, c = 2 * (q / ntap) + par, k = hop * j + c;
+  out[i] = k < n_fft ? basis[(long long)k * ld + col] : 0.f;
+}
+
+// co_major: spec is [2*bins][R][frames] (1x4-conv form) instead of [R][2*bins][frames]
+__global__ __launch_bounds__(256) void stft_magphase_kernel(const float* __restrict__ spec, int bins, int frames, int R,
+                                                            int co_major, float* __restrict__ mag,
+                                                            float* __restrict__ phase) {
   const int r = blockIdx.y;
   const long long n = (long long)bins * frames;
-  const float* re = spec + (long long)r * 2 * n;
-  const float* im = re + n;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    float a = re[i], b = im[i];
+    float a, b;
+    if (co_major) {
+      const long long m = i / frames, f = i % frames;
+      a = spec[(m * R + r) * frames + f];
+      b = spec[((bins + m) * R + r) * frames + f];
+    } else {
+      a = spec[(long long)r * 2 * n + i];
+      b = spec[(long long)r * 2 * n + n + i];
+    }
     mag[(long long)r * n + i] = sqrtf(a * a + b * b);
     if (phase) phase[(long long)r * n + i] = atan2f(b, a);
   }
 }
 
+int c1x4_stft_fwd(const float* xt, const float* wp, float* out, int R, int NH, int hop, int cout, int frames,
+                  hipStream_t st);   // conv3x3.hip
+
+// the 1x4-conv form needs n_fft <= 4 hops (librosa's default 1022/256 does), whole channel pairs and room for a tile
+static bool stft_fast(int R, int L, int n_fft, int hop) {
+  return n_fft > 3 * hop && n_fft <= 4 * hop && (hop & 3) == 0 && hop <= 1024 && 1 + L / hop >= 32 && R >= 1;
+}
 extern "C" size_t avsep_stft_workspace_bytes(int32_t R, int32_t L, int32_t n_fft, int32_t hop) {
   if (R <= 0 || L <= 0 || n_fft < 2 || hop <= 0) return 0;
   size_t frames = 1 + L / hop;
-  return ((size_t)R * (L + n_fft) + (size_t)R * 2 * bins_of(n_fft) * frames) * sizeof(float);
+  size_t spec = (size_t)R * 2 * bins_of(n_fft) * frames;
+  if (stft_fast(R, L, n_fft, hop))   // hop-transposed input + repacked basis + spectrum
+    return ((size_t)hop * R * (frames + 3) + (size_t)hop * 4 * roundup(2 * bins_of(n_fft), 128) + spec) * sizeof(float);
+  return ((size_t)R * (L + n_fft) + spec) * sizeof(float);
 }
 
 extern "C" int avsep_stft_mag(const float* wav, int32_t R, int32_t L, int32_t n_fft, int32_t hop, int32_t reflect,
@@ -95,9 +151,28 @@ extern "C" int avsep_stft_mag(const float* wav, int32_t R, int32_t L, int32_t n_
     return AVSEP_ERR_ARG;
   if (!workspace || workspace_bytes < avsep_stft_workspace_bytes(R, L, n_fft, hop)) return AVSEP_ERR_WORKSPACE;
   const int pad = n_fft / 2, Lp = L + 2 * pad, bins = bins_of(n_fft), frames = 1 + L / hop;
+  hipStream_t st = (hipStream_t)stream;
+  if (stft_fast(R, L, n_fft, hop)) {
+    const int NH = frames + 3, ld = roundup(2 * bins, 128);
+    float* xt = (float*)workspace;
+    float* wp = xt + (size_t)hop * R * NH;
+    float* spec = wp + (size_t)hop * 4 * ld;
+    hipLaunchKernelGGL(stft_pad_t_kernel, dim3(cdiv(NH, 32), R), dim3(256), (size_t)32 * (hop + 1) * sizeof(float), st, wav, L,
+                       pad, reflect, hop, R, NH, xt);
+    AVSEP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stft_basis_repack_kernel, dim3(cdiv((long long)hop * 4 * ld, 256)), dim3(256), 0, st, basis, n_fft, hop,
+                       4, ld, wp);
+    AVSEP_LAUNCH_CHECK();
+    int rc = c1x4_stft_fwd(xt, wp, spec, R, NH, hop, 2 * bins, frames, st);
+    if (rc) return rc;
+    long long n = (long long)bins * frames;
+    hipLaunchKernelGGL(stft_magphase_kernel, dim3((int)min((n + 255) / 256, (long long)1024), R), dim3(256), 0, st, spec, bins,
+                       frames, R, 1, mag, phase);
+    AVSEP_LAUNCH_CHECK();
+    return AVSEP_OK;
+  }
   float* padded = (float*)workspace;
   float* spec = padded + (size_t)R * Lp;
-  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(stft_pad_kernel, dim3(min(cdiv(Lp, 256), 1024), R), dim3(256), 0, st, wav, L, pad, reflect, padded);
   AVSEP_LAUNCH_CHECK();
   avsep_conv_desc d{};
@@ -107,7 +182,7 @@ extern "C" int avsep_stft_mag(const float* wav, int32_t R, int32_t L, int32_t n_
   if (rc) return rc;
   long long n = (long long)bins * frames;
   hipLaunchKernelGGL(stft_magphase_kernel, dim3((int)min((n + 255) / 256, (long long)1024), R), dim3(256), 0, st, spec, bins,
-                     frames, mag, phase);
+                     frames, R, 0, mag, phase);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }

@@ -1,6 +1,7 @@
 """-m gpu: every HIP entry point against plain PyTorch fp32 on the CPU (conv/BN/upsample are
 floating-point kernels, so the torch reference is kept beside the oracle; tolerances are stated
 per test: fp32 accumulation-order noise only)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -271,6 +272,24 @@ def test_stft_against_numpy(dev):
         assert_close(back, ref, 5e-5, "istft " + mode)
     # round trip: interior samples are reconstructed
     assert (back.cpu()[:, 1024:64000] - wav[:, 1024:64000]).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("n_fft,hop,L,R", [(510, 128, 9000, 5), (254, 128, 8000, 2), (1022, 256, 12000, 1)])
+def test_stft_other_geometries(dev, n_fft, hop, L, R):
+    """n_fft within (3, 4] hops takes the 1x4-conv form on the halo-patch kernel (ragged row / frame tiles here),
+    anything else the strided 1-D conv through the im2col kernel."""
+    from oracle import stft as OS
+    K = _pkg().kernels
+    wav = torch.randn(R, L, generator=torch.Generator().manual_seed(L)) * 0.3
+    plan = K.Stft(dev, n_fft, hop, "reflect")
+    mag, phase = plan.stft(wav.to(dev))
+    assert mag.shape == (R, n_fft // 2 + 1, 1 + L // hop)
+    for r in range(R):
+        m_ref, p_ref = OS.stft_mag_phase(wav[r].numpy(), n_fft, hop, "reflect")
+        assert_close(mag[r], torch.from_numpy(m_ref), 2e-5, "stft mag")
+        spec = mag[r].cpu() * torch.exp(1j * phase[r].cpu())
+        spec_ref = torch.from_numpy(m_ref * np.exp(1j * p_ref))
+        assert (spec - spec_ref).abs().max() / spec_ref.abs().max() < 5e-5
 
 
 def test_pool_and_mean(dev):
