@@ -30,6 +30,11 @@ def _geom(conv):
     return k[0], s[0], p[0], d[0]
 
 
+def _w(conv):
+    """OIHW-dense weight (the flat optimizer may hold it channels-last for the MIOpen backend)."""
+    return conv.weight.detach().contiguous()
+
+
 def _conv(src, conv, aff=None):
     k, s, p, d = _geom(conv)
     if aff is None:
@@ -40,7 +45,7 @@ def _conv(src, conv, aff=None):
 def _conv_bn(src, conv, bn, training, aff=None):
     cv = _conv(src, conv, aff)
     st = K.zeros_stats(conv.out_channels, src) if training else None
-    y = cv.fwd(cv.pack(conv.weight.detach(), 0), None, st)
+    y = cv.fwd(cv.pack(_w(conv), 0), None, st)
     return cv, y, _bn_run(bn, st, y.numel() // y.shape[1], training, src)
 
 
@@ -71,7 +76,7 @@ def trunk_forward(net, x, training):
     S["cvf"] = _conv(z, net.fc)
     S["zf"] = z
     bias = net.fc.bias.detach() if net.fc.bias is not None else None
-    return S, S["cvf"].fwd(S["cvf"].pack(net.fc.weight.detach(), 0), bias, None)
+    return S, S["cvf"].fwd(S["cvf"].pack(_w(net.fc), 0), bias, None)
 
 
 def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None):
@@ -87,7 +92,7 @@ def trunk_backward(net, S, dout, grads):
     dw, db = cvf.wgrad(dout, want_bias=net.fc.bias is not None)
     _acc(grads, net.fc.weight, dw)
     _acc(grads, net.fc.bias, db)
-    g = cvf.dgrad(cvf.pack(net.fc.weight.detach(), 1), dout)          # dL/dz of the last block
+    g = cvf.dgrad(cvf.pack(_w(net.fc), 1), dout)          # dL/dz of the last block
     for R in reversed(S["blocks"]):
         blk = R["mod"]
         ds = blk.downsample is not None
@@ -96,12 +101,12 @@ def trunk_backward(net, S, dout, grads):
                              rs=bnd[0] if ds else None, rh=bnd[1] if ds else None)   # g = dL/d(pre-ReLU sum)
         dy2 = K.bn_bwd_apply_(g, R["y2"], pqr2, out=torch.empty_like(g))
         _acc(grads, blk.conv2.weight, R["cv2"].wgrad(dy2)[0])
-        da = R["cv2"].dgrad(R["cv2"].pack(blk.conv2.weight.detach(), 1), dy2)
+        da = R["cv2"].dgrad(R["cv2"].pack(_w(blk.conv2), 1), dy2)
         del dy2
         pqr1 = _relu_bn_back(grads, da, R["y1"], R["bn1"], blk.bn1)
         K.bn_bwd_apply_(da, R["y1"], pqr1)                              # da = dL/dy1
         _acc(grads, blk.conv1.weight, R["cv1"].wgrad(da)[0])
-        dz = R["cv1"].dgrad(R["cv1"].pack(blk.conv1.weight.detach(), 1), da)
+        dz = R["cv1"].dgrad(R["cv1"].pack(_w(blk.conv1), 1), da)
         del da
         if ds:
             bst = K.zeros_stats(g.shape[1], g)                          # BNd statistics of g (values of g unchanged)
@@ -109,7 +114,7 @@ def trunk_backward(net, S, dout, grads):
             pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, g.numel() // g.shape[1])
             K.bn_bwd_apply_(g, R["yd"], pqrd)                           # g = dL/dyd
             _acc(grads, blk.downsample[0].weight, R["cvd"].wgrad(g)[0])
-            dz.add_(R["cvd"].dgrad(R["cvd"].pack(blk.downsample[0].weight.detach(), 1), g))
+            dz.add_(R["cvd"].dgrad(R["cvd"].pack(_w(blk.downsample[0]), 1), g))
         else:
             dz.add_(g)
         g = dz

@@ -182,7 +182,8 @@ class FlatSGD:
         params = []
         for g in groups:
             ps = [p for p in g["params"] if p.requires_grad]
-            self.param_groups.append({"params": ps, "lr": g["lr"], "name": g.get("name", str(len(self.param_groups)))})
+            self.param_groups.append({"params": ps, "lr": g["lr"], "name": g.get("name", str(len(self.param_groups))),
+                                      "channels_last": bool(g.get("channels_last", False))})
             params += ps
         if not params:
             raise ValueError("no parameters")
@@ -198,9 +199,18 @@ class FlatSGD:
             g["range"] = [off, off]
             for p in g["params"]:
                 n = p.numel()
-                self.flat_param[off:off + n].copy_(p.data.reshape(-1))
-                p.data = self.flat_param[off:off + n].view_as(p.data)
-                gv = self.flat_grad[off:off + n].view_as(p.data)
+                if g["channels_last"] and p.dim() == 4:
+                    # conv weights of a module that runs on MIOpen's NHWC kernels: keep them OHWI inside the flat
+                    # buffers (a channels_last-strided view), or MIOpen transposes every weight on every call
+                    O, I, KH, KW = p.shape
+                    view = lambda flat: flat[off:off + n].view(O, KH, KW, I).permute(0, 3, 1, 2)   # noqa: E731
+                    view(self.flat_param).copy_(p.data)
+                    p.data = view(self.flat_param)
+                    gv = view(self.flat_grad)
+                else:
+                    self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+                    p.data = self.flat_param[off:off + n].view_as(p.data)
+                    gv = self.flat_grad[off:off + n].view_as(p.data)
                 p.grad = gv
                 self._views.append((p, gv))
                 off += n
@@ -292,11 +302,12 @@ class FlatSGD:
 
 def create_optimizer(nets, args, process_group=None, world_size=1):
     (net_sound, net_frame) = nets
+    nhwc = getattr(net_frame, "backend", None) == "torch"      # the MIOpen path wants OHWI conv weights
     groups = [{"params": list(net_sound.parameters()), "lr": args.lr_sound, "name": "sound"},
-              {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound, "name": "frame_fc"}]
+              {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound, "name": "frame_fc", "channels_last": nhwc}]
     if not args.fix_vis:
         groups.append({"params": list(net_frame.features.parameters()), "lr": args.lr_frame,
-                       "name": "frame_features"})
+                       "name": "frame_features", "channels_last": nhwc})
     return FlatSGD(groups, momentum=args.beta1, weight_decay=args.weight_decay,
                    process_group=process_group, world_size=world_size)
 
