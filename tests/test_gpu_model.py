@@ -641,3 +641,49 @@ def test_data_parallel_two_ranks_early_allreduce(dev, tmp_path):
     assert_close(res["1"][0]["params"], res["0"][0]["params"], 1e-5, "overlapped vs single all-reduce")
     for x, y in zip(res["0"][0]["losses"], res["1"][0]["losses"]):
         assert abs(x - y) < 1e-5
+
+
+@pytest.mark.parametrize("ftype,att,loss,binary,weighted,log_freq", [
+    ("CoLoc_Sel", "cos", "l1", 0, 0, 0), ("hidsep", "cos", "l2", 0, 1, 0), ("CoLoc_Sel", "sig", "bce", 1, 1, 1)])
+def test_step_variants_vs_oracle(dev, ftype, att, loss, binary, weighted, log_freq):
+    """The remaining flag combinations of the train step: CoLoc_Sel fusion, cosine attention, ratio
+    masks with L1 / L2, unweighted loss, with and without the log-frequency warp; AV and AO steps on small nets
+    against the CPU oracle (same weights, same inputs): losses, masks and the parameters after SGD."""
+    P = _pkg()
+    from oracle import nets as O, step as OS, criterion as OC
+    torch.manual_seed(8)
+    gen = torch.Generator().manual_seed(8)
+    osnd = O.Unet(fc_dim=2, num_downs=5, ngf=8, fusion_type=ftype, att_type=att)
+    O.wide_init(osnd, gen)
+    ofrm = O.VisualNet(fc_dim=32, pool_type="maxpool", dilate_scale=16)
+    snd = P.models.Unet(fc_dim=2, num_downs=5, ngf=8, fusion_type=ftype, att_type=att)
+    frm = P.models.ResnetDilated(None, fc_dim=32, pool_type="maxpool")
+    snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict())
+    snd, frm = snd.to(dev), frm.to(dev)
+    args = _args(fusion_type=ftype, att_type=att, loss=loss, binary_mask=binary, weighted_loss=weighted, log_freq=log_freq)
+    F_in = 128 if log_freq else 64                      # the warp always produces 256 bins; keep the small case small
+    srcs = [torch.rand(2, 1, F_in, 64, generator=gen) ** 2 for _ in range(2)]
+    frames = [torch.randn(2, 3, 2, 64, 64, generator=gen) for _ in range(2)]
+
+    def batch(d):
+        return {"mag_mix": (srcs[0] + srcs[1]).to(d), "mags": [s.clone().to(d) for s in srcs], "frames": [f.to(d) for f in frames]}
+    mb = P.ModelBuilder()
+    wrap = P.NetWrapper((snd, frm), mb.build_criterion(loss, use_pit=True), mb.build_criterion(loss))
+    opt = P.create_optimizer((snd, frm), args)
+    owrap = OS.NetWrapper((osnd, ofrm), OC.build_criterion(loss, True), OC.build_criterion(loss))
+    oopt = OS.create_optimizer((osnd, ofrm), args)
+    for it, use_vis in enumerate((True, False, True)):
+        draws = torch.tensor([it % 2 == 0, True])
+        snd.ao_draws = draws
+        osnd.levels()[-1].fusion.ao_draws = draws
+        err, match, outs = P.net_wrapper.train_step_async(wrap, batch(dev), opt, use_vis, args)
+        oerr, omatch, oouts = OS.train_step(owrap, batch("cpu"), oopt, use_vis, args)
+        assert abs(err.item() - oerr) < 3e-4 * max(1.0, abs(oerr)), (it, err.item(), oerr)
+        if use_vis:
+            assert abs(match.item() - omatch) < 3e-4
+        for n in range(2):
+            assert ((outs["pred_masks"][n].detach().cpu() - oouts["pred_masks"][n].detach()) ** 2).mean().item() < 1e-6
+    osd = osnd.state_dict()
+    for k, v in snd.state_dict().items():
+        if v.dtype.is_floating_point and "running" not in k:
+            assert_close(v, osd[k], 2e-3, "after 3 steps: " + k)
