@@ -687,3 +687,37 @@ def test_step_variants_vs_oracle(dev, ftype, att, loss, binary, weighted, log_fr
     for k, v in snd.state_dict().items():
         if v.dtype.is_floating_point and "running" not in k:
             assert_close(v, osd[k], 2e-3, "after 3 steps: " + k)
+
+
+def test_training_driver_end_to_end(dev, tmp_path):
+    """avsep_amd.train (the loop of main.py:572-763): AV/AO alternation by the reference's schedule rule, history with
+    the reference's keys, evaluation (SI-SDR/SDR) at eval_iter, checkpoint files, lr drop, then --mode eval from the
+    best checkpoint — on a tiny on-disk wav/jpg dataset."""
+    import os
+    P = _pkg()
+    from avsep_amd import train as T
+    from test_dataset import _make_disk_dataset
+    lst = _make_disk_dataset(str(tmp_path))
+    flags = ("--id run --ckpt {ck} --av_list_train {l} --ao_list_train {l} --list_val {l} --start_av_first --num_fsteps 0 "
+             "--arch_sound unet5 --arch_frame resnet18dilated --img_pool maxpool --num_channels 2 --img_activation relu "
+             "--output_activation sigmoid --vis_channels 256 --fusion_type hidsep --not_pool_vis --att_type sig "
+             "--binary_mask 1 --loss bce --weighted_loss 1 --num_mix 2 --log_freq 1 --num_frames 1 --stride_frames 2 "
+             "--imgSize 64 --audLen 16383 --margin 1.0 --batch_size_per_gpu 2 --workers 0 --train_repeat 1 --val_repeat 1 "
+             "--lr_steps 5 --num_iters 8 --iter_per_av 2 --eval_iter 4 --disp_iter 2 --max_silent 0.87").format(
+                 ck=str(tmp_path / "ck"), l=lst).split()
+    # the schedule rule itself (main.py:578-581)
+    a = P.ArgParser().parse_train_arguments(flags, verbose=False)
+    assert [T.av_ao_schedule(i, a) for i in range(1, 7)] == [False, True, False, True, False, True]
+    a.start_av_first, a.num_fsteps = False, 3
+    assert [T.av_ao_schedule(i, a) for i in range(1, 7)] == [False, False, False, True, False, True]
+    hist = T.cli(flags)
+    assert hist["train"]["iter"] == [2, 4, 6] and all(e == e and 0 < e < 5 for e in hist["train"]["err"])
+    assert hist["train_av"]["iter"] == [2, 4, 6] and hist["train_ao"]["iter"] == [2, 4, 6]
+    assert hist["val_av"]["iter"] == [4] and hist["val_ao"]["iter"] == [4]
+    assert all(v == v for v in hist["val_ao"]["si_sdr"] + hist["val_av"]["sdr"])        # finite, not NaN
+    ck = str(tmp_path / "ck" / "run")
+    assert sorted(os.listdir(ck)) == ["frame_best.pth", "frame_latest.pth", "history_latest.pth", "optim_latest.pth",
+                                      "sound_best.pth", "sound_latest.pth"]
+    ev = T.cli(flags + ["--mode", "eval"])
+    assert ev["val_av"]["iter"] == [0] and ev["val_ao"]["iter"] == [0]
+    assert abs(ev["val_ao"]["si_sdr"][0] - hist["val_ao"]["si_sdr"][0]) < 1e-3      # same weights as at iteration 4
