@@ -6,7 +6,7 @@ Layout: ``csrc/`` HIP kernels + C ABI (include/avsep.h) -> ``lib.py`` ctypes bin
 models/__init__.py) and ``net_wrapper.py`` (NetWrapper / train_step surface of main.py).
 """
 from . import lib, kernels, arguments, synth          # noqa: F401
-from . import models, net_wrapper, dp, evaluate, sopp, inference, checkpoint, dataset, train  # noqa: F401
+from . import models, net_wrapper, dp, evaluate, bss_eval, sopp, inference, checkpoint, dataset, train  # noqa: F401
 from .models import ModelBuilder, activate             # noqa: F401
 from .net_wrapper import NetWrapper, create_optimizer, train_step, adjust_learning_rate  # noqa: F401
 from .arguments import ArgParser                       # noqa: F401

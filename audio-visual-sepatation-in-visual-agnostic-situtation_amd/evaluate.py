@@ -4,9 +4,9 @@ un-warp the predicted masks (grid_sample on the inverse log-frequency grid, main
 separation ratios against the ground-truth waveforms.
 
 Built: SI-SDR (asteroid/pb_bss_eval definition: projection of the estimate on the reference, no mean
-removal) and the plain SDR 10*log10(|s|^2 / |s - s_hat|^2).  NOT built: BSS-eval SDR/SIR/SAR
-(mir_eval.bss_eval_sources, 512-tap distortion filters) — third-party, unpinned, a later row.
-The reference runs this per sample on the CPU (librosa + mir_eval); here it is 3 launches per batch.
+removal), the plain SDR 10*log10(|s|^2 / |s - s_hat|^2), and BSS-eval SDR / SIR / SAR with mir_eval's
+semantics (bss_eval.py: 512-tap projections, batched on the device).  The reference runs all of this per
+sample on the CPU (librosa + mir_eval); here the waveforms are 3 launches per batch.
 """
 import torch
 
@@ -52,11 +52,23 @@ def reconstruct(batch_data, outputs, args, stft_plan=None):
     return torch.stack(wavs, 0)
 
 
-def calc_metrics(batch_data, outputs, args, stft_plan=None):
-    """Returns a dict with per-(sample, source) 'si_sdr' and 'sdr' [B,N] and their batch means."""
+def calc_metrics(batch_data, outputs, args, stft_plan=None, bss=True):
+    """Per-(sample, source) [B,N] 'si_sdr', 'sdr_plain' and — with bss=True — BSS-eval 'sdr', 'sir', 'sar' (what the
+    reference's get_metrics reports, main.py:260-266), plus their batch means ('<key>_mean')."""
+    from . import bss_eval
     pred = reconstruct(batch_data, outputs, args, stft_plan)                 # [N,B,L]
     N, B, L = pred.shape
+    silent = (pred == 0).all(-1)                                             # main.py:248-249
+    if bool(silent.any()):
+        pred = torch.where(silent[..., None], 0.01 * torch.rand_like(pred), pred)
     gts = torch.stack([a.float() for a in batch_data["audios"][:N]], 0)      # [N,B,audLen]
     s = sdr_sums(pred.reshape(N * B, L), gts.reshape(N * B, -1).contiguous())
-    si, sd = si_sdr_from_sums(s).view(N, B).t(), sdr_from_sums(s).view(N, B).t()
-    return {"si_sdr": si, "sdr": sd, "si_sdr_mean": si.mean(), "sdr_mean": sd.mean(), "pred_wavs": pred}
+    out = {"si_sdr": si_sdr_from_sums(s).view(N, B).t(), "sdr_plain": sdr_from_sums(s).view(N, B).t(), "pred_wavs": pred}
+    if bss:
+        sdr, sir, sar = bss_eval.bss_eval_sources(gts[..., :L].permute(1, 0, 2), pred.permute(1, 0, 2))
+        out.update(sdr=sdr.float(), sir=sir.float(), sar=sar.float())
+    else:
+        out["sdr"] = out["sdr_plain"]
+    for k in [k for k in out if k != "pred_wavs"]:
+        out[k + "_mean"] = out[k].mean()
+    return out

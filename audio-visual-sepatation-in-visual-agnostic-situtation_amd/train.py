@@ -14,8 +14,8 @@ Same flags, same schedule and same bookkeeping as the reference:
   the audio-only SI-SDR); learning rates drop x0.1 at `lr_steps`; `--mode eval` loads `*_best.pth` and only evaluates.
 
 Different on purpose: one process per GPU (torch.distributed + RCCL; each rank draws its own shard of every global
-batch) instead of nn.DataParallel; batches carry waveforms and the STFT runs on the GPU; metrics are SI-SDR and plain
-SDR (evaluate.py) — BSS-eval SIR/SAR (mir_eval) are not built and are recorded as NaN; no HTML visualisation.
+batch) instead of nn.DataParallel; batches carry waveforms and the STFT runs on the GPU; the metrics (SI-SDR and
+BSS-eval SDR / SIR / SAR, evaluate.py + bss_eval.py) are computed on the device; no HTML visualisation.
 """
 import os
 import random
@@ -61,7 +61,7 @@ def evaluate(wrapper, loader, history, itera, args, use_vis, device, world=1):
     """main.py:421-503 without the visualisation: mean loss / match loss / SI-SDR / SDR over the validation list."""
     print("Evaluating at {} iterations...".format(itera))
     wrapper.eval()
-    tot = torch.zeros(5, dtype=torch.float64, device=device)      # loss, match, si_sdr, sdr, batches
+    tot = torch.zeros(7, dtype=torch.float64, device=device)      # loss, match, si_sdr, sdr, sir, sar, batches
     with torch.no_grad():
         for host in loader:
             batch = dataset.to_device(host, device)
@@ -69,16 +69,16 @@ def evaluate(wrapper, loader, history, itera, args, use_vis, device, world=1):
             m = ev.calc_metrics(batch, outputs, args, wrapper.stft_plan)
             match = outputs["match_loss"].mean() if use_vis else err.new_zeros(())
             tot += torch.stack([err.mean().double(), match.double(), m["si_sdr_mean"].double(), m["sdr_mean"].double(),
-                                tot.new_ones(())])
+                                m["sir_mean"].double(), m["sar_mean"].double(), tot.new_ones(())])
     if world > 1:
         import torch.distributed as dist
         dist.all_reduce(tot)
-    loss, match, si_sdr, sdr = (tot[:4] / tot[4].clamp_min(1)).tolist()
-    print("[Eval Summary] iterations: {}, Loss: {:.4f}, Loss_match: {:.4f}, SI-SDR: {:.4f}, SDR: {:.4f}".format(
-        itera, loss, match, si_sdr, sdr))
+    loss, match, si_sdr, sdr, sir, sar = (tot[:6] / tot[6].clamp_min(1)).tolist()
+    print("[Eval Summary] iterations: {}, Loss: {:.4f}, Loss_match: {:.4f}, SI-SDR: {:.4f}, SDR: {:.4f}, SIR: {:.4f}, "
+          "SAR: {:.4f}".format(itera, loss, match, si_sdr, sdr, sir, sar))
     h = history["val_av" if use_vis else "val_ao"]
     h["iter"].append(itera); h["err"].append(loss); h["sdr"].append(sdr); h["si_sdr"].append(si_sdr)
-    h["sir"].append(float("nan")); h["sar"].append(float("nan"))
+    h["sir"].append(sir); h["sar"].append(sar)
     torch.set_grad_enabled(True)
 
 
