@@ -139,6 +139,50 @@ def affine_act_bwd_(dz, y, scale, shift, residual, add, mean, invstd, act, bstat
     return dst
 
 
+# ---- channels-last ([N,C,H,W] tensors with torch.channels_last strides = dense [N*H*W, C]) ----------------------
+def _cl(t):
+    """(M, C) of a dense channels-last 4-D tensor."""
+    lib.ptr_cl(t)
+    return t.numel() // t.shape[1], t.shape[1]
+
+
+def _nhwc_ws(M, Cc, like):
+    nbytes = lib.load().avsep_nhwc_stats_workspace_bytes(M, Cc)
+    return torch.empty((nbytes // 4,), dtype=torch.float32, device=like.device), nbytes
+
+
+def nhwc_channel_stats(x, stats):
+    M, Cc = _cl(x)
+    ws, nbytes = _nhwc_ws(M, Cc, x)
+    call("avsep_nhwc_channel_stats", lib.ptr_cl(x), M, Cc, ptr(stats), ptr(ws), nbytes)
+
+
+def nhwc_affine_act(y, scale, shift, residual, act, res_scale=None, res_shift=None):
+    M, Cc = _cl(y)
+    z = torch.empty_like(y)                       # preserves the channels_last strides
+    call("avsep_nhwc_affine_act", lib.ptr_cl(y), ptr(scale), ptr(shift), lib.ptr_cl(residual), ptr(res_scale),
+         ptr(res_shift), act, M, Cc, lib.ptr_cl(z))
+    return z
+
+
+def nhwc_affine_act_bwd_(dz, y, scale, shift, residual, mean, invstd, act, bstats, res_scale=None, res_shift=None,
+                         stats_only=False):
+    """dz <- act'(scale*y+shift [+res]) * dz in place (or statistics only); accumulates bstats."""
+    M, Cc = _cl(y)
+    ws, nbytes = _nhwc_ws(M, Cc, y) if bstats is not None else (None, 0)
+    call("avsep_nhwc_affine_act_bwd", lib.ptr_cl(dz), lib.ptr_cl(y), ptr(scale), ptr(shift), lib.ptr_cl(residual),
+         ptr(res_scale), ptr(res_shift), ptr(mean), ptr(invstd), act, M, Cc, None if stats_only else lib.ptr_cl(dz),
+         ptr(bstats), ptr(ws), nbytes)
+    return dz
+
+
+def nhwc_bn_bwd_apply_(dz, y, pqr, out=None):
+    M, Cc = _cl(y)
+    dst = dz if out is None else out
+    call("avsep_nhwc_bn_bwd_apply", lib.ptr_cl(dz), lib.ptr_cl(y), ptr(pqr), M, Cc, lib.ptr_cl(dst))
+    return dst
+
+
 class Cat:
     def __init__(self, x0, x1, sc0=None, sh0=None, sc1=None, sh1=None, bcast0=False, hw=None):
         N, C0 = x0.shape[:2]

@@ -1,0 +1,129 @@
+"""ResNet-18 (dilated) frame trunk + fc conv, "hybrid" backend: convolutions on MIOpen's NHWC fp32 implicit-GEMM
+kernels (through aten::convolution / convolution_backward on channels-last tensors), everything between them —
+train-mode BatchNorm statistics, normalise + residual + ReLU, and their backward with the BatchNorm gradient folded
+as dy = p*dz + q*y + r — on this library's channels-last kernels (csrc/ops_nhwc.hip).
+
+Reference: models/vision_net.py:62-147 + torchvision BasicBlock.  Same launch plan as models/vision_hip.py except
+that relu(bn1(y1)) is materialised (MIOpen cannot fold it into its operand load).  Compared with the plain
+PyTorch-ROCm module graph ("torch" backend) this removes one full read+write pass per BatchNorm in each direction
+and the separate add / ReLU / threshold kernels of every BasicBlock tail; ONE autograd node for the whole trunk.
+"""
+import torch
+
+from .. import kernels as K
+from .. import lib
+from ..lib import ACT_NONE, ACT_RELU
+from .audio_net import _acc, _bn_back, _bn_run
+from .vision_hip import blocks_of, param_list
+
+aten = torch.ops.aten
+
+
+def _stats(c, like):
+    """fp64 [2*c] statistics buffer; the channels-last kernels overwrite it (no zero fill)."""
+    return torch.empty((2 * c,), dtype=torch.float64, device=like.device)
+
+
+def _conv(x, conv):
+    return aten.convolution(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, False, [0, 0], 1)
+
+
+def _conv_back(grads, g, x, conv, need_dx=True):
+    bias = [conv.out_channels] if conv.bias is not None else None
+    dx, dw, db = aten.convolution_backward(g, x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, False,
+                                           [0, 0], 1, [need_dx, True, conv.bias is not None])
+    _acc(grads, conv.weight, dw)
+    if conv.bias is not None:
+        _acc(grads, conv.bias, db)
+    return dx
+
+
+def _conv_bn(x, conv, bn, training):
+    y = _conv(x, conv)
+    st = None
+    if training:
+        st = _stats(conv.out_channels, y)
+        K.nhwc_channel_stats(y, st)
+    return y, _bn_run(bn, st, y.numel() // y.shape[1], training, y)
+
+
+def trunk_forward(net, x, training):
+    f = net.features
+    S = {"x": x}
+    S["y0"], S["bn0"] = _conv_bn(x, f[0], f[1], training)
+    S["a0"] = K.nhwc_affine_act(S["y0"], S["bn0"][0], S["bn0"][1], None, ACT_RELU)
+    z, S["idx"] = aten.max_pool2d_with_indices(S["a0"], [3, 3], [2, 2], [1, 1], [1, 1], False)
+    S["blocks"] = []
+    for blk in blocks_of(f):
+        R = {"mod": blk, "z": z}
+        R["y1"], R["bn1"] = _conv_bn(z, blk.conv1, blk.bn1, training)
+        R["a1"] = K.nhwc_affine_act(R["y1"], R["bn1"][0], R["bn1"][1], None, ACT_RELU)
+        R["y2"], R["bn2"] = _conv_bn(R["a1"], blk.conv2, blk.bn2, training)
+        if blk.downsample is not None:
+            R["yd"], R["bnd"] = _conv_bn(z, blk.downsample[0], blk.downsample[1], training)
+            z = K.nhwc_affine_act(R["y2"], R["bn2"][0], R["bn2"][1], R["yd"], ACT_RELU, R["bnd"][0], R["bnd"][1])
+        else:
+            z = K.nhwc_affine_act(R["y2"], R["bn2"][0], R["bn2"][1], R["z"], ACT_RELU)
+        S["blocks"].append(R)
+    S["zf"] = z
+    return S, _conv(z, net.fc)
+
+
+def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None):
+    bst = _stats(y.shape[1], y)
+    K.nhwc_affine_act_bwd_(g, y, bnrow[0], bnrow[1], res, bnrow[2], bnrow[3], ACT_RELU, bst, res_scale=rs, res_shift=rh)
+    return _bn_back(grads, bn_mod, bnrow, bst, y.numel() // y.shape[1])
+
+
+def trunk_backward(net, S, dout, grads):
+    f = net.features
+    g = _conv_back(grads, dout, S["zf"], net.fc)                       # dL/dz of the last block
+    for R in reversed(S["blocks"]):
+        blk = R["mod"]
+        ds = blk.downsample is not None
+        bnd = R.get("bnd")
+        pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
+                             rs=bnd[0] if ds else None, rh=bnd[1] if ds else None)   # g = dL/d(pre-ReLU sum)
+        dy2 = K.nhwc_bn_bwd_apply_(g, R["y2"], pqr2, out=torch.empty_like(g))
+        da = _conv_back(grads, dy2, R["a1"], blk.conv2)
+        del dy2
+        pqr1 = _relu_bn_back(grads, da, R["y1"], R["bn1"], blk.bn1)
+        K.nhwc_bn_bwd_apply_(da, R["y1"], pqr1)                         # da = dL/dy1
+        dz = _conv_back(grads, da, R["z"], blk.conv1)
+        del da
+        if ds:
+            bst = _stats(g.shape[1], g)                                 # BNd statistics of g (values of g unchanged)
+            K.nhwc_affine_act_bwd_(g, R["yd"], None, None, None, bnd[2], bnd[3], ACT_NONE, bst, stats_only=True)
+            pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, g.numel() // g.shape[1])
+            K.nhwc_bn_bwd_apply_(g, R["yd"], pqrd)                      # g = dL/dyd
+            dz.add_(_conv_back(grads, g, R["z"], blk.downsample[0]))
+        else:
+            dz.add_(g)
+        g = dz
+    g = aten.max_pool2d_with_indices_backward(g, S["a0"], [3, 3], [2, 2], [1, 1], [1, 1], False, S["idx"])
+    pqr0 = _relu_bn_back(grads, g, S["y0"], S["bn0"], f[1])
+    K.nhwc_bn_bwd_apply_(g, S["y0"], pqr0)
+    _conv_back(grads, g, S["x"], f[0], need_dx=False)                   # the frames need no gradient
+
+
+class _ResnetHybridFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        S, out = trunk_forward(net, x, net.training)
+        ctx.S, ctx.net, ctx.training = S, net, net.training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise lib.AvsepError("backward through the visual trunk needs train mode (batch statistics)")
+        grads = {}
+        trunk_backward(ctx.net, ctx.S, dout.contiguous(memory_format=torch.channels_last), grads)
+        ctx.S = None
+        return (None, None, *[grads.get(p) for p in param_list(ctx.net)])
+
+
+def run(net, x):
+    """fc(features(x)) for frames x [N,3,H,W]: MIOpen convolutions + channels-last HIP BatchNorm/ReLU/residual."""
+    lib.require_gpu(x)
+    return _ResnetHybridFn.apply(net, x.float().contiguous(memory_format=torch.channels_last), *param_list(net))

@@ -1,10 +1,13 @@
 """Per-frame visual encoder (reference: models/vision_net.py:20-147 + torchvision resnet18).
 
-Two backends for the ResNet-18 trunk + fc conv, selected by ``net.backend`` (default from the environment
-variable AVSEP_VISION_BACKEND, else "torch"): "torch" runs PyTorch-ROCm operators (BASELINE.json configs[1]:
-"vision on PyTorch-ROCm"); "hip" runs the trunk as one autograd node over libavsep_gfx950.so
-(models/vision_hip.py).  Both use the same parameter tensors.  The temporal mean that feeds the fusion is a
-HIP kernel either way.
+Three backends for the ResNet-18 trunk + fc conv, selected by ``net.backend`` (default from the environment
+variable AVSEP_VISION_BACKEND, else "hybrid"), all over the same parameter tensors:
+  "torch"  : the plain PyTorch-ROCm module graph (MIOpen convolutions and BatchNorm, ATen elementwise);
+  "hybrid" : MIOpen's NHWC convolutions (BASELINE.json configs[1]: "vision on PyTorch-ROCm") with everything between
+             them — BatchNorm statistics, normalise + residual + ReLU and their backward — on this library's
+             channels-last kernels, as one autograd node (models/vision_hybrid.py); the fastest today;
+  "hip"    : the whole trunk on libavsep_gfx950.so (models/vision_hip.py).
+The temporal mean that feeds the fusion is a HIP kernel in every case.
 torchvision is not part of this image, so the standard ResNet-18 architecture is restated here
 with torchvision's child order, which keeps the reference's ``features.{0,1,4..7}.*`` /
 ``fc.*`` checkpoint keys.  ``pretrained=True`` (models/__init__.py:63) cannot be honoured
@@ -17,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import kernels as K
-from . import vision_hip
+from . import vision_hip, vision_hybrid
 
 
 class BasicBlock(nn.Module):
@@ -60,12 +63,14 @@ class _TemporalMean(torch.autograd.Function):
 
 
 class _VisualBase(nn.Module):
-    backend = os.environ.get("AVSEP_VISION_BACKEND", "torch")
+    backend = os.environ.get("AVSEP_VISION_BACKEND", "hybrid")
 
     def _trunk(self, x):
         """fc(features(x)) for x [N,3,H,W]."""
         if self.backend == "hip":
             return vision_hip.run(self, x)
+        if self.backend == "hybrid":
+            return vision_hybrid.run(self, x)
         if self.backend != "torch":
             raise Exception("Unknown vision backend: " + str(self.backend))
         return self.fc(self.features(self._nhwc(x)))

@@ -302,7 +302,7 @@ class FlatSGD:
 
 def create_optimizer(nets, args, process_group=None, world_size=1):
     (net_sound, net_frame) = nets
-    nhwc = getattr(net_frame, "backend", None) == "torch"      # the MIOpen path wants OHWI conv weights
+    nhwc = getattr(net_frame, "backend", None) in ("torch", "hybrid")   # the MIOpen paths want OHWI conv weights
     groups = [{"params": list(net_sound.parameters()), "lr": args.lr_sound, "name": "sound"},
               {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound, "name": "frame_fc", "channels_last": nhwc}]
     if not args.fix_vis:

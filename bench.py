@@ -7,7 +7,8 @@ Workload at every N (weak scaling): BASELINE.json configs[1] per GPU — 2-sourc
 (AV: visual encoder on 2x3 frames, TWO U-Net passes, fusion, BCE) + backward + SGD(momentum, wd)
 (reference main.py:557-569).  Inputs are resident in HBM before the timed region.
 The U-Net / fusion / loss / STFT / prepare / SGD run on libavsep_gfx950.so; the ResNet-18 frame
-encoder runs on PyTorch-ROCm (that is what configs[1] names).
+encoder's convolutions run on PyTorch-ROCm/MIOpen (that is what configs[1] names), its BatchNorm / ReLU / residual
+glue on this library's channels-last kernels (the "hybrid" backend of models/vision_net.py).
 
 Launch: python bench.py --gpus N --steps K --warmup W   (N>1: under torch.distributed.run).
 Prints ONE JSON line on rank 0.
@@ -228,8 +229,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("AO" if o.ao else "AV") + " train step: 2-source mix, batch %d/GPU, 65535-sample "
                        "waveforms -> STFT 1022/256 -> 256x256 log-freq tiles, 3x224^2 frames/source, unet7+hidsep(sig)+"
-                       "resnet18dilated, BCE, SGD; HIP STFT+prepare+U-Net+fusion+loss+SGD, vision on PyTorch-ROCm "
-                       "(BASELINE configs[1])" % B,
+                       "resnet18dilated, BCE, SGD; HIP STFT+prepare+U-Net+fusion+loss+SGD, visual convolutions on PyTorch-ROCm/"
+                       "MIOpen with HIP BatchNorm/ReLU glue (BASELINE configs[1])" % B,
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "loss": float(err), "match_loss": float(match) if match is not None else None,
             "extra": None if ao_rate is None else {

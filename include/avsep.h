@@ -103,6 +103,29 @@ int avsep_conv2d_dgrad_up2x(const avsep_conv_desc* d, const float* w, const floa
                             int32_t acc0, avsep_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * The same BatchNorm / ReLU / residual pieces for channels-last activations ([N,H,W,C] viewed as [M, C];
+ * C % 4 == 0, C/4 a divisor of 256).  They sit between the MIOpen NHWC convolutions of the "hybrid" visual backend
+ * (torchvision resnet BasicBlock.forward: bn -> relu, bn2 + identity -> relu; vision_net.py:62-147).
+ * ------------------------------------------------------------------------- */
+/* statistics are two-stage (per-block partial rows in the workspace, then an fp64 reduce that OVERWRITES stats[2*C]:
+ * unlike the NCHW entry points these do not accumulate, so the caller needs no zero fill) */
+size_t avsep_nhwc_stats_workspace_bytes(int64_t M, int32_t C);
+int avsep_nhwc_channel_stats(const float* x, int64_t M, int32_t C, double* stats, void* workspace,
+                             size_t workspace_bytes, avsep_stream_t stream);
+int avsep_nhwc_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
+                          const float* res_scale, const float* res_shift, int32_t act, int64_t M, int32_t C,
+                          float* z, avsep_stream_t stream);
+/* dz_pre = act'(scale*y+shift [+ res_scale*residual+res_shift]) * dz (dz_pre may alias dz or be NULL = statistics
+ * only); bstats[2*C] = (sum dz_pre, sum dz_pre*xhat(y)) when bstats != NULL. */
+int avsep_nhwc_affine_act_bwd(const float* dz, const float* y, const float* scale, const float* shift,
+                              const float* residual, const float* res_scale, const float* res_shift,
+                              const float* mean, const float* invstd, int32_t act, int64_t M, int32_t C,
+                              float* dz_pre, double* bstats, void* workspace, size_t workspace_bytes,
+                              avsep_stream_t stream);
+int avsep_nhwc_bn_bwd_apply(const float* dz, const float* y, const float* pqr, int64_t M, int32_t C,
+                            float* out, avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * BatchNorm2d pieces (train-mode batch statistics; nn.BatchNorm2d at audio_net.py:37,65,67).
  * ------------------------------------------------------------------------- */
 /* stats[2*C] += per-channel (sum, sumsq) of x [N,C,HW]. */

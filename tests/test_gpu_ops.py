@@ -455,3 +455,45 @@ def test_bss_eval_vs_oracle(dev):
     assert abs(sir[0, 0].item() - 20.0) < 1.0 and abs(sdr[0, 1].item() - 40.0) < 1.0 and abs(sar[0, 1].item() - 40.0) < 1.0
     plain = 10 * np.log10((s[1, 0] ** 2).sum() / ((s[1, 0] - ests[1, 0]) ** 2).sum())
     assert sdr[1, 0].item() > 25 and plain < 3
+
+
+@pytest.mark.parametrize("N,C,H,W", [(4, 128, 8, 8), (3, 64, 9, 7), (2, 512, 4, 4), (5, 256, 6, 10), (2, 16, 5, 5),
+                                     (40, 64, 56, 56)])
+def test_channels_last_bn_pieces(dev, N, C, H, W):
+    """csrc/ops_nhwc.hip against torch: two-stage statistics, normalise + residual (with its own affine) + ReLU, its
+    backward with the BatchNorm-backward sums, and the folded BatchNorm gradient, on channels-last tensors."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(C + H)
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)   # noqa: E731
+    y, r, dz = (torch.randn(N, C, H, W, generator=g) for _ in range(3))
+    sc, sh, rs, rh = (torch.randn(C, generator=g) for _ in range(4))
+    mean, inv = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    st = torch.full((2 * C,), float("nan"), dtype=torch.float64, device=dev)          # overwritten, not accumulated
+    K.nhwc_channel_stats(cl(y), st)
+    assert_close(st, torch.cat([y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))]), 1e-5, "stats")
+    v = lambda t: t.view(1, -1, 1, 1)   # noqa: E731
+    for use_res, use_rs in ((False, False), (True, False), (True, True)):
+        pre = y * v(sc) + v(sh)
+        if use_res:
+            pre = pre + (r * v(rs) + v(rh) if use_rs else r)
+        gpre = dz * (pre > 0).float()
+        z = K.nhwc_affine_act(cl(y), sc.to(dev), sh.to(dev), cl(r) if use_res else None, 1,
+                              rs.to(dev) if use_rs else None, rh.to(dev) if use_rs else None)
+        assert_close(z, torch.relu(pre), 1e-6, "affine + residual + relu")
+        bst = torch.full((2 * C,), float("nan"), dtype=torch.float64, device=dev)
+        d = cl(dz).clone()
+        K.nhwc_affine_act_bwd_(d, cl(y), sc.to(dev), sh.to(dev), cl(r) if use_res else None, mean.to(dev), inv.to(dev), 1,
+                               bst, res_scale=rs.to(dev) if use_rs else None, res_shift=rh.to(dev) if use_rs else None)
+        assert_close(d, gpre, 1e-6, "masked gradient")
+        xhat = (y - v(mean)) * v(inv)
+        assert_close(bst, torch.cat([gpre.double().sum((0, 2, 3)), (gpre.double() * xhat.double()).sum((0, 2, 3))]), 1e-5,
+                     "BatchNorm-backward sums")
+        bst2 = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        d2 = cl(dz).clone()
+        K.nhwc_affine_act_bwd_(d2, cl(y), None, None, None, mean.to(dev), inv.to(dev), 0, bst2, stats_only=True)
+        assert torch.equal(d2, cl(dz))
+        assert_close(bst2, torch.cat([dz.double().sum((0, 2, 3)), (dz.double() * xhat.double()).sum((0, 2, 3))]), 1e-5,
+                     "statistics-only pass")
+    pqr = torch.randn(3, C, generator=g)
+    out = K.nhwc_bn_bwd_apply_(cl(dz).clone(), cl(y), pqr.to(dev))
+    assert_close(out, v(pqr[0]) * dz + v(pqr[1]) * y + v(pqr[2]), 1e-6, "folded BatchNorm gradient")
