@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void nhwc_affine_act_kernel(const float* __res
                                                               const float* __restrict__ rshift, int act, long long n4,
                                                               int C4, float* __restrict__ z) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const int cq = (int)(i % C4);
+    const int cq = (int)i & (C4 - 1);                      // C4 is a power of two (it divides 256)
     f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
     if (scale) v = v * reinterpret_cast<const f32x4*>(scale)[cq] + reinterpret_cast<const f32x4*>(shift)[cq];
     if (res) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void nhwc_bn_bwd_apply_kernel(const float* dz,
                                                                 const float* __restrict__ pqr, long long n4, int C4,
                                                                 float* out) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const int cq = (int)(i % C4);
+    const int cq = (int)i & (C4 - 1);
     const f32x4 p = reinterpret_cast<const f32x4*>(pqr)[cq], q = reinterpret_cast<const f32x4*>(pqr)[C4 + cq],
                 r = reinterpret_cast<const f32x4*>(pqr)[2 * C4 + cq];
     reinterpret_cast<f32x4*>(out)[i] = p * reinterpret_cast<const f32x4*>(dz)[i] + q * reinterpret_cast<const f32x4*>(y)[i] + r;
