@@ -11,7 +11,8 @@
 // fp64 by nhwc_stats_reduce_kernel (every block would otherwise hit the same 2*C addresses with atomics: measured
 // 3x slower than the two-stage form).
 template <bool BWD>
-__global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* __restrict__ dz, const float* __restrict__ dz2,
+                                                         const float* __restrict__ y,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ res, const float* __restrict__ rscale,
                                                          const float* __restrict__ rshift, const float* __restrict__ mean,
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* __restrict
       yv[u] = reinterpret_cast<const f32x4*>(y)[o];
       if constexpr (BWD) {
         dv[u] = reinterpret_cast<const f32x4*>(dz)[o];
+        if (dz2) dv[u] += reinterpret_cast<const f32x4*>(dz2)[o];   // second branch of a residual join
         if (res) rv[u] = reinterpret_cast<const f32x4*>(res)[o];
       }
     }
@@ -151,8 +153,8 @@ extern "C" int avsep_nhwc_channel_stats(const float* x, int64_t M, int32_t C, do
   if (!x || !stats || !nhwc_ok(M, C)) return AVSEP_ERR_ARG;
   if (!workspace || workspace_bytes < avsep_nhwc_stats_workspace_bytes(M, C)) return AVSEP_ERR_WORKSPACE;
   const int nb = nhwc_grid(M, C, NHWC_STAT_BLOCKS);
-  hipLaunchKernelGGL(nhwc_stats_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, nullptr, x, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, (long long)M, C, nullptr, (float*)workspace);
+  hipLaunchKernelGGL(nhwc_stats_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, x, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (long long)M, C, nullptr, (float*)workspace);
   AVSEP_LAUNCH_CHECK();
   return nhwc_reduce((const float*)workspace, nb, C, stats, (hipStream_t)stream);
 }
@@ -168,7 +170,8 @@ extern "C" int avsep_nhwc_affine_act(const float* y, const float* scale, const f
   return AVSEP_OK;
 }
 
-extern "C" int avsep_nhwc_affine_act_bwd(const float* dz, const float* y, const float* scale, const float* shift,
+extern "C" int avsep_nhwc_affine_act_bwd(const float* dz, const float* dz2, const float* y, const float* scale,
+                                         const float* shift,
                                          const float* residual, const float* res_scale, const float* res_shift,
                                          const float* mean, const float* invstd, int32_t act, int64_t M, int32_t C,
                                          float* dz_pre, double* bstats, void* workspace, size_t workspace_bytes,
@@ -178,7 +181,7 @@ extern "C" int avsep_nhwc_affine_act_bwd(const float* dz, const float* y, const 
   if (bstats && (!mean || !invstd)) return AVSEP_ERR_ARG;
   if (bstats && (!workspace || workspace_bytes < avsep_nhwc_stats_workspace_bytes(M, C))) return AVSEP_ERR_WORKSPACE;
   const int nb = nhwc_grid(M, C, bstats ? NHWC_STAT_BLOCKS : 4096);
-  hipLaunchKernelGGL(nhwc_stats_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dz, y, scale, shift, residual,
+  hipLaunchKernelGGL(nhwc_stats_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dz, dz2, y, scale, shift, residual,
                      res_scale, res_shift, mean, invstd, act, (long long)M, C, dz_pre, bstats ? (float*)workspace : nullptr);
   AVSEP_LAUNCH_CHECK();
   return bstats ? nhwc_reduce((const float*)workspace, nb, C, bstats, (hipStream_t)stream) : AVSEP_OK;

@@ -166,11 +166,11 @@ def nhwc_affine_act(y, scale, shift, residual, act, res_scale=None, res_shift=No
 
 
 def nhwc_affine_act_bwd_(dz, y, scale, shift, residual, mean, invstd, act, bstats, res_scale=None, res_shift=None,
-                         stats_only=False):
-    """dz <- act'(scale*y+shift [+res]) * dz in place (or statistics only); accumulates bstats."""
+                         stats_only=False, dz2=None):
+    """dz <- act'(scale*y+shift [+res]) * (dz [+ dz2]) in place (or statistics only); writes bstats."""
     M, Cc = _cl(y)
     ws, nbytes = _nhwc_ws(M, Cc, y) if bstats is not None else (None, 0)
-    call("avsep_nhwc_affine_act_bwd", lib.ptr_cl(dz), lib.ptr_cl(y), ptr(scale), ptr(shift), lib.ptr_cl(residual),
+    call("avsep_nhwc_affine_act_bwd", lib.ptr_cl(dz), lib.ptr_cl(dz2), lib.ptr_cl(y), ptr(scale), ptr(shift), lib.ptr_cl(residual),
          ptr(res_scale), ptr(res_shift), ptr(mean), ptr(invstd), act, M, Cc, None if stats_only else lib.ptr_cl(dz),
          ptr(bstats), ptr(ws), nbytes)
     return dz

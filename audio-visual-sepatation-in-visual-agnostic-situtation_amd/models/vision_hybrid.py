@@ -69,21 +69,23 @@ def trunk_forward(net, x, training):
     return S, _conv(z, net.fc)
 
 
-def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None):
+def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None, g2=None):
+    """g <- relu'(.) * (g [+ g2]) in place (g2: the other incoming gradient of a residual join, summed on the fly)."""
     bst = _stats(y.shape[1], y)
-    K.nhwc_affine_act_bwd_(g, y, bnrow[0], bnrow[1], res, bnrow[2], bnrow[3], ACT_RELU, bst, res_scale=rs, res_shift=rh)
+    K.nhwc_affine_act_bwd_(g, y, bnrow[0], bnrow[1], res, bnrow[2], bnrow[3], ACT_RELU, bst, res_scale=rs, res_shift=rh,
+                           dz2=g2)
     return _bn_back(grads, bn_mod, bnrow, bst, y.numel() // y.shape[1])
 
 
 def trunk_backward(net, S, dout, grads):
     f = net.features
-    g = _conv_back(grads, dout, S["zf"], net.fc)                       # dL/dz of the last block
+    g, g2 = _conv_back(grads, dout, S["zf"], net.fc), None           # dL/dz of the last block (+ its second branch)
     for R in reversed(S["blocks"]):
         blk = R["mod"]
         ds = blk.downsample is not None
         bnd = R.get("bnd")
         pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
-                             rs=bnd[0] if ds else None, rh=bnd[1] if ds else None)   # g = dL/d(pre-ReLU sum)
+                             rs=bnd[0] if ds else None, rh=bnd[1] if ds else None, g2=g2)   # g = dL/d(pre-ReLU sum)
         dy2 = K.nhwc_bn_bwd_apply_(g, R["y2"], pqr2, out=torch.empty_like(g))
         da = _conv_back(grads, dy2, R["a1"], blk.conv2)
         del dy2
@@ -96,10 +98,11 @@ def trunk_backward(net, S, dout, grads):
             K.nhwc_affine_act_bwd_(g, R["yd"], None, None, None, bnd[2], bnd[3], ACT_NONE, bst, stats_only=True)
             pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, g.numel() // g.shape[1])
             K.nhwc_bn_bwd_apply_(g, R["yd"], pqrd)                      # g = dL/dyd
-            dz.add_(_conv_back(grads, g, R["z"], blk.downsample[0]))
+            g2 = _conv_back(grads, g, R["z"], blk.downsample[0])
         else:
-            dz.add_(g)
-        g = dz
+            g2 = g                                                      # identity branch
+        g = dz                                                          # the join (g + g2) is summed by the next consumer
+    g.add_(g2)
     g = aten.max_pool2d_with_indices_backward(g, S["a0"], [3, 3], [2, 2], [1, 1], [1, 1], False, S["idx"])
     pqr0 = _relu_bn_back(grads, g, S["y0"], S["bn0"], f[1])
     K.nhwc_bn_bwd_apply_(g, S["y0"], pqr0)

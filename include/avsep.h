@@ -115,9 +115,10 @@ int avsep_nhwc_channel_stats(const float* x, int64_t M, int32_t C, double* stats
 int avsep_nhwc_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
                           const float* res_scale, const float* res_shift, int32_t act, int64_t M, int32_t C,
                           float* z, avsep_stream_t stream);
-/* dz_pre = act'(scale*y+shift [+ res_scale*residual+res_shift]) * dz (dz_pre may alias dz or be NULL = statistics
- * only); bstats[2*C] = (sum dz_pre, sum dz_pre*xhat(y)) when bstats != NULL. */
-int avsep_nhwc_affine_act_bwd(const float* dz, const float* y, const float* scale, const float* shift,
+/* dz_pre = act'(scale*y+shift [+ res_scale*residual+res_shift]) * (dz [+ dz2]) (dz2: the second incoming gradient of
+ * a residual join, NULL if none; dz_pre may alias dz or be NULL = statistics only);
+ * bstats[2*C] = (sum dz_pre, sum dz_pre*xhat(y)) when bstats != NULL. */
+int avsep_nhwc_affine_act_bwd(const float* dz, const float* dz2, const float* y, const float* scale, const float* shift,
                               const float* residual, const float* res_scale, const float* res_shift,
                               const float* mean, const float* invstd, int32_t act, int64_t M, int32_t C,
                               float* dz_pre, double* bstats, void* workspace, size_t workspace_bytes,

@@ -494,6 +494,11 @@ def test_channels_last_bn_pieces(dev, N, C, H, W):
         assert torch.equal(d2, cl(dz))
         assert_close(bst2, torch.cat([dz.double().sum((0, 2, 3)), (dz.double() * xhat.double()).sum((0, 2, 3))]), 1e-5,
                      "statistics-only pass")
+        d3 = cl(dz).clone()                                  # residual join: the second gradient is summed on the fly
+        K.nhwc_affine_act_bwd_(d3, cl(y), sc.to(dev), sh.to(dev), cl(r) if use_res else None, mean.to(dev), inv.to(dev), 1,
+                               bst, res_scale=rs.to(dev) if use_rs else None, res_shift=rh.to(dev) if use_rs else None,
+                               dz2=cl(r))
+        assert_close(d3, (dz + r) * (pre > 0).float(), 1e-6, "masked sum of two gradients")
     pqr = torch.randn(3, C, generator=g)
     out = K.nhwc_bn_bwd_apply_(cl(dz).clone(), cl(y), pqr.to(dev))
     assert_close(out, v(pqr[0]) * dz + v(pqr[1]) * y + v(pqr[2]), 1e-6, "folded BatchNorm gradient")
