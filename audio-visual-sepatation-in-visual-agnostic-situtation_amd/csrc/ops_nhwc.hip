@@ -77,24 +77,61 @@ __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* __restrict
   }
 }
 
-// stats[i] = sum_b partial[b][i]   (fp64, overwrites: no zero fill needed), i < n = 2*C.  Block = 64 columns x 16 row lanes (coalesced 256-byte rows,
-// 16 independent chains per column), LDS tree over the row lanes.
-__global__ __launch_bounds__(1024) void nhwc_stats_reduce_kernel(const float* __restrict__ partial, int nblocks, int n,
-                                                                 double* __restrict__ stats) {
-  __shared__ double red[16][64];
-  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6, i = blockIdx.x * 64 + col;
-  double s = 0.0;
-  if (i < n) {
+// Second stage: per channel, (S1, S2) = sum over the partial rows (fp64), written to stats[2*C]; optionally followed
+// in the same launch by what the caller would do next with them:
+//   mode 1 (forward):  BatchNorm2d finalisation (scale, shift, mean, invstd, running statistics) = avsep_bn_finalize
+//   mode 2 (backward): dgamma, dbeta and the folded-gradient coefficients (p, q, r)               = avsep_bn_bwd_coeffs
+// Block = 64 channels x 16 row lanes (coalesced 256-byte partial rows, 16 independent chains per column).
+struct NhwcTail {
+  int mode;
+  double count;
+  const float *gamma, *beta, *mean_in, *invstd_in;
+  float *running_mean, *running_var, *scale, *shift, *mean_o, *invstd_o, *dgamma, *dbeta, *pqr;
+  float momentum, eps;
+};
+__global__ __launch_bounds__(1024) void nhwc_stats_reduce_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                                 double* __restrict__ stats, NhwcTail t) {
+  __shared__ double red[2][16][64];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + col;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
 #pragma unroll 4
-    for (int b = rl; b < nblocks; b += 16) s += (double)partial[(long long)b * n + i];
+    for (int b = rl; b < nblocks; b += 16) {
+      s1 += (double)partial[(long long)b * 2 * C + c];
+      s2 += (double)partial[(long long)b * 2 * C + C + c];
+    }
   }
-  red[rl][col] = s;
+  red[0][rl][col] = s1;
+  red[1][rl][col] = s2;
   __syncthreads();
-  if (rl == 0 && i < n) {
-    double t = 0.0;
+  if (rl != 0 || c >= C) return;
+  s1 = s2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) t += red[j][col];
-    stats[i] = t;
+  for (int j = 0; j < 16; ++j) { s1 += red[0][j][col]; s2 += red[1][j][col]; }
+  if (stats) { stats[c] = s1; stats[C + c] = s2; }
+  if (t.mode == 1) {            // same arithmetic as bn_finalize_kernel (ops.hip), training mode
+    const double mean = s1 / t.count;
+    double var = s2 / t.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (t.running_mean) {
+      const double unb = t.count > 1.0 ? var * t.count / (t.count - 1.0) : var;
+      t.running_mean[c] = (float)((1.0 - t.momentum) * t.running_mean[c] + t.momentum * mean);
+      t.running_var[c] = (float)((1.0 - t.momentum) * t.running_var[c] + t.momentum * unb);
+    }
+    const float invstd = (float)(1.0 / sqrt(var + (double)t.eps));
+    const float g = t.gamma ? t.gamma[c] : 1.f, b = t.beta ? t.beta[c] : 0.f, sc = g * invstd;
+    t.scale[c] = sc;
+    t.shift[c] = b - (float)mean * sc;
+    t.mean_o[c] = (float)mean;
+    t.invstd_o[c] = invstd;
+  } else if (t.mode == 2) {     // same arithmetic as bn_bwd_coeffs_kernel (ops.hip)
+    const double g = t.gamma ? t.gamma[c] : 1.0, is = t.invstd_in[c], mu = t.mean_in[c];
+    const double p = g * is, q = -p * is * s2 / t.count, r = -p * s1 / t.count - q * mu;
+    if (t.dgamma) t.dgamma[c] = (float)s2;
+    if (t.dbeta) t.dbeta[c] = (float)s1;
+    t.pqr[c] = (float)p;
+    t.pqr[C + c] = (float)q;
+    t.pqr[2 * C + c] = (float)r;
   }
 }
 
@@ -130,6 +167,7 @@ __global__ __launch_bounds__(256) void nhwc_bn_bwd_apply_kernel(const float* dz,
   }
 }
 
+constexpr int NHWC_STAT_BLOCKS = 1024;
 static bool nhwc_ok(long long M, int C) {
   return M > 0 && C >= 4 && (C & 3) == 0 && C <= 1024 && 256 % (C >> 2) == 0;
 }
@@ -138,12 +176,18 @@ static int nhwc_grid(long long M, int C, int cap) {
   return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
-constexpr int NHWC_STAT_BLOCKS = 1024;
 extern "C" size_t avsep_nhwc_stats_workspace_bytes(int64_t M, int32_t C) {
   return nhwc_ok(M, C) ? (size_t)nhwc_grid(M, C, NHWC_STAT_BLOCKS) * 2 * C * sizeof(float) : 0;
 }
-static int nhwc_reduce(const float* partial, int nblocks, int C, double* stats, hipStream_t st) {
-  hipLaunchKernelGGL(nhwc_stats_reduce_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, partial, nblocks, 2 * C, stats);
+static int nhwc_reduce(const float* partial, int nblocks, int C, double* stats, const NhwcTail& t, hipStream_t st) {
+  hipLaunchKernelGGL(nhwc_stats_reduce_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, partial, nblocks, C, stats, t);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+static int nhwc_launch_stats(const float* x, long long M, int C, void* workspace, hipStream_t st) {
+  const int nb = nhwc_grid(M, C, NHWC_STAT_BLOCKS);
+  hipLaunchKernelGGL(nhwc_stats_kernel<false>, dim3(nb), dim3(256), 0, st, nullptr, nullptr, x, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, 0, M, C, nullptr, (float*)workspace);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
@@ -152,11 +196,27 @@ extern "C" int avsep_nhwc_channel_stats(const float* x, int64_t M, int32_t C, do
                                         size_t workspace_bytes, avsep_stream_t stream) {
   if (!x || !stats || !nhwc_ok(M, C)) return AVSEP_ERR_ARG;
   if (!workspace || workspace_bytes < avsep_nhwc_stats_workspace_bytes(M, C)) return AVSEP_ERR_WORKSPACE;
-  const int nb = nhwc_grid(M, C, NHWC_STAT_BLOCKS);
-  hipLaunchKernelGGL(nhwc_stats_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, x, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (long long)M, C, nullptr, (float*)workspace);
-  AVSEP_LAUNCH_CHECK();
-  return nhwc_reduce((const float*)workspace, nb, C, stats, (hipStream_t)stream);
+  int rc = nhwc_launch_stats(x, M, C, workspace, (hipStream_t)stream);
+  if (rc) return rc;
+  return nhwc_reduce((const float*)workspace, nhwc_grid(M, C, NHWC_STAT_BLOCKS), C, stats, NhwcTail{}, (hipStream_t)stream);
+}
+
+// statistics of x + BatchNorm2d finalisation in the second stage (training mode): avsep_nhwc_channel_stats followed by
+// avsep_bn_finalize, one launch fewer
+extern "C" int avsep_nhwc_bn_train_stats(const float* x, int64_t M, int32_t C, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                                         float* shift, float* mean, float* invstd, void* workspace, size_t workspace_bytes,
+                                         avsep_stream_t stream) {
+  if (!x || !scale || !shift || !mean || !invstd || !nhwc_ok(M, C)) return AVSEP_ERR_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return AVSEP_ERR_ARG;
+  if (!workspace || workspace_bytes < avsep_nhwc_stats_workspace_bytes(M, C)) return AVSEP_ERR_WORKSPACE;
+  int rc = nhwc_launch_stats(x, M, C, workspace, (hipStream_t)stream);
+  if (rc) return rc;
+  NhwcTail t{};
+  t.mode = 1; t.count = (double)M; t.gamma = gamma; t.beta = beta; t.running_mean = running_mean;
+  t.running_var = running_var; t.momentum = momentum; t.eps = eps; t.scale = scale; t.shift = shift; t.mean_o = mean;
+  t.invstd_o = invstd;
+  return nhwc_reduce((const float*)workspace, nhwc_grid(M, C, NHWC_STAT_BLOCKS), C, nullptr, t, (hipStream_t)stream);
 }
 
 extern "C" int avsep_nhwc_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
@@ -174,17 +234,24 @@ extern "C" int avsep_nhwc_affine_act_bwd(const float* dz, const float* dz2, cons
                                          const float* shift,
                                          const float* residual, const float* res_scale, const float* res_shift,
                                          const float* mean, const float* invstd, int32_t act, int64_t M, int32_t C,
-                                         float* dz_pre, double* bstats, void* workspace, size_t workspace_bytes,
-                                         avsep_stream_t stream) {
-  if (!dz || !y || !nhwc_ok(M, C) || (!dz_pre && !bstats)) return AVSEP_ERR_ARG;
+                                         float* dz_pre, double* bstats, const float* gamma, float* dgamma, float* dbeta,
+                                         float* pqr, void* workspace, size_t workspace_bytes, avsep_stream_t stream) {
+  if (!dz || !y || !nhwc_ok(M, C) || (!dz_pre && !bstats && !pqr)) return AVSEP_ERR_ARG;
   if ((scale == nullptr) != (shift == nullptr) || (res_scale == nullptr) != (res_shift == nullptr)) return AVSEP_ERR_ARG;
-  if (bstats && (!mean || !invstd)) return AVSEP_ERR_ARG;
-  if (bstats && (!workspace || workspace_bytes < avsep_nhwc_stats_workspace_bytes(M, C))) return AVSEP_ERR_WORKSPACE;
-  const int nb = nhwc_grid(M, C, bstats ? NHWC_STAT_BLOCKS : 4096);
+  const bool want = bstats || pqr;
+  if (want && (!mean || !invstd)) return AVSEP_ERR_ARG;
+  if (want && (!workspace || workspace_bytes < avsep_nhwc_stats_workspace_bytes(M, C))) return AVSEP_ERR_WORKSPACE;
+  const int nb = nhwc_grid(M, C, want ? NHWC_STAT_BLOCKS : 4096);
   hipLaunchKernelGGL(nhwc_stats_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dz, dz2, y, scale, shift, residual,
-                     res_scale, res_shift, mean, invstd, act, (long long)M, C, dz_pre, bstats ? (float*)workspace : nullptr);
+                     res_scale, res_shift, mean, invstd, act, (long long)M, C, dz_pre, want ? (float*)workspace : nullptr);
   AVSEP_LAUNCH_CHECK();
-  return bstats ? nhwc_reduce((const float*)workspace, nb, C, bstats, (hipStream_t)stream) : AVSEP_OK;
+  if (!want) return AVSEP_OK;
+  NhwcTail t{};
+  if (pqr) {   // BatchNorm-backward coefficients of bn(y) in the second stage (= avsep_bn_bwd_coeffs)
+    t.mode = 2; t.count = (double)M; t.gamma = gamma; t.mean_in = mean; t.invstd_in = invstd; t.dgamma = dgamma;
+    t.dbeta = dbeta; t.pqr = pqr;
+  }
+  return nhwc_reduce((const float*)workspace, nb, C, bstats, t, (hipStream_t)stream);
 }
 
 extern "C" int avsep_nhwc_bn_bwd_apply(const float* dz, const float* y, const float* pqr, int64_t M, int32_t C, float* out,

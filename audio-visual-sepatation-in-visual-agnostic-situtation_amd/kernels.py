@@ -157,6 +157,16 @@ def nhwc_channel_stats(x, stats):
     call("avsep_nhwc_channel_stats", lib.ptr_cl(x), M, Cc, ptr(stats), ptr(ws), nbytes)
 
 
+def nhwc_bn_train_stats(x, gamma, beta, rmean, rvar, momentum, eps):
+    """Train-mode BatchNorm2d statistics of a channels-last tensor + finalisation: rows (scale, shift, mean, invstd)."""
+    M, Cc = _cl(x)
+    ws, nbytes = _nhwc_ws(M, Cc, x)
+    out = _f32((4, Cc), x)
+    call("avsep_nhwc_bn_train_stats", lib.ptr_cl(x), M, Cc, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(momentum),
+         float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(ws), nbytes)
+    return out
+
+
 def nhwc_affine_act(y, scale, shift, residual, act, res_scale=None, res_shift=None):
     M, Cc = _cl(y)
     z = torch.empty_like(y)                       # preserves the channels_last strides
@@ -166,14 +176,18 @@ def nhwc_affine_act(y, scale, shift, residual, act, res_scale=None, res_shift=No
 
 
 def nhwc_affine_act_bwd_(dz, y, scale, shift, residual, mean, invstd, act, bstats, res_scale=None, res_shift=None,
-                         stats_only=False, dz2=None):
-    """dz <- act'(scale*y+shift [+res]) * (dz [+ dz2]) in place (or statistics only); writes bstats."""
+                         stats_only=False, dz2=None, gamma=None, coeffs=False):
+    """dz <- act'(scale*y+shift [+res]) * (dz [+ dz2]) in place (or statistics only); writes bstats.  With `coeffs` the
+    second stage also produces (dgamma, dbeta, pqr) of bn(y) with weight `gamma`, which are returned."""
     M, Cc = _cl(y)
-    ws, nbytes = _nhwc_ws(M, Cc, y) if bstats is not None else (None, 0)
+    ws, nbytes = _nhwc_ws(M, Cc, y) if (bstats is not None or coeffs) else (None, 0)
+    dgamma = dbeta = pqr = None
+    if coeffs:
+        dgamma, dbeta, pqr = _f32((Cc,), y), _f32((Cc,), y), _f32((3, Cc), y)
     call("avsep_nhwc_affine_act_bwd", lib.ptr_cl(dz), lib.ptr_cl(dz2), lib.ptr_cl(y), ptr(scale), ptr(shift), lib.ptr_cl(residual),
          ptr(res_scale), ptr(res_shift), ptr(mean), ptr(invstd), act, M, Cc, None if stats_only else lib.ptr_cl(dz),
-         ptr(bstats), ptr(ws), nbytes)
-    return dz
+         ptr(bstats), ptr(gamma), ptr(dgamma), ptr(dbeta), ptr(pqr), ptr(ws), nbytes)
+    return (dgamma, dbeta, pqr) if coeffs else dz
 
 
 def nhwc_bn_bwd_apply_(dz, y, pqr, out=None):

@@ -13,15 +13,10 @@ import torch
 from .. import kernels as K
 from .. import lib
 from ..lib import ACT_NONE, ACT_RELU
-from .audio_net import _acc, _bn_back, _bn_run
+from .audio_net import BN_EPS, BN_MOMENTUM, _acc, _bn_run
 from .vision_hip import blocks_of, param_list
 
 aten = torch.ops.aten
-
-
-def _stats(c, like):
-    """fp64 [2*c] statistics buffer; the channels-last kernels overwrite it (no zero fill)."""
-    return torch.empty((2 * c,), dtype=torch.float64, device=like.device)
 
 
 def _conv(x, conv):
@@ -40,11 +35,12 @@ def _conv_back(grads, g, x, conv, need_dx=True):
 
 def _conv_bn(x, conv, bn, training):
     y = _conv(x, conv)
-    st = None
-    if training:
-        st = _stats(conv.out_channels, y)
-        K.nhwc_channel_stats(y, st)
-    return y, _bn_run(bn, st, y.numel() // y.shape[1], training, y)
+    if not training:
+        return y, _bn_run(bn, None, y.numel() // y.shape[1], False, y)
+    rows = K.nhwc_bn_train_stats(y, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, BN_MOMENTUM,
+                                 BN_EPS)                   # statistics + finalisation: two launches
+    bn.num_batches_tracked += 1
+    return y, rows
 
 
 def trunk_forward(net, x, training):
@@ -69,12 +65,16 @@ def trunk_forward(net, x, training):
     return S, _conv(z, net.fc)
 
 
-def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None, g2=None):
-    """g <- relu'(.) * (g [+ g2]) in place (g2: the other incoming gradient of a residual join, summed on the fly)."""
-    bst = _stats(y.shape[1], y)
-    K.nhwc_affine_act_bwd_(g, y, bnrow[0], bnrow[1], res, bnrow[2], bnrow[3], ACT_RELU, bst, res_scale=rs, res_shift=rh,
-                           dz2=g2)
-    return _bn_back(grads, bn_mod, bnrow, bst, y.numel() // y.shape[1])
+def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None, g2=None, act=ACT_RELU, stats_only=False):
+    """g <- act'(.) * (g [+ g2]) in place (g2: the other incoming gradient of a residual join, summed on the fly);
+    accumulates the BatchNorm parameter gradients of bn(y) and returns its folded-gradient coefficients (p, q, r)."""
+    dgamma, dbeta, pqr = K.nhwc_affine_act_bwd_(g, y, bnrow[0] if not stats_only else None,
+                                                bnrow[1] if not stats_only else None, res, bnrow[2], bnrow[3], act, None,
+                                                res_scale=rs, res_shift=rh, dz2=g2, stats_only=stats_only,
+                                                gamma=bn_mod.weight.detach(), coeffs=True)
+    _acc(grads, bn_mod.weight, dgamma)
+    _acc(grads, bn_mod.bias, dbeta)
+    return pqr
 
 
 def trunk_backward(net, S, dout, grads):
@@ -94,9 +94,7 @@ def trunk_backward(net, S, dout, grads):
         dz = _conv_back(grads, da, R["z"], blk.conv1)
         del da
         if ds:
-            bst = _stats(g.shape[1], g)                                 # BNd statistics of g (values of g unchanged)
-            K.nhwc_affine_act_bwd_(g, R["yd"], None, None, None, bnd[2], bnd[3], ACT_NONE, bst, stats_only=True)
-            pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, g.numel() // g.shape[1])
+            pqrd = _relu_bn_back(grads, g, R["yd"], bnd, blk.downsample[1], act=ACT_NONE, stats_only=True)   # g unchanged
             K.nhwc_bn_bwd_apply_(g, R["yd"], pqrd)                      # g = dL/dyd
             g2 = _conv_back(grads, g, R["z"], blk.downsample[0])
         else:

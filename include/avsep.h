@@ -115,14 +115,20 @@ int avsep_nhwc_channel_stats(const float* x, int64_t M, int32_t C, double* stats
 int avsep_nhwc_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
                           const float* res_scale, const float* res_shift, int32_t act, int64_t M, int32_t C,
                           float* z, avsep_stream_t stream);
+/* avsep_nhwc_channel_stats + avsep_bn_finalize (training mode, count = M) with the finalisation in the second stage */
+int avsep_nhwc_bn_train_stats(const float* x, int64_t M, int32_t C, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps,
+                              float* scale, float* shift, float* mean, float* invstd, void* workspace,
+                              size_t workspace_bytes, avsep_stream_t stream);
 /* dz_pre = act'(scale*y+shift [+ res_scale*residual+res_shift]) * (dz [+ dz2]) (dz2: the second incoming gradient of
  * a residual join, NULL if none; dz_pre may alias dz or be NULL = statistics only);
- * bstats[2*C] = (sum dz_pre, sum dz_pre*xhat(y)) when bstats != NULL. */
+ * bstats[2*C] = (sum dz_pre, sum dz_pre*xhat(y)) when bstats != NULL; when pqr != NULL the second stage also emits
+ * dgamma, dbeta and pqr[3*C] of bn(y) (= avsep_bn_bwd_coeffs with count = M; gamma NULL = ones). */
 int avsep_nhwc_affine_act_bwd(const float* dz, const float* dz2, const float* y, const float* scale, const float* shift,
                               const float* residual, const float* res_scale, const float* res_shift,
                               const float* mean, const float* invstd, int32_t act, int64_t M, int32_t C,
-                              float* dz_pre, double* bstats, void* workspace, size_t workspace_bytes,
-                              avsep_stream_t stream);
+                              float* dz_pre, double* bstats, const float* gamma, float* dgamma, float* dbeta,
+                              float* pqr, void* workspace, size_t workspace_bytes, avsep_stream_t stream);
 int avsep_nhwc_bn_bwd_apply(const float* dz, const float* y, const float* pqr, int64_t M, int32_t C,
                             float* out, avsep_stream_t stream);
 

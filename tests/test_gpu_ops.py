@@ -502,3 +502,25 @@ def test_channels_last_bn_pieces(dev, N, C, H, W):
     pqr = torch.randn(3, C, generator=g)
     out = K.nhwc_bn_bwd_apply_(cl(dz).clone(), cl(y), pqr.to(dev))
     assert_close(out, v(pqr[0]) * dz + v(pqr[1]) * y + v(pqr[2]), 1e-6, "folded BatchNorm gradient")
+    # second-stage tails: statistics + finalisation, and backward sums + coefficients, against the two-call forms
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    rm2, rv2 = rm.clone(), rv.clone()
+    rows = K.nhwc_bn_train_stats(cl(y), gamma.to(dev), beta.to(dev), rm, rv, 0.1, 1e-5)
+    st2 = K.zeros_stats(C, y.to(dev))
+    K.channel_stats(y.to(dev), st2)
+    ref_rows = K.bn_finalize(st2, N * H * W, gamma.to(dev), beta.to(dev), rm2, rv2, 0.1, 1e-5, True, y.to(dev))
+    assert_close(rows, ref_rows, 1e-5, "statistics + finalisation")
+    assert_close(rm, rm2, 1e-6, "running mean")
+    assert_close(rv, rv2, 1e-6, "running var")
+    d = cl(dz).clone()
+    dgamma, dbeta, pq = K.nhwc_affine_act_bwd_(d, cl(y), rows[0], rows[1], None, rows[2], rows[3], 1, None,
+                                               gamma=gamma.to(dev), coeffs=True)
+    bst = K.zeros_stats(C, y.to(dev))
+    d_ref = K.affine_act_bwd_(dz.to(dev).clone(), y.to(dev), ref_rows[0], ref_rows[1], None, None, ref_rows[2], ref_rows[3],
+                              1, bst)
+    rg, rb, rpq = K.bn_bwd_coeffs(bst, N * H * W, gamma.to(dev), ref_rows[2], ref_rows[3])
+    assert_close(d, d_ref, 1e-6, "masked gradient (tail form)")
+    assert_close(dgamma, rg, 2e-5, "dgamma")
+    assert_close(dbeta, rb, 2e-5, "dbeta")
+    assert_close(pq, rpq, 2e-5, "pqr")
