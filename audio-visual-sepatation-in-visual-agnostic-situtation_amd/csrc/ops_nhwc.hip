@@ -262,3 +262,163 @@ extern "C" int avsep_nhwc_bn_bwd_apply(const float* dz, const float* y, const fl
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ResNet stem tail, channels-last: MaxPool2d(3, 2, 1) of relu(scale*y + shift) without materialising the activated
+// tensor (the stem output is the largest activation of the trunk: 308 MB at 96 frames), and its backward fused with
+// the ReLU mask and the BatchNorm backward.  thread = one output (forward) / input (backward) pixel x channel quad.
+// The winning tap (0..8, first maximum in scan order like nn.MaxPool2d) is kept as one byte per element.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nhwc_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int N, int H, int W, int C4,
+                                                            int Ho, int Wo, float* __restrict__ out,
+                                                            uint32_t* __restrict__ taps) {
+  const long long total = (long long)N * Ho * Wo * C4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cq = (int)(i % C4);
+    long long t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const long long n = t / Ho;
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[cq], sh = reinterpret_cast<const f32x4*>(shift)[cq];
+    f32x4 best = {-1.f, -1.f, -1.f, -1.f};                 // activations are >= 0: any valid tap beats it
+    uint32_t bt = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = 2 * ho - 1 + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = 2 * wo - 1 + kw;
+        if (w < 0 || w >= W) continue;
+        f32x4 v = reinterpret_cast<const f32x4*>(y)[((n * H + h) * W + w) * C4 + cq] * sc + sh;
+        const uint32_t tap = kh * 3 + kw;
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (v.x > best.x) { best.x = v.x; bt = (bt & 0xffffff00u) | tap; }
+        if (v.y > best.y) { best.y = v.y; bt = (bt & 0xffff00ffu) | (tap << 8); }
+        if (v.z > best.z) { best.z = v.z; bt = (bt & 0xff00ffffu) | (tap << 16); }
+        if (v.w > best.w) { best.w = v.w; bt = (bt & 0x00ffffffu) | (tap << 24); }
+      }
+    }
+    reinterpret_cast<f32x4*>(out)[i] = best;
+    taps[i] = bt;
+  }
+}
+
+// gradient reaching input pixel (n,h,w) of the pooled map's cotangent g: the <= 4 windows that contain the pixel and
+// chose it; then the ReLU mask of relu(scale*y+shift).
+__device__ __forceinline__ f32x4 pool_gather(const float* __restrict__ g, const uint32_t* __restrict__ taps, long long n,
+                                             int h, int w, int cq, int C4, int Ho, int Wo) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int ho1 = (h + 1) >> 1, wo1 = (w + 1) >> 1;        // window whose rows are 2*ho1-1 .. 2*ho1+1
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int ho = ho1 - a;
+    if (ho < 0 || ho >= Ho || (a == 1 && (h & 1) == 0)) continue;       // even rows belong to one window only
+    const uint32_t kh = h - (2 * ho - 1);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int wo = wo1 - b;
+      if (wo < 0 || wo >= Wo || (b == 1 && (w & 1) == 0)) continue;
+      const uint32_t tap = kh * 3 + (w - (2 * wo - 1));
+      const long long o = ((n * Ho + ho) * Wo + wo) * C4 + cq;
+      const uint32_t bt = taps[o];
+      const f32x4 gv = reinterpret_cast<const f32x4*>(g)[o];
+      if ((bt & 0xffu) == tap) acc.x += gv.x;
+      if (((bt >> 8) & 0xffu) == tap) acc.y += gv.y;
+      if (((bt >> 16) & 0xffu) == tap) acc.z += gv.z;
+      if ((bt >> 24) == tap) acc.w += gv.w;
+    }
+  }
+  return acc;
+}
+
+// APPLY = false: per-block partial (sum gm, sum gm*xhat(y)) of the masked gradient gm (statistics pass, writes nothing
+// else); APPLY = true: dy = p*gm + q*y + r.  Rows of the input image are the reduction rows (M = N*H*W).
+template <bool APPLY>
+__global__ __launch_bounds__(256) void nhwc_pool_bwd_kernel(const float* __restrict__ g, const uint32_t* __restrict__ taps,
+                                                            const float* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ pqr,
+                                                            int N, int H, int W, int C, int Ho, int Wo,
+                                                            float* __restrict__ out, float* __restrict__ partial) {
+  __shared__ float red[8][256];
+  const int C4 = C >> 2, tid = threadIdx.x, cq = tid % C4, rl = tid / C4, RL = 256 / C4;
+  const long long M = (long long)N * H * W, rows_per = (M + gridDim.x - 1) / gridDim.x;
+  const long long r_beg = blockIdx.x * rows_per, r_end = min(M, r_beg + rows_per);
+  const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[cq], sh = reinterpret_cast<const f32x4*>(shift)[cq];
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, p = mu, q = mu, r3 = mu, s1 = mu, s2 = mu;
+  if constexpr (APPLY) {
+    p = reinterpret_cast<const f32x4*>(pqr)[cq]; q = reinterpret_cast<const f32x4*>(pqr)[C4 + cq];
+    r3 = reinterpret_cast<const f32x4*>(pqr)[2 * C4 + cq];
+  } else {
+    mu = reinterpret_cast<const f32x4*>(mean)[cq]; is = reinterpret_cast<const f32x4*>(invstd)[cq];
+  }
+  for (long long r = r_beg + rl; r < r_end; r += RL) {
+    const int w = (int)(r % W), h = (int)((r / W) % H);
+    const long long n = r / ((long long)W * H);
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[r * C4 + cq];
+    f32x4 gm = pool_gather(g, taps, n, h, w, cq, C4, Ho, Wo);
+    const f32x4 pre = yv * sc + sh;
+    gm.x = pre.x > 0.f ? gm.x : 0.f; gm.y = pre.y > 0.f ? gm.y : 0.f;
+    gm.z = pre.z > 0.f ? gm.z : 0.f; gm.w = pre.w > 0.f ? gm.w : 0.f;
+    if constexpr (APPLY) {
+      reinterpret_cast<f32x4*>(out)[r * C4 + cq] = p * gm + q * yv + r3;
+    } else {
+      s1 += gm;
+      s2 += gm * ((yv - mu) * is);
+    }
+  }
+  if constexpr (!APPLY) {
+    red[0][tid] = s1.x; red[1][tid] = s1.y; red[2][tid] = s1.z; red[3][tid] = s1.w;
+    red[4][tid] = s2.x; red[5][tid] = s2.y; red[6][tid] = s2.z; red[7][tid] = s2.w;
+    __syncthreads();
+    for (int i = tid; i < 8 * C4; i += 256) {
+      const int k = i / C4, qq = i % C4;
+      float s = 0.f;
+      for (int j = 0; j < RL; ++j) s += red[k][j * C4 + qq];
+      partial[(long long)blockIdx.x * 2 * C + (k >> 2) * C + 4 * qq + (k & 3)] = s;
+    }
+  }
+}
+
+extern "C" int avsep_nhwc_maxpool_bn_relu_fwd(const float* y, const float* scale, const float* shift, int32_t N, int32_t H,
+                                              int32_t W, int32_t C, float* out, uint32_t* taps, avsep_stream_t stream) {
+  if (!y || !scale || !shift || !out || !taps || N <= 0 || H <= 0 || W <= 0 || !nhwc_ok((long long)N * H * W, C))
+    return AVSEP_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C >> 2);
+  hipLaunchKernelGGL(nhwc_pool_fwd_kernel, dim3((unsigned)min((total + 255) / 256, (long long)8192)), dim3(256), 0,
+                     (hipStream_t)stream, y, scale, shift, N, H, W, C >> 2, Ho, Wo, out, taps);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// g: cotangent of the pooled map [N,Ho,Wo,C].  Pass 1 (dy == NULL): dgamma, dbeta, pqr of the stem BatchNorm (two-stage
+// sums + avsep_bn_bwd_coeffs tail).  Pass 2 (dy != NULL): dy = p*gm + q*y + r with the pqr of pass 1.
+extern "C" int avsep_nhwc_maxpool_bn_relu_bwd(const float* g, const uint32_t* taps, const float* y, const float* scale,
+                                              const float* shift, const float* mean, const float* invstd,
+                                              const float* gamma, int32_t N, int32_t H, int32_t W, int32_t C, float* dgamma,
+                                              float* dbeta, float* pqr, float* dy, void* workspace, size_t workspace_bytes,
+                                              avsep_stream_t stream) {
+  const long long M = (long long)N * H * W;
+  if (!g || !taps || !y || !scale || !shift || !pqr || N <= 0 || H <= 0 || W <= 0 || !nhwc_ok(M, C)) return AVSEP_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dy) {
+    hipLaunchKernelGGL(nhwc_pool_bwd_kernel<true>, dim3(nhwc_grid(M, C, 8192)), dim3(256), 0, st, g, taps, y, scale, shift,
+                       nullptr, nullptr, pqr, N, H, W, C, Ho, Wo, dy, nullptr);
+    AVSEP_LAUNCH_CHECK();
+    return AVSEP_OK;
+  }
+  if (!mean || !invstd) return AVSEP_ERR_ARG;
+  if (!workspace || workspace_bytes < avsep_nhwc_stats_workspace_bytes(M, C)) return AVSEP_ERR_WORKSPACE;
+  const int nb = nhwc_grid(M, C, NHWC_STAT_BLOCKS);
+  hipLaunchKernelGGL(nhwc_pool_bwd_kernel<false>, dim3(nb), dim3(256), 0, st, g, taps, y, scale, shift, mean, invstd, nullptr,
+                     N, H, W, C, Ho, Wo, nullptr, (float*)workspace);
+  AVSEP_LAUNCH_CHECK();
+  NhwcTail t{};
+  t.mode = 2; t.count = (double)M; t.gamma = gamma; t.mean_in = mean; t.invstd_in = invstd; t.dgamma = dgamma;
+  t.dbeta = dbeta; t.pqr = pqr;
+  return nhwc_reduce((const float*)workspace, nb, C, nullptr, t, st);
+}

@@ -197,6 +197,32 @@ def nhwc_bn_bwd_apply_(dz, y, pqr, out=None):
     return dst
 
 
+def nhwc_maxpool_bn_relu(y, scale, shift):
+    """MaxPool2d(3,2,1) of relu(scale*y+shift), channels-last, activated map never materialised -> (pooled, taps)."""
+    M, Cc = _cl(y)
+    N, _, H, W = y.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=y.device).contiguous(memory_format=torch.channels_last)
+    taps = torch.empty((N * Ho * Wo * (Cc // 4),), dtype=torch.int32, device=y.device)
+    call("avsep_nhwc_maxpool_bn_relu_fwd", lib.ptr_cl(y), ptr(scale), ptr(shift), N, H, W, Cc, lib.ptr_cl(out), ptr(taps))
+    return out, taps
+
+
+def nhwc_maxpool_bn_relu_bwd(g, taps, y, bnrow, gamma):
+    """Backward of nhwc_maxpool_bn_relu + the stem BatchNorm: returns (dgamma, dbeta, dy)."""
+    M, Cc = _cl(y)
+    _cl(g)
+    N, _, H, W = y.shape
+    ws, nbytes = _nhwc_ws(M, Cc, y)
+    dgamma, dbeta, pqr = _f32((Cc,), y), _f32((Cc,), y), _f32((3, Cc), y)
+    args = (lib.ptr_cl(g), ptr(taps), lib.ptr_cl(y), ptr(bnrow[0]), ptr(bnrow[1]), ptr(bnrow[2]), ptr(bnrow[3]), ptr(gamma),
+            N, H, W, Cc, ptr(dgamma), ptr(dbeta), ptr(pqr))
+    call("avsep_nhwc_maxpool_bn_relu_bwd", *args, None, ptr(ws), nbytes)
+    dy = torch.empty_like(y)
+    call("avsep_nhwc_maxpool_bn_relu_bwd", *args, lib.ptr_cl(dy), ptr(ws), nbytes)
+    return dgamma, dbeta, dy
+
+
 class Cat:
     def __init__(self, x0, x1, sc0=None, sh0=None, sc1=None, sh1=None, bcast0=False, hw=None):
         N, C0 = x0.shape[:2]

@@ -62,6 +62,8 @@ SIGNATURES = {
     "avsep_nhwc_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, C.c_int64, _I, _P, _P, _P, _P, _P,
                                             _P, _P, _Z, _P]),
     "avsep_nhwc_bn_bwd_apply": (C.c_int, [_P, _P, _P, C.c_int64, _I, _P, _P]),
+    "avsep_nhwc_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_nhwc_maxpool_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "avsep_affine_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "avsep_relu_up2x_fwd": (C.c_int, [_KD, _P, _P]),

@@ -47,8 +47,7 @@ def trunk_forward(net, x, training):
     f = net.features
     S = {"x": x}
     S["y0"], S["bn0"] = _conv_bn(x, f[0], f[1], training)
-    S["a0"] = K.nhwc_affine_act(S["y0"], S["bn0"][0], S["bn0"][1], None, ACT_RELU)
-    z, S["idx"] = aten.max_pool2d_with_indices(S["a0"], [3, 3], [2, 2], [1, 1], [1, 1], False)
+    z, S["taps"] = K.nhwc_maxpool_bn_relu(S["y0"], S["bn0"][0], S["bn0"][1])   # relu(bn(y0)) is never materialised
     S["blocks"] = []
     for blk in blocks_of(f):
         R = {"mod": blk, "z": z}
@@ -101,10 +100,10 @@ def trunk_backward(net, S, dout, grads):
             g2 = g                                                      # identity branch
         g = dz                                                          # the join (g + g2) is summed by the next consumer
     g.add_(g2)
-    g = aten.max_pool2d_with_indices_backward(g, S["a0"], [3, 3], [2, 2], [1, 1], [1, 1], False, S["idx"])
-    pqr0 = _relu_bn_back(grads, g, S["y0"], S["bn0"], f[1])
-    K.nhwc_bn_bwd_apply_(g, S["y0"], pqr0)
-    _conv_back(grads, g, S["x"], f[0], need_dx=False)                   # the frames need no gradient
+    dgamma, dbeta, dy0 = K.nhwc_maxpool_bn_relu_bwd(g, S["taps"], S["y0"], S["bn0"], f[1].weight.detach())
+    _acc(grads, f[1].weight, dgamma)
+    _acc(grads, f[1].bias, dbeta)
+    _conv_back(grads, dy0, S["x"], f[0], need_dx=False)                 # the frames need no gradient
 
 
 class _ResnetHybridFn(torch.autograd.Function):

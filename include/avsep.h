@@ -131,6 +131,17 @@ int avsep_nhwc_affine_act_bwd(const float* dz, const float* dz2, const float* y,
                               float* pqr, void* workspace, size_t workspace_bytes, avsep_stream_t stream);
 int avsep_nhwc_bn_bwd_apply(const float* dz, const float* y, const float* pqr, int64_t M, int32_t C,
                             float* out, avsep_stream_t stream);
+/* ResNet stem tail (torchvision resnet: bn1 -> relu -> maxpool 3x3/s2/p1) on channels-last tensors without materialising
+ * the activated map: out [N,Ho,Wo,C] = maxpool(relu(scale*y+shift)), taps = winning tap 0..8 per element (one byte each,
+ * packed per channel quad).  Backward: pass 1 (dy NULL) -> dgamma, dbeta, pqr of the stem BatchNorm from the masked
+ * pooled gradient; pass 2 (dy given, same pqr) -> dy = p*gm + q*y + r. */
+int avsep_nhwc_maxpool_bn_relu_fwd(const float* y, const float* scale, const float* shift, int32_t N, int32_t H,
+                                   int32_t W, int32_t C, float* out, uint32_t* taps, avsep_stream_t stream);
+int avsep_nhwc_maxpool_bn_relu_bwd(const float* g, const uint32_t* taps, const float* y, const float* scale,
+                                   const float* shift, const float* mean, const float* invstd, const float* gamma,
+                                   int32_t N, int32_t H, int32_t W, int32_t C, float* dgamma, float* dbeta,
+                                   float* pqr, float* dy, void* workspace, size_t workspace_bytes,
+                                   avsep_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * BatchNorm2d pieces (train-mode batch statistics; nn.BatchNorm2d at audio_net.py:37,65,67).

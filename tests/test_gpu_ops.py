@@ -524,3 +524,27 @@ def test_channels_last_bn_pieces(dev, N, C, H, W):
     assert_close(dgamma, rg, 2e-5, "dgamma")
     assert_close(dbeta, rb, 2e-5, "dbeta")
     assert_close(pq, rpq, 2e-5, "pqr")
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 14, 18), (3, 16, 9, 11), (1, 64, 112, 112)])
+def test_channels_last_stem_tail(dev, N, C, H, W):
+    """maxpool(relu(bn(y))) fused forward (activated map never materialised) and its backward fused with the ReLU mask
+    and the train-mode BatchNorm backward, against torch autograd on the CPU."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(H)
+    y = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data, bn.bias.data = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    yr = y.clone().requires_grad_(True)
+    p_ref = F.max_pool2d(torch.relu(bn(yr)), 3, 2, 1)
+    cot = torch.randn(p_ref.shape, generator=g)
+    (p_ref * cot).sum().backward()
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)   # noqa: E731
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    rows = K.nhwc_bn_train_stats(cl(y), bn.weight.data.to(dev), bn.bias.data.to(dev), rm, rv, 0.1, 1e-5)
+    p, taps = K.nhwc_maxpool_bn_relu(cl(y), rows[0], rows[1])
+    assert_close(p, p_ref, 2e-6, "pooled activations")
+    dgamma, dbeta, dy = K.nhwc_maxpool_bn_relu_bwd(cl(cot), taps, cl(y), rows, bn.weight.data.to(dev))
+    assert_close(dy, yr.grad, 2e-5, "gradient wrt the conv output (through batch statistics)")
+    assert_close(dgamma, bn.weight.grad, 2e-5, "dgamma")
+    assert_close(dbeta, bn.bias.grad, 2e-5, "dbeta")
