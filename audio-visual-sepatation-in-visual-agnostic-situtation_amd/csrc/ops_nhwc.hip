@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* __restrict
 // in the same launch by what the caller would do next with them:
 //   mode 1 (forward):  BatchNorm2d finalisation (scale, shift, mean, invstd, running statistics) = avsep_bn_finalize
 //   mode 2 (backward): dgamma, dbeta and the folded-gradient coefficients (p, q, r)               = avsep_bn_bwd_coeffs
-// Block = 64 channels x 16 row lanes (coalesced 256-byte partial rows, 16 independent chains per column).
+// Block = 16 channels x 64 row lanes: the per-thread chain over the partial rows is the latency of this launch
+// (measured 10 us with 16 lanes), the partials are L2-resident, so short 64-byte row segments are fine.
 struct NhwcTail {
   int mode;
   double count;
@@ -91,12 +92,12 @@ struct NhwcTail {
 };
 __global__ __launch_bounds__(1024) void nhwc_stats_reduce_kernel(const float* __restrict__ partial, int nblocks, int C,
                                                                  double* __restrict__ stats, NhwcTail t) {
-  __shared__ double red[2][16][64];
-  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + col;
+  __shared__ double red[2][64][17];
+  const int col = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + col;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
 #pragma unroll 4
-    for (int b = rl; b < nblocks; b += 16) {
+    for (int b = rl; b < nblocks; b += 64) {
       s1 += (double)partial[(long long)b * 2 * C + c];
       s2 += (double)partial[(long long)b * 2 * C + C + c];
     }
@@ -104,10 +105,13 @@ __global__ __launch_bounds__(1024) void nhwc_stats_reduce_kernel(const float* __
   red[0][rl][col] = s1;
   red[1][rl][col] = s2;
   __syncthreads();
+  for (int half = 32; half >= 1; half >>= 1) {             // tree over the 64 row lanes
+    if (rl < half) { red[0][rl][col] += red[0][rl + half][col]; red[1][rl][col] += red[1][rl + half][col]; }
+    __syncthreads();
+  }
   if (rl != 0 || c >= C) return;
-  s1 = s2 = 0.0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) { s1 += red[0][j][col]; s2 += red[1][j][col]; }
+  s1 = red[0][0][col];
+  s2 = red[1][0][col];
   if (stats) { stats[c] = s1; stats[C + c] = s2; }
   if (t.mode == 1) {            // same arithmetic as bn_finalize_kernel (ops.hip), training mode
     const double mean = s1 / t.count;
@@ -180,7 +184,7 @@ extern "C" size_t avsep_nhwc_stats_workspace_bytes(int64_t M, int32_t C) {
   return nhwc_ok(M, C) ? (size_t)nhwc_grid(M, C, NHWC_STAT_BLOCKS) * 2 * C * sizeof(float) : 0;
 }
 static int nhwc_reduce(const float* partial, int nblocks, int C, double* stats, const NhwcTail& t, hipStream_t st) {
-  hipLaunchKernelGGL(nhwc_stats_reduce_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, partial, nblocks, C, stats, t);
+  hipLaunchKernelGGL(nhwc_stats_reduce_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, st, partial, nblocks, C, stats, t);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
