@@ -89,6 +89,7 @@ struct NhwcTail {
   const float *gamma, *beta, *mean_in, *invstd_in;
   float *running_mean, *running_var, *scale, *shift, *mean_o, *invstd_o, *dgamma, *dbeta, *pqr;
   float momentum, eps;
+  long long* counter;      // nn.BatchNorm2d.num_batches_tracked (mode 1), incremented by one thread
 };
 __global__ __launch_bounds__(1024) void nhwc_stats_reduce_kernel(const float* __restrict__ partial, int nblocks, int C,
                                                                  double* __restrict__ stats, NhwcTail t) {
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(1024) void nhwc_stats_reduce_kernel(const float* __
     if (rl < half) { red[0][rl][col] += red[0][rl + half][col]; red[1][rl][col] += red[1][rl + half][col]; }
     __syncthreads();
   }
+  if (t.counter && blockIdx.x == 0 && threadIdx.x == 0) *t.counter += 1;
   if (rl != 0 || c >= C) return;
   s1 = red[0][0][col];
   s2 = red[1][0][col];
@@ -208,9 +210,9 @@ extern "C" int avsep_nhwc_channel_stats(const float* x, int64_t M, int32_t C, do
 // statistics of x + BatchNorm2d finalisation in the second stage (training mode): avsep_nhwc_channel_stats followed by
 // avsep_bn_finalize, one launch fewer
 extern "C" int avsep_nhwc_bn_train_stats(const float* x, int64_t M, int32_t C, const float* gamma, const float* beta,
-                                         float* running_mean, float* running_var, float momentum, float eps, float* scale,
-                                         float* shift, float* mean, float* invstd, void* workspace, size_t workspace_bytes,
-                                         avsep_stream_t stream) {
+                                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                         float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                                         void* workspace, size_t workspace_bytes, avsep_stream_t stream) {
   if (!x || !scale || !shift || !mean || !invstd || !nhwc_ok(M, C)) return AVSEP_ERR_ARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return AVSEP_ERR_ARG;
   if (!workspace || workspace_bytes < avsep_nhwc_stats_workspace_bytes(M, C)) return AVSEP_ERR_WORKSPACE;
@@ -219,7 +221,7 @@ extern "C" int avsep_nhwc_bn_train_stats(const float* x, int64_t M, int32_t C, c
   NhwcTail t{};
   t.mode = 1; t.count = (double)M; t.gamma = gamma; t.beta = beta; t.running_mean = running_mean;
   t.running_var = running_var; t.momentum = momentum; t.eps = eps; t.scale = scale; t.shift = shift; t.mean_o = mean;
-  t.invstd_o = invstd;
+  t.invstd_o = invstd; t.counter = (long long*)num_batches_tracked;
   return nhwc_reduce((const float*)workspace, nhwc_grid(M, C, NHWC_STAT_BLOCKS), C, nullptr, t, (hipStream_t)stream);
 }
 

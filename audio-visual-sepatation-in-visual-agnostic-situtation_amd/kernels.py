@@ -157,13 +157,14 @@ def nhwc_channel_stats(x, stats):
     call("avsep_nhwc_channel_stats", lib.ptr_cl(x), M, Cc, ptr(stats), ptr(ws), nbytes)
 
 
-def nhwc_bn_train_stats(x, gamma, beta, rmean, rvar, momentum, eps):
-    """Train-mode BatchNorm2d statistics of a channels-last tensor + finalisation: rows (scale, shift, mean, invstd)."""
+def nhwc_bn_train_stats(x, gamma, beta, rmean, rvar, momentum, eps, num_batches_tracked=None):
+    """Train-mode BatchNorm2d statistics of a channels-last tensor + finalisation: rows (scale, shift, mean, invstd);
+    updates the running statistics and (if given) the int64 num_batches_tracked buffer."""
     M, Cc = _cl(x)
     ws, nbytes = _nhwc_ws(M, Cc, x)
     out = _f32((4, Cc), x)
-    call("avsep_nhwc_bn_train_stats", lib.ptr_cl(x), M, Cc, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(momentum),
-         float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(ws), nbytes)
+    call("avsep_nhwc_bn_train_stats", lib.ptr_cl(x), M, Cc, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+         ptr(num_batches_tracked), float(momentum), float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(ws), nbytes)
     return out
 
 

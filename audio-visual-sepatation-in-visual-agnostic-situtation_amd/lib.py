@@ -58,7 +58,7 @@ SIGNATURES = {
     "avsep_nhwc_stats_workspace_bytes": (C.c_size_t, [C.c_int64, _I]),
     "avsep_nhwc_channel_stats": (C.c_int, [_P, C.c_int64, _I, _P, _P, _Z, _P]),
     "avsep_nhwc_affine_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, C.c_int64, _I, _P, _P]),
-    "avsep_nhwc_bn_train_stats": (C.c_int, [_P, C.c_int64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    "avsep_nhwc_bn_train_stats": (C.c_int, [_P, C.c_int64, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "avsep_nhwc_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, C.c_int64, _I, _P, _P, _P, _P, _P,
                                             _P, _P, _Z, _P]),
     "avsep_nhwc_bn_bwd_apply": (C.c_int, [_P, _P, _P, C.c_int64, _I, _P, _P]),

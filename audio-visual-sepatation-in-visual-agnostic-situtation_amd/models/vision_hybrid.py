@@ -38,8 +38,7 @@ def _conv_bn(x, conv, bn, training):
     if not training:
         return y, _bn_run(bn, None, y.numel() // y.shape[1], False, y)
     rows = K.nhwc_bn_train_stats(y, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, BN_MOMENTUM,
-                                 BN_EPS)                   # statistics + finalisation: two launches
-    bn.num_batches_tracked += 1
+                                 BN_EPS, bn.num_batches_tracked)   # statistics + finalisation + counter: two launches
     return y, rows
 
 

@@ -115,9 +115,11 @@ int avsep_nhwc_channel_stats(const float* x, int64_t M, int32_t C, double* stats
 int avsep_nhwc_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
                           const float* res_scale, const float* res_shift, int32_t act, int64_t M, int32_t C,
                           float* z, avsep_stream_t stream);
-/* avsep_nhwc_channel_stats + avsep_bn_finalize (training mode, count = M) with the finalisation in the second stage */
+/* avsep_nhwc_channel_stats + avsep_bn_finalize (training mode, count = M) with the finalisation in the second stage;
+ * num_batches_tracked (nn.BatchNorm2d's int64 counter, may be NULL) is incremented by one */
 int avsep_nhwc_bn_train_stats(const float* x, int64_t M, int32_t C, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float momentum, float eps,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                              float momentum, float eps,
                               float* scale, float* shift, float* mean, float* invstd, void* workspace,
                               size_t workspace_bytes, avsep_stream_t stream);
 /* dz_pre = act'(scale*y+shift [+ res_scale*residual+res_shift]) * (dz [+ dz2]) (dz2: the second incoming gradient of
