@@ -548,13 +548,13 @@ __device__ __forceinline__ float w3_src(const W3Args& a, int n, int c, int hs, i
 }
 
 // one pixel tile of the wgrad GEMM for a wave that owns NTAP consecutive taps starting at tap0 (wave-uniform)
-template <int TH, int TW, int PW, int MAXT, int NTAP>
+template <int TH, int TW, int PW, int MAXT, int NTAP, int DIL = 1>
 __device__ __forceinline__ void w3_mfma_tile(const float* Ap, const float* Bp, int tap0, f32x16 (&acc)[MAXT]) {
-  int toff[NTAP];                                           // (kh*PW + kw) per owned tap
+  int toff[NTAP];                                           // (kh*PW + kw) * dilation per owned tap
 #pragma unroll
   for (int j = 0; j < NTAP; ++j) {
     int tp = tap0 + j;
-    toff[j] = (tp / 3) * PW + (tp % 3);
+    toff[j] = ((tp / 3) * PW + (tp % 3)) * DIL;
   }
   for (int py = 0; py < TH; ++py) {
     const float* ar = Ap + py * TW;
@@ -579,9 +579,12 @@ __device__ __forceinline__ void w3_mfma_tile(const float* Ap, const float* Bp, i
   }
 }
 
-template <int TH, int TW, bool UP2X, int BM>
+// DIL: dilation (pad = DIL); A2: rows of dY are only 8-byte aligned (W % 4 == 2, e.g. the 14x14 ResNet maps), the A tile
+// is then loaded as pairs of float2.  The U-Net instantiations are <.., 1, false>.
+template <int TH, int TW, bool UP2X, int BM, int DIL = 1, bool A2 = false>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
-  constexpr int NPIX = TH * TW, PH = TH + 2, PW = TW + 2;
+  static_assert(!(UP2X && DIL != 1), "the fused upsample path is undilated");
+  constexpr int NPIX = TH * TW, PH = TH + 2 * DIL, PW = TW + 2 * DIL;
   constexpr int PS = (PH * PW) | 1;                       // odd per-channel stride: lanes = channels -> no bank conflicts
   constexpr int LDA = NPIX + 1;
   constexpr int NT = 512;
@@ -641,10 +644,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
     int cc = idx / (PH * PW), r = (idx % (PH * PW)) / PW, col = idx % PW;
     p_chok[e] = (PE * NT == NP || tid + NT * e < NP) && c0 + cc < a.Cin;
     int cs = min(csrc0 + cc, Csrc - 1);
-    p_goff[e] = cs * (int)sHW + (r - 1) * a.Ws + (col - 1);
+    p_goff[e] = cs * (int)sHW + (r - DIL) * a.Ws + (col - DIL);
     p_lds[e] = cc * PS + r * PW + col;
-    p_r[e] = r - 1;
-    p_col[e] = col - 1;
+    p_r[e] = r - DIL;
+    p_col[e] = col - DIL;
     p_sc[e] = scs ? scs[cs] : 1.f;
     p_sh[e] = scs ? shs[cs] : 0.f;
   }
@@ -659,7 +662,14 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
       const bool ok = a_rowok[e] && h0 + a_r[e] < a.H && w0 + a_c[e] < a.W;
-      areg[e] = *reinterpret_cast<const f32x4*>(ok ? dyb + a_goff[e] : a.dy);
+      if constexpr (!A2) {
+        areg[e] = *reinterpret_cast<const f32x4*>(ok ? dyb + a_goff[e] : a.dy);
+      } else {                 // the second pair of the quad may lie past the row end
+        const bool ok2 = ok && w0 + a_c[e] + 2 < a.W;
+        const float2 lo = *reinterpret_cast<const float2*>(ok ? dyb + a_goff[e] : a.dy);
+        const float2 hi = *reinterpret_cast<const float2*>(ok2 ? dyb + a_goff[e] + 2 : a.dy);
+        areg[e] = f32x4{lo.x, lo.y, ok2 ? hi.x : 0.f, ok2 ? hi.y : 0.f};
+      }
       amask |= (unsigned)ok << e;
     }
 #pragma unroll
@@ -722,10 +732,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
     if constexpr (BM == 128) {
       // both tap groups run 5 taps ({0..4} and {4..8}: tap 4 is computed twice, the copy is dropped in the
       // epilogue) so the whole loop is one branch-free instruction stream; costs 10 instead of 9 MFMAs per step
-      w3_mfma_tile<TH, TW, PW, MAXT, MAXT>(Ap, Bp, tap0, acc);
+      w3_mfma_tile<TH, TW, PW, MAXT, MAXT, DIL>(Ap, Bp, tap0, acc);
     } else {
-      if (ntap == MAXT) w3_mfma_tile<TH, TW, PW, MAXT, MAXT>(Ap, Bp, tap0, acc);
-      else w3_mfma_tile<TH, TW, PW, MAXT, MAXT - 1>(Ap, Bp, tap0, acc);
+      if (ntap == MAXT) w3_mfma_tile<TH, TW, PW, MAXT, MAXT, DIL>(Ap, Bp, tap0, acc);
+      else w3_mfma_tile<TH, TW, PW, MAXT, MAXT - 1, DIL>(Ap, Bp, tap0, acc);
     }
     if (t + 1 < t_end) {
       finish(buf ^ 1);
@@ -752,15 +762,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
 }
 
 bool w3_applicable(const avsep_conv_desc* d) {
-  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->W >= 16 && d->H >= 2 &&
-         (d->W & 3) == 0 && d->Cout > 4 && d->Cin >= 32 && d->N <= 65535 && (d->C0 == d->Cin || d->C0 % W3_CC == 0) &&
+  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil)) return false;
+  if (d->up2x && (d->dil != 1 || (d->W & 3))) return false;
+  return d->W >= 12 && d->H >= 2 && (d->W & 1) == 0 && d->Cout > 4 && d->Cin >= 32 && d->N <= 65535 &&
+         (d->C0 == d->Cin || d->C0 % W3_CC == 0) &&
          (long long)(d->Cout > d->Cin ? d->Cout : d->Cin) * d->H * d->W < 0x7fffffffLL;
 }
 
 struct W3Plan { int tilesX, tilesY, gridM, gridC, splits, tps; bool wide; };
 static W3Plan w3_plan(const avsep_conv_desc* d) {
   W3Plan p;
-  p.wide = d->W >= 32;
+  p.wide = d->W >= 32 && d->dil == 1;      // the dilated patch of a 2x32 tile would not leave room for two workgroups per CU
   p.tilesX = cdiv(d->W, p.wide ? 32 : 16);
   p.tilesY = cdiv(d->H, p.wide ? 2 : 4);
   p.gridM = cdiv(d->Cout, d->Cout <= 64 ? 64 : 128);
@@ -803,15 +815,26 @@ int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   a.dy = dy; a.out = p.splits > 1 ? ws : dw; a.tapmajor = p.splits > 1;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.gridM = p.gridM; a.gridC = p.gridC; a.tiles_per_split = p.tps;
   dim3 grid(p.gridM * p.gridC, p.splits);
-#define W3_LAUNCH(TH_, TW_, UP_)                                                                             \
-  do {                                                                                                     \
-    if (d->Cout <= 64) hipLaunchKernelGGL((wgrad3x3_kernel<TH_, TW_, UP_, 64>), grid, dim3(512), 0, st, a); \
-    else hipLaunchKernelGGL((wgrad3x3_kernel<TH_, TW_, UP_, 128>), grid, dim3(512), 0, st, a);             \
+#define W3_LAUNCH(TH_, TW_, UP_, DIL_, A2_)                                                                            \
+  do {                                                                                                                 \
+    if (d->Cout <= 64) hipLaunchKernelGGL((wgrad3x3_kernel<TH_, TW_, UP_, 64, DIL_, A2_>), grid, dim3(512), 0, st, a);  \
+    else hipLaunchKernelGGL((wgrad3x3_kernel<TH_, TW_, UP_, 128, DIL_, A2_>), grid, dim3(512), 0, st, a);              \
   } while (0)
-  if (p.wide && !d->up2x) W3_LAUNCH(2, 32, false);
-  else if (p.wide) W3_LAUNCH(2, 32, true);
-  else if (!d->up2x) W3_LAUNCH(4, 16, false);
-  else W3_LAUNCH(4, 16, true);
+  const bool a2 = (d->W & 3) != 0;
+  if (d->up2x) {
+    if (p.wide) W3_LAUNCH(2, 32, true, 1, false);
+    else W3_LAUNCH(4, 16, true, 1, false);
+  } else if (d->dil == 1 && !a2) {                // the U-Net's instantiations
+    if (p.wide) W3_LAUNCH(2, 32, false, 1, false);
+    else W3_LAUNCH(4, 16, false, 1, false);
+  } else if (d->dil == 1) {
+    if (p.wide) W3_LAUNCH(2, 32, false, 1, true);
+    else W3_LAUNCH(4, 16, false, 1, true);
+  } else if (!a2) {
+    W3_LAUNCH(4, 16, false, 2, false);
+  } else {
+    W3_LAUNCH(4, 16, false, 2, true);
+  }
 #undef W3_LAUNCH
   AVSEP_LAUNCH_CHECK();
   if (p.splits > 1) {

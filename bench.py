@@ -98,7 +98,7 @@ def kernel_family(cv, mode):
             return "conv3x3_kernel"
         if mode == "dgrad" and cv.Cout % 4 == 0 and cv.Cin >= 32:
             return "conv3x3_kernel"
-        if mode == "wgrad" and cv.Cout > 4 and cv.Cin >= 32 and cv.W % 4 == 0 and cv.W >= 16:
+        if mode == "wgrad" and cv.Cout > 4 and cv.Cin >= 32 and cv.W % 2 == 0:
             return "wgrad3x3_kernel"
     if cv.KH == 4 and cv.KW == 4 and cv.d.stride == 2 and cv.d.pad == 1 and cv.Wo >= 16 and cv.Ho >= 4:
         if mode == "fwd" and cv.Cin % 2 == 0 and cv.Cout >= 32:

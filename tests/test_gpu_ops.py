@@ -35,6 +35,8 @@ CONV_CASES = [
     (2, 37, 21, 144, 2, 3, 1, 1, 1),       # same path: ragged H, W > one 128 tile, Cin not a multiple of the chunk
     (2, 16, 10, 10, 3, 3, 1, 1, 1),        # W % 16 != 0 -> falls back to the MFMA path
     (3, 32, 14, 14, 40, 3, 1, 2, 2),       # dilated 3x3 (ResNet layer4) on the halo-patch kernel, 14x14 map
+    (2, 64, 14, 14, 136, 3, 1, 2, 2),      # same, 128-row weight-gradient tiles, rows only 8-byte aligned
+    (2, 64, 18, 22, 72, 3, 1, 1, 1),       # W % 4 == 2 undilated weight gradient
     (2, 36, 20, 40, 136, 3, 1, 2, 2),      # dilated, 4x32 tiles
     (3, 32, 14, 14, 48, 3, 1, 1, 1),       # 14x14 map, undilated
     (2, 1, 32, 48, 24, 4, 2, 1, 1),        # first U-Net conv (Cin = 1): blocked small-Cin data gradient
