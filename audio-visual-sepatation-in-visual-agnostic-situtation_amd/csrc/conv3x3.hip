@@ -352,8 +352,11 @@ static int c3_launch(C3Args& a, hipStream_t st, int dil = 1) {
   const bool wide = a.W >= 32;
   a.tilesX = cdiv(a.W, wide ? 32 : 16);
   a.tilesY = cdiv(a.H, wide ? 4 : 8);
-  // 64-row tiles when the GEMM M dimension is small, or when 128-row tiles would leave most CUs with one workgroup
-  const bool narrow = a.Cout <= 64 || (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * a.N < 384;
+  // 64-row tiles when the GEMM M dimension is small, when 128-row tiles would leave most CUs with one workgroup, or when
+  // their count quantises badly over the 256 CUs (384 workgroups = 1.5 per CU runs at 75 %: the ResNet 256-channel
+  // 14x14 layers)
+  const long long wg128 = (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * a.N;
+  const bool narrow = a.Cout <= 64 || wg128 < 384 || (wg128 < 1024 && wg128 * 5 < ((wg128 + 255) / 256) * 256 * 4);
   a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
 #define C3_LAUNCH(TH_, TW_, BM_)                                                                               \
