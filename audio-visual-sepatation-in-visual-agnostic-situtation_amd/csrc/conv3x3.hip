@@ -426,12 +426,12 @@ __global__ void c4_pack_kernel(const float* __restrict__ w, float* __restrict__ 
   out[i] = v;
 }
 
-// forward: Cin, C0 even, Wo >= 16; dgrad: Cout % 4 == 0, even H and W (all four classes have the same extent)
+// forward: Cin, C0 even, Wo >= 16; dgrad: Cout % 8 == 0, even H and W (all four classes have the same extent)
 bool c4_applicable(const avsep_conv_desc* d, int mode) {
   if (!(d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->dil == 1) || d->up2x) return false;
   if (d->Wo < 16 || d->Ho < 4 || d->N > 65535) return false;
   if (mode == 0) return d->Cin % 2 == 0 && d->C0 % 2 == 0 && d->Cout >= 32;
-  return d->Cout % 4 == 0 && d->Cin >= 32 && (d->H & 1) == 0 && (d->W & 1) == 0;
+  return d->Cout % 8 == 0 && d->Cin >= 32 && (d->H & 1) == 0 && (d->W & 1) == 0;
 }
 size_t c4_packed_floats(const avsep_conv_desc* d, int mode) {
   int rows = (mode == 0 ? d->Cin : d->Cout) * 16, ld = roundup(mode == 0 ? d->Cout : d->Cin, 128);
@@ -484,7 +484,7 @@ int c4_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
     a.x0 = dy; a.wp = wp + (size_t)cls * d->Cout * 4 * ld; a.wp_ld = ld; a.out = dx;
     a.Ho = d->H / 2; a.Wo = d->W / 2; a.padh = ph ? 0 : 1; a.padw = pw ? 0 : 1;
     a.os = 2; a.ooh = ph; a.oow = pw; a.OHs = d->H; a.OWs = d->W;
-    int rc = c4_launch<2, 1, 4>(a, st);
+    int rc = c4_launch<2, 1, 8>(a, st);     // 8 channels per K-tile: 16 k-steps per staged patch (4 left the MFMA pipe 47-63 % busy)
     if (rc) return rc;
   }
   return AVSEP_OK;

@@ -103,7 +103,7 @@ def kernel_family(cv, mode):
     if cv.KH == 4 and cv.KW == 4 and cv.d.stride == 2 and cv.d.pad == 1 and cv.Wo >= 16 and cv.Ho >= 4:
         if mode == "fwd" and cv.Cin % 2 == 0 and cv.Cout >= 32:
             return "conv3x3_kernel"           # the same halo-patch kernel, KS = 4 / S = 2 instantiation
-        if mode == "dgrad" and cv.Cout % 4 == 0 and cv.Cin >= 32 and cv.H % 2 == 0 and cv.W % 2 == 0:
+        if mode == "dgrad" and cv.Cout % 8 == 0 and cv.Cin >= 32 and cv.H % 2 == 0 and cv.W % 2 == 0:
             return "conv3x3_kernel"           # 4 parity-class launches of the KS = 2 instantiation
     return "igemm_kernel<%s>" % mode
 
