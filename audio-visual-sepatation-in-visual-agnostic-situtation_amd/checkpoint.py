@@ -12,6 +12,13 @@ import os
 import torch
 
 
+def _save(obj, path):
+    """torch.save to a temporary file + os.replace: a kill mid-save never corrupts the only resume point."""
+    tmp = path + ".tmp"
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
 def _cpu_state(net):
     return {k: v.detach().cpu() for k, v in net.state_dict().items()}
 
@@ -21,16 +28,16 @@ def checkpoint(nets, history, itera, args, optimizer=None):
     net_sound, net_frame = nets
     os.makedirs(args.ckpt, exist_ok=True)
     path = lambda what, suffix: os.path.join(args.ckpt, "{}_{}".format(what, suffix))   # noqa: E731
-    torch.save(history, path("history", "latest.pth"))
-    torch.save(_cpu_state(net_sound), path("sound", "latest.pth"))
-    torch.save(_cpu_state(net_frame), path("frame", "latest.pth"))
+    _save(history, path("history", "latest.pth"))
+    _save(_cpu_state(net_sound), path("sound", "latest.pth"))
+    _save(_cpu_state(net_frame), path("frame", "latest.pth"))
     if optimizer is not None:
-        torch.save({"itera": itera, "state": optimizer.state_dict()}, path("optim", "latest.pth"))
+        _save({"itera": itera, "state": optimizer.state_dict()}, path("optim", "latest.pth"))
     cur_err = -history["val_ao"]["si_sdr"][-1]
     if cur_err < args.best_err:
         args.best_err = cur_err
-        torch.save(_cpu_state(net_sound), path("sound", "best.pth"))
-        torch.save(_cpu_state(net_frame), path("frame", "best.pth"))
+        _save(_cpu_state(net_sound), path("sound", "best.pth"))
+        _save(_cpu_state(net_frame), path("frame", "best.pth"))
 
 
 def resume_paths(args, best=False):

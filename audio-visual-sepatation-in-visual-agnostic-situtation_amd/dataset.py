@@ -268,21 +268,20 @@ class MUSICMixDataset(torch.utils.data.Dataset):
 
 
 # ------------------------------------------------------------------------------------------ hand-off
-def _pinned_stack(ts):
-    out = torch.empty((len(ts), *ts[0].shape), dtype=ts[0].dtype)
-    if torch.cuda.is_available():
-        out = out.pin_memory()
-    torch.stack(ts, 0, out=out)
-    return out
+def _stack(ts):
+    # No pinning here: with workers > 0 this runs in fork()ed children of a process that may already have
+    # initialised HIP, where hipHostMalloc is unusable — and a tensor returned through the worker queue is copied
+    # into shared memory anyway.  The parent pins (DataLoader(pin_memory=True): its pin thread runs in the main process).
+    return torch.stack(ts, 0)
 
 
 def collate(samples):
     """default_collate's layout for this dict (lists of per-source tensors stay lists; `infos` transposed like
-    default_collate does for nested lists of strings), stacked into pinned host memory."""
+    default_collate does for nested lists of strings).  GPU-free: safe in forked workers."""
     N = len(samples[0]["audios"])
-    return {"audios": [_pinned_stack([s["audios"][n] for s in samples]) for n in range(N)],
-            "audio_mix": _pinned_stack([s["audio_mix"] for s in samples]),
-            "frames": [_pinned_stack([s["frames"][n] for s in samples]) for n in range(N)],
+    return {"audios": [_stack([s["audios"][n] for s in samples]) for n in range(N)],
+            "audio_mix": _stack([s["audio_mix"] for s in samples]),
+            "frames": [_stack([s["frames"][n] for s in samples]) for n in range(N)],
             "id": [s["id"] for s in samples], "class": torch.stack([s["class"] for s in samples], 0),
             "infos": [[[s["infos"][n][k] for s in samples] for k in range(len(samples[0]["infos"][n]))] for n in range(N)]}
 
@@ -298,7 +297,8 @@ def to_device(batch, device):
 
 
 def make_loader(csv_paths, args, split, batch_size, shuffle, workers=0, **kw):
-    """ConcatDataset of the lists + DataLoader with the pinned collate (main.py:633-659)."""
+    """ConcatDataset of the lists + DataLoader (main.py:633-659); batches are pinned by the parent's pin thread."""
     sets = [MUSICMixDataset(pth, vars(args), split=split, **kw) for pth in csv_paths]
     return torch.utils.data.DataLoader(torch.utils.data.ConcatDataset(sets), batch_size=batch_size, shuffle=shuffle,
-                                       num_workers=workers, drop_last=False, collate_fn=collate)
+                                       num_workers=workers, drop_last=False, collate_fn=collate,
+                                       pin_memory=torch.cuda.is_available())

@@ -108,6 +108,59 @@ def best_permutations(loss_mat):
     return out
 
 
+class DevicePerms:
+    """The winning permutations as a device tensor `idx` [B,S] (idx[b,i] = prediction assigned to target i).  Behaves
+    like the reference's list of tuples when a caller looks inside (that, and only that, synchronises)."""
+
+    def __init__(self, idx):
+        self.idx = idx
+        self._host = None
+
+    def tolist(self):
+        if self._host is None:
+            self._host = [tuple(r) for r in self.idx.tolist()]
+        return self._host
+
+    def __len__(self):
+        return self.idx.shape[0]
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __getitem__(self, i):
+        return self.tolist()[i]
+
+    def __eq__(self, other):
+        return self.tolist() == [tuple(q) for q in other]
+
+    def __repr__(self):
+        return repr(self.tolist())
+
+
+_PERM_TABLES = {}
+
+
+def best_permutations_device(mat):
+    """best_permutations without leaving the device: all S! candidate costs in one gather, argmin keeps the FIRST
+    minimum = the first permutation in itertools order on ties (criterion.py:133's strict '>')."""
+    B, S = mat.shape[:2]
+    key = (S, mat.device)
+    if key not in _PERM_TABLES:
+        _PERM_TABLES[key] = torch.tensor(list(permutations(range(S))), device=mat.device)      # [S!, S]
+    table = _PERM_TABLES[key]
+    P = table.shape[0]
+    cost = torch.gather(mat.detach().unsqueeze(1).expand(B, P, S, S), 3, table[None, :, :, None].expand(B, P, S, 1))
+    best = (cost.squeeze(-1).sum(-1) / S).argmin(1)
+    return DevicePerms(table[best])
+
+
+def pit_select(mat):
+    """(per-sample PIT loss [B] fp32-castable, DevicePerms) from the mean loss matrix [B,S,S]; no host sync."""
+    perms = best_permutations_device(mat)
+    loss = torch.gather(mat, 2, perms.idx[:, :, None]).squeeze(-1).mean(-1)
+    return loss, perms
+
+
 class PitWrapper(nn.Module):
     """Permutation-invariant wrapper; preds/targets/weights are [B, ..., S] like the reference.
     ``base_loss`` is kept for signature compatibility (the reference always passes BCE,
@@ -128,15 +181,12 @@ class PitWrapper(nn.Module):
 
     def forward(self, preds, targets, weights=None):
         _, mat = self.loss_matrix(preds, targets, weights)
-        perms = best_permutations(mat.detach().cpu().numpy())      # one small D2H copy per call
-        S = mat.shape[-1]
-        idx = torch.tensor(perms, device=mat.device)               # [B,S]
-        loss = torch.gather(mat, 2, idx[:, :, None]).squeeze(-1).mean(-1)
+        loss, perms = pit_select(mat)                              # permutation chosen on the device, no D2H copy
         return loss.to(torch.float32), perms
 
     @staticmethod
     def reorder_tensor(tensor, p):
         # criterion.py:180-200: out[b][..., i] = tensor[b][..., p[b][i]]
-        idx = torch.tensor([list(q) for q in p], device=tensor.device)
+        idx = p.idx if isinstance(p, DevicePerms) else torch.tensor([list(q) for q in p], device=tensor.device)
         shape = [tensor.shape[0]] + [1] * (tensor.dim() - 2) + [tensor.shape[-1]]
         return torch.gather(tensor, -1, idx.view(shape).expand_as(tensor))

@@ -57,26 +57,41 @@ def param_list(net):
     return list(net.features.parameters()) + list(net.fc.parameters())
 
 
-def trunk_forward(net, x, training):
-    f = net.features
+def stem_forward(f, x, training):
+    """conv7x7/s2 (+BN statistics) -> max-pool 3x3/s2 over relu(bn(y0)) read on the fly."""
     S = {"x": x}
     S["cv0"], S["y0"], S["bn0"] = _conv_bn(x, f[0], f[1], training)
     z, S["idx"] = K.maxpool3x3s2(S["y0"], S["bn0"][0], S["bn0"][1], ACT_RELU)
+    return S, z
+
+
+def block_forward(blk, z, training):
+    """One BasicBlock on a materialised post-ReLU input z -> (saved record, z')."""
+    R = {"mod": blk, "z": z}
+    R["cv1"], R["y1"], R["bn1"] = _conv_bn(z, blk.conv1, blk.bn1, training)
+    R["cv2"], R["y2"], R["bn2"] = _conv_bn(R["y1"], blk.conv2, blk.bn2, training, aff=R["bn1"])
+    if blk.downsample is not None:
+        R["cvd"], R["yd"], R["bnd"] = _conv_bn(z, blk.downsample[0], blk.downsample[1], training)
+        out = K.affine_act(R["y2"], R["bn2"][0], R["bn2"][1], R["yd"], ACT_RELU, R["bnd"][0], R["bnd"][1])
+    else:
+        out = K.affine_act(R["y2"], R["bn2"][0], R["bn2"][1], R["z"], ACT_RELU)
+    return R, out
+
+
+def fc_forward(fc, z):
+    cvf = _conv(z, fc)
+    bias = fc.bias.detach() if fc.bias is not None else None
+    return cvf, cvf.fwd(cvf.pack(_w(fc), 0), bias, None)
+
+
+def trunk_forward(net, x, training):
+    S, z = stem_forward(net.features, x, training)
     S["blocks"] = []
-    for blk in blocks_of(f):
-        R = {"mod": blk, "z": z}
-        R["cv1"], R["y1"], R["bn1"] = _conv_bn(z, blk.conv1, blk.bn1, training)
-        R["cv2"], R["y2"], R["bn2"] = _conv_bn(R["y1"], blk.conv2, blk.bn2, training, aff=R["bn1"])
-        if blk.downsample is not None:
-            R["cvd"], R["yd"], R["bnd"] = _conv_bn(z, blk.downsample[0], blk.downsample[1], training)
-            z = K.affine_act(R["y2"], R["bn2"][0], R["bn2"][1], R["yd"], ACT_RELU, R["bnd"][0], R["bnd"][1])
-        else:
-            z = K.affine_act(R["y2"], R["bn2"][0], R["bn2"][1], R["z"], ACT_RELU)
+    for blk in blocks_of(net.features):
+        R, z = block_forward(blk, z, training)
         S["blocks"].append(R)
-    S["cvf"] = _conv(z, net.fc)
-    S["zf"] = z
-    bias = net.fc.bias.detach() if net.fc.bias is not None else None
-    return S, S["cvf"].fwd(S["cvf"].pack(_w(net.fc), 0), bias, None)
+    S["cvf"], out = fc_forward(net.fc, z)
+    return S, out
 
 
 def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None):
@@ -86,43 +101,54 @@ def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None):
     return _bn_back(grads, bn_mod, bnrow, bst, y.numel() // y.shape[1])
 
 
-def trunk_backward(net, S, dout, grads):
-    f = net.features
-    cvf = S["cvf"]
-    dw, db = cvf.wgrad(dout, want_bias=net.fc.bias is not None)
-    _acc(grads, net.fc.weight, dw)
-    _acc(grads, net.fc.bias, db)
-    g = cvf.dgrad(cvf.pack(_w(net.fc), 1), dout)          # dL/dz of the last block
-    for R in reversed(S["blocks"]):
-        blk = R["mod"]
-        ds = blk.downsample is not None
-        bnd = R.get("bnd")
-        pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
-                             rs=bnd[0] if ds else None, rh=bnd[1] if ds else None)   # g = dL/d(pre-ReLU sum)
-        dy2 = K.bn_bwd_apply_(g, R["y2"], pqr2, out=torch.empty_like(g))
-        _acc(grads, blk.conv2.weight, R["cv2"].wgrad(dy2)[0])
-        da = R["cv2"].dgrad(R["cv2"].pack(_w(blk.conv2), 1), dy2)
-        del dy2
-        pqr1 = _relu_bn_back(grads, da, R["y1"], R["bn1"], blk.bn1)
-        K.bn_bwd_apply_(da, R["y1"], pqr1)                              # da = dL/dy1
-        _acc(grads, blk.conv1.weight, R["cv1"].wgrad(da)[0])
-        dz = R["cv1"].dgrad(R["cv1"].pack(_w(blk.conv1), 1), da)
-        del da
-        if ds:
-            bst = K.zeros_stats(g.shape[1], g)                          # BNd statistics of g (values of g unchanged)
-            K.affine_act_bwd_(g, R["yd"], None, None, None, None, bnd[2], bnd[3], ACT_NONE, bst)
-            pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, g.numel() // g.shape[1])
-            K.bn_bwd_apply_(g, R["yd"], pqrd)                           # g = dL/dyd
-            _acc(grads, blk.downsample[0].weight, R["cvd"].wgrad(g)[0])
-            dz.add_(R["cvd"].dgrad(R["cvd"].pack(_w(blk.downsample[0]), 1), g))
-        else:
-            dz.add_(g)
-        g = dz
+def fc_backward(fc, cvf, dout, grads):
+    dw, db = cvf.wgrad(dout, want_bias=fc.bias is not None)
+    _acc(grads, fc.weight, dw)
+    _acc(grads, fc.bias, db)
+    return cvf.dgrad(cvf.pack(_w(fc), 1), dout)
+
+
+def block_backward(R, g, grads):
+    """g = dL/dz' (consumed in place) -> dL/dz; parameter gradients are accumulated into `grads`."""
+    blk = R["mod"]
+    ds = blk.downsample is not None
+    bnd = R.get("bnd")
+    pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
+                         rs=bnd[0] if ds else None, rh=bnd[1] if ds else None)   # g = dL/d(pre-ReLU sum)
+    dy2 = K.bn_bwd_apply_(g, R["y2"], pqr2, out=torch.empty_like(g))
+    _acc(grads, blk.conv2.weight, R["cv2"].wgrad(dy2)[0])
+    da = R["cv2"].dgrad(R["cv2"].pack(_w(blk.conv2), 1), dy2)
+    del dy2
+    pqr1 = _relu_bn_back(grads, da, R["y1"], R["bn1"], blk.bn1)
+    K.bn_bwd_apply_(da, R["y1"], pqr1)                              # da = dL/dy1
+    _acc(grads, blk.conv1.weight, R["cv1"].wgrad(da)[0])
+    dz = R["cv1"].dgrad(R["cv1"].pack(_w(blk.conv1), 1), da)
+    del da
+    if ds:
+        bst = K.zeros_stats(g.shape[1], g)                          # BNd statistics of g (values of g unchanged)
+        K.affine_act_bwd_(g, R["yd"], None, None, None, None, bnd[2], bnd[3], ACT_NONE, bst)
+        pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, g.numel() // g.shape[1])
+        K.bn_bwd_apply_(g, R["yd"], pqrd)                           # g = dL/dyd
+        _acc(grads, blk.downsample[0].weight, R["cvd"].wgrad(g)[0])
+        dz.add_(R["cvd"].dgrad(R["cvd"].pack(_w(blk.downsample[0]), 1), g))
+    else:
+        dz.add_(g)
+    return dz
+
+
+def stem_backward(f, S, g, grads):
     y0 = S["y0"]
     g = K.maxpool3x3s2_bwd(g, S["idx"], y0.shape[2], y0.shape[3])
     pqr0 = _relu_bn_back(grads, g, y0, S["bn0"], f[1])
     K.bn_bwd_apply_(g, y0, pqr0)
-    _acc(grads, f[0].weight, S["cv0"].wgrad(g)[0])                      # the frames need no gradient
+    _acc(grads, f[0].weight, S["cv0"].wgrad(g)[0])                  # the frames need no gradient
+
+
+def trunk_backward(net, S, dout, grads):
+    g = fc_backward(net.fc, S["cvf"], dout, grads)                  # dL/dz of the last block
+    for R in reversed(S["blocks"]):
+        g = block_backward(R, g, grads)
+    stem_backward(net.features, S, g, grads)
 
 
 class _ResnetFn(torch.autograd.Function):

@@ -15,7 +15,7 @@ from . import kernels as K
 from . import lib
 from .lib import ACT_BY_NAME
 from .models import activate
-from .models.criterion import PitWrapper, best_permutations, mask_loss
+from .models.criterion import PitWrapper, mask_loss, pit_select
 
 args = None  # module-global like main.py's `args`, used by train_step when none is passed
 
@@ -59,9 +59,8 @@ class NetWrapper(torch.nn.Module):
         B = feat_sound.shape[0]
         pred, sums, FT = mask_loss(feat_sound, self._gt_stack, weight, act, "bce")   # PIT always uses BCE
         mat = sums / FT                                                              # [B,2,2] target x prediction
-        perms = best_permutations(mat.detach().cpu().numpy())
-        idx = torch.tensor(perms, device=mat.device)
-        err = torch.gather(mat, 2, idx[:, :, None]).squeeze(-1).mean(-1).mean().to(torch.float32)
+        loss, perms = pit_select(mat)                    # winning permutation picked on the device (no host sync)
+        err = loss.mean().to(torch.float32)
         pred_last = pred.permute(0, 2, 3, 1)                                          # B x F x T x C
         ordered = PitWrapper.reorder_tensor(pred_last, perms)
         gt = torch.stack(gt_masks, dim=-1)[:, 0]
@@ -123,9 +122,8 @@ class NetWrapper(torch.nn.Module):
             raise Exception("Unkown activation!")
         pred, sums, FT = mask_loss(feat_sound, self._gt_stack, weight, act, "bce")
         mat = sums / FT
-        perms = best_permutations(mat.detach().cpu().numpy())
-        idx = torch.tensor(perms, device=mat.device)
-        err = torch.gather(mat, 2, idx[:, :, None]).squeeze(-1).mean(-1).mean().to(torch.float32).reshape(1)
+        loss, perms = pit_select(mat)
+        err = loss.mean().to(torch.float32).reshape(1)
         ordered = PitWrapper.reorder_tensor(pred.permute(0, 2, 3, 1), perms)
         gt = torch.stack(gt_masks, dim=-1)[:, 0]
         match_loss = meta[0].reshape(1)
@@ -241,12 +239,13 @@ class FlatSGD:
             p.grad = gv
         self._early, self._early_left = None, 0             # disarmed until arm_early_reduce()
 
-    def arm_early_reduce(self, accumulations):
-        """Call between forward and backward: every parameter of the first group will be accumulated into exactly
-        `accumulations` times (= autograd nodes that own the U-Net's parameters in this step's graph); the
-        all-reduce of that group then starts the moment the last one lands."""
+    def arm_early_reduce(self, accumulations=1):
+        """Call between forward and backward.  Autograd runs each leaf's AccumulateGrad ONCE per backward, however
+        many graph nodes use the parameter, so the post-accumulate hook fires exactly once per parameter of the first
+        group; the all-reduce of that group starts the moment the last one lands.  (`accumulations` only says whether
+        the U-Net took part in this step's graph at all.)"""
         if self.world_size > 1 and self.overlap and accumulations > 0:
-            self._early_left = getattr(self, "_early_total", 0) * accumulations
+            self._early_left = getattr(self, "_early_total", 0)
 
     def _collect(self):
         # a caller that ran module.zero_grad(set_to_none=True) (torch default, main.py:560) left
@@ -260,16 +259,40 @@ class FlatSGD:
                 gv.copy_(p.grad)
             p.grad = gv
 
+    def _relayout(self, flat, to_logical):
+        """Copy of a flat buffer with every conv weight of the channels-last groups moved between the OHWI order it
+        has inside the flat buffers and the logical OIHW order (`to_logical`), or back."""
+        out = flat.clone()
+        off = 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                n = p.numel()
+                if g["channels_last"] and p.dim() == 4:
+                    O, I, KH, KW = p.shape
+                    seg = flat[off:off + n]
+                    out[off:off + n] = (seg.view(O, KH, KW, I).permute(0, 3, 1, 2) if to_logical
+                                        else seg.view(O, I, KH, KW).permute(0, 2, 3, 1)).reshape(-1)
+                off += n
+        return out
+
     def state_dict(self):
-        """Momentum buffers + per-group lr / started flags (what torch.optim.SGD.state_dict carries, flat)."""
-        return {"momentum_buffer": self.flat_buf.detach().cpu(),
+        """Momentum buffers + per-group lr / started flags (what torch.optim.SGD.state_dict carries, flat).  The
+        momentum is saved in LOGICAL (OIHW) order whatever layout the visual backend keeps inside the flat buffers,
+        so a run resumed under another AVSEP_VISION_BACKEND loads the right values."""
+        return {"momentum_buffer": self._relayout(self.flat_buf.detach(), True).cpu(), "layout": "oihw",
                 "groups": [{"name": g["name"], "lr": g["lr"], "started": bool(g.get("started", False)),
                             "range": list(g["range"])} for g in self.param_groups]}
 
     def load_state_dict(self, state):
         if [g["range"] for g in state["groups"]] != [list(g["range"]) for g in self.param_groups]:
             raise ValueError("optimizer state does not match the parameter groups")
-        self.flat_buf.copy_(state["momentum_buffer"])
+        buf = state["momentum_buffer"].to(self.flat_buf.device)
+        if state.get("layout") == "oihw":
+            buf = self._relayout(buf, False)
+        elif any(g["channels_last"] for g in self.param_groups):
+            raise ValueError("optimizer state without a layout tag (written before the layout was recorded) cannot be "
+                             "loaded into channels-last groups: resume with AVSEP_VISION_BACKEND=hip or retrain")
+        self.flat_buf.copy_(buf)
         for g, s in zip(self.param_groups, state["groups"]):
             g["lr"], g["started"] = s["lr"], s["started"]
 

@@ -104,8 +104,14 @@ def main(args):
     if args.load_ckpt:
         print("Recovered from history.")
         history = torch.load(os.path.join(args.ckpt, "history_latest.pth"))
-        start_i = history["train"]["iter"][-1] if history["train"]["iter"] else 0
-        ckpt.load_optimizer(optimizer, args)
+        start_i = ckpt.load_optimizer(optimizer, args)              # the iteration the checkpoint was written at
+        if start_i == 0:                                            # a reference-written checkpoint has no optimizer file
+            start_i = history["train"]["iter"][-1] if history["train"]["iter"] else 0
+        for g in optimizer.param_groups:                            # the restored (possibly decayed) learning rates
+            if g["name"] == "sound":
+                args.lr_sound = g["lr"]
+            elif g["name"] == "frame_features":
+                args.lr_frame = g["lr"]
     if args.mode == "eval":
         evaluate(wrapper, loader_val, history, 0, args, True, device, world)
         evaluate(wrapper, loader_val, history, 0, args, False, device, world)

@@ -338,7 +338,7 @@ def test_shared_encoder_pair_equals_two_passes(dev, golden):
         assert_close(a["b"][k].double(), b["b"][k].double(), 1e-6, "buffer " + k)
 
 
-@pytest.mark.parametrize("log_freq,backend", [(1, "torch"), (0, "hip")])
+@pytest.mark.parametrize("log_freq,backend", [(1, "torch"), (1, "hybrid"), (1, "hip"), (0, "hip")])
 def test_config1_full_size_step_vs_oracle(dev, log_freq, backend):
     """(log_freq 0 keeps the 512x256 tiles of configs[4]; backend "hip" runs the visual trunk on this library too.)
     BASELINE.json configs[0]/[1] shapes at batch 2: 65535-sample waveforms -> STFT 1022/256 -> 512x256 ->
