@@ -10,301 +10,9 @@
 //   operand address is  lane_base(pixel, parity) + const(pair, tap)  — zero VALU per operand.
 // The same kernel computes the data gradient (a 3x3/s1/p1 conv of dY with flipped, transposed weights):
 // only the weight packing differs.  D[co][pix], pixels on the lanes -> coalesced NCHW stores.
-#include "common.h"
+#include <stdlib.h>
 
-struct C3Args {
-  int N, Cin, H, W, Cout;
-  int C0, C1, act0, act1, up2x, Hs, Ws;
-  float rh, rw;
-  const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
-  const float* wp;
-  int wp_ld;
-  float* out;
-  const float* bias;
-  double* stats;
-  int tilesX, tilesY, gridM;
-  // generalised geometry (3x3/s1/p1: Ho = H, Wo = W, pad 1, unit store stride):
-  int Ho, Wo;            // output tile space
-  int padh, padw;        // patch origin = tile origin * S - pad
-  int os, ooh, oow;      // store position = (oh*os + ooh, ow*os + oow) in an [OHs x OWs] plane
-  int OHs, OWs;
-};
-
-constexpr int C3_CK = 4;            // input channels per K-tile of the 3x3 path (host-side packing constant)
-
-__device__ __forceinline__ float c3_src(const C3Args& a, int n, int c, int hs, int ws) {
-  float v;
-  if (c < a.C0) {
-    v = a.x0[(((long long)n * a.C0 + c) * a.Hs + hs) * a.Ws + ws];
-    if (a.sc0) v = fmaf(v, a.sc0[c], a.sh0[c]);
-    v = act_apply(v, a.act0);
-  } else {
-    int c1 = c - a.C0;
-    v = a.x1[(((long long)n * a.C1 + c1) * a.Hs + hs) * a.Ws + ws];
-    if (a.sc1) v = fmaf(v, a.sc1[c1], a.sh1[c1]);
-    v = act_apply(v, a.act1);
-  }
-  return v;
-}
-
-// KS x KS taps, stride S (1 or 2), dilation DIL, CK input channels per K-tile.  With S == 2 the patch columns are
-// stored de-interleaved (even columns, then odd columns) so that the 32 pixels of an MFMA column tile still read
-// consecutive LDS words (a stride-2 read would be a 2-way bank conflict on ds_read_b32).
-template <int TH, int TW, int BM, bool UP2X, int KS = 3, int S = 1, int DIL = 1, int CK = 4, int KH_ = KS, int KW_ = KS>
-__global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
-  constexpr int NT = KH_ * KW_, C3_KT = CK * NT, C3_CK = CK;
-  constexpr int PH = (TH - 1) * S + (KH_ - 1) * DIL + 1, PWR = (TW - 1) * S + (KW_ - 1) * DIL + 1;
-  constexpr int PW = (S == 2) ? (PWR + 1) / 2 * 2 : PWR, PWH = PW / 2, PS = PH * PW;   // patch per channel
-  constexpr int LDA = BM + 4;
-  constexpr int NPATCH = C3_CK * PS;
-  constexpr int PE = (NPATCH + 255) / 256;                // patch elements per thread
-  constexpr int A4 = BM / 4, NA4 = C3_KT * A4, AE = (NA4 + 255) / 256;
-  constexpr int WTM = BM / 2, TM = WTM / 32;              // waves 2 (M) x 2 (N); wave N-tile = 64 pixels
-  __shared__ __attribute__((aligned(16))) float As[2][C3_KT][LDA];
-  __shared__ float Ps[2][NPATCH];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
-  // block -> (pixel tile, image, M tile); consecutive logical ids share the pixel tile (same XCD L2)
-  int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = t % a.gridM; t /= a.gridM;
-  const int tx = t % a.tilesX; t /= a.tilesX;
-  const int ty = t % a.tilesY;
-  const int n = t / a.tilesY;
-  const int h0 = ty * TH, w0 = tx * TW, m0 = mt * BM;
-
-  // ---- loader state -------------------------------------------------------------------------------
-  // The f32 MFMA executes on the vector ALUs, so every VALU instruction inside the K loop is taken from
-  // it (measured: this loop without staging runs at 140 TFLOP/s).  All index decoding therefore happens
-  // ONCE here: each thread keeps a pointer per staged element that simply advances by one K-tile.
-  //   issue():  unconditional loads (clamped addresses) into registers + pointer bumps;
-  //   finish(): affine/activation (+ bilinear blend) + zero masking + LDS stores, after the MFMA loop.
-  const bool has0 = a.sc0 != nullptr, has1 = a.sc1 != nullptr;
-  const long long sHW = (long long)a.Hs * a.Ws;
-  f32x4 areg[AE];   // native vector type: an array of float4 structs is not promoted out of scratch memory
-  const float* aptr[AE];
-  int a_lds[AE];
-#pragma unroll
-  for (int e = 0; e < AE; ++e) {
-    int idx = min(tid + 256 * e, NA4 - 1);
-    int row = idx / A4, c4 = idx % A4;
-    aptr[e] = a.wp + (long long)row * a.wp_ld + m0 + c4 * 4;
-    a_lds[e] = row * LDA + c4 * 4;
-  }
-  const long long a_step = (long long)C3_KT * a.wp_ld;
-
-  constexpr int NRAW = UP2X ? 4 : 1;
-  float praw[PE][NRAW], psc[PE], psh[PE], plh[UP2X ? PE : 1], plw[UP2X ? PE : 1];
-  const float* pptr[PE][NRAW];      // element source pointers for the current K-tile (source 0 first)
-  long long poff1[PE][NRAW];        // offsets of the same elements inside source 1 (its channel 0 + cc)
-  int p_cc[PE];
-  int p_lds[S == 2 ? PE : 1];       // LDS slot of the element (identity for S == 1)
-  unsigned pok = 0;
-#pragma unroll
-  for (int e = 0; e < PE; ++e) {
-    int idx = min(tid + 256 * e, NPATCH - 1);
-    int cc = idx / PS, r = (idx % PS) / PW, col = idx % PW;
-    int gh = h0 * S - a.padh + r, gw = w0 * S - a.padw + col;
-    if constexpr (S == 2) p_lds[e] = cc * PS + r * PW + (col & 1) * PWH + (col >> 1);
-    bool ok = (PE * 256 == NPATCH || tid + 256 * e < NPATCH) && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
-    int ghc = min(max(gh, 0), a.H - 1), gwc = min(max(gw, 0), a.W - 1);
-    long long o[NRAW];
-    if constexpr (!UP2X) {
-      o[0] = (long long)ghc * a.Ws + gwc;
-    } else {  // nn.Upsample(x2, bilinear, align_corners=True): src = dst*(in-1)/(out-1)
-      float fh = a.rh * (float)ghc, fw = a.rw * (float)gwc;
-      int hh0 = (int)fh, ww0 = (int)fw;
-      int hh1 = hh0 + (hh0 < a.Hs - 1), ww1 = ww0 + (ww0 < a.Ws - 1);
-      plh[e] = fh - (float)hh0;
-      plw[e] = fw - (float)ww0;
-      o[0] = (long long)hh0 * a.Ws + ww0; o[1] = (long long)hh0 * a.Ws + ww1;
-      o[2] = (long long)hh1 * a.Ws + ww0; o[3] = (long long)hh1 * a.Ws + ww1;
-    }
-#pragma unroll
-    for (int q = 0; q < NRAW; ++q) {
-      pptr[e][q] = a.x0 + ((long long)n * a.C0 + cc) * sHW + o[q];
-      poff1[e][q] = ((long long)n * a.C1 + cc) * sHW + o[q];
-    }
-    p_cc[e] = cc;
-    pok |= (unsigned)ok << e;
-  }
-  const long long p_step = (long long)C3_CK * sHW;
-  const int kt_switch = a.C0 / C3_CK;          // first K-tile that reads source 1 (C0 % C3_CK == 0)
-  bool cur_has = has0;
-  const float *scp = a.sc0, *shp = a.sh0;      // affine rows of the current source, advanced per K-tile
-
-  auto issue = [&](int kt) __attribute__((always_inline)) {
-    if (kt == kt_switch && a.C1 > 0) {         // block-uniform: switch every element pointer to source 1
-#pragma unroll
-      for (int e = 0; e < PE; ++e)
-#pragma unroll
-        for (int q = 0; q < NRAW; ++q) pptr[e][q] = a.x1 + poff1[e][q];
-      cur_has = has1;
-      scp = a.sc1;
-      shp = a.sh1;
-    }
-#pragma unroll
-    for (int e = 0; e < AE; ++e) {
-      areg[e] = *reinterpret_cast<const f32x4*>(aptr[e]);
-      aptr[e] += a_step;
-    }
-#pragma unroll
-    for (int e = 0; e < PE; ++e) {
-#pragma unroll
-      for (int q = 0; q < NRAW; ++q) {
-        praw[e][q] = *pptr[e][q];
-        pptr[e][q] += p_step;
-      }
-      if (cur_has) {
-        psc[e] = scp[p_cc[e]];
-        psh[e] = shp[p_cc[e]];
-      }
-    }
-    if (cur_has) {
-      scp += C3_CK;
-      shp += C3_CK;
-    }
-  };
-  // the affine/activation flags that belong to the tile held in registers (issue() may already have switched)
-  bool fin_has = has0;
-  int fin_act = a.act0;
-  auto finish = [&](int buf, int kt) __attribute__((always_inline)) {
-    if (kt == kt_switch && a.C1 > 0) {
-      fin_has = has1;
-      fin_act = a.act1;
-    }
-    float* Ab = &As[buf][0][0];
-#pragma unroll
-    for (int e = 0; e < AE; ++e)
-      if (AE * 256 == NA4 || tid + 256 * e < NA4) *reinterpret_cast<f32x4*>(Ab + a_lds[e]) = areg[e];
-#pragma unroll
-    for (int e = 0; e < PE; ++e) {
-      float v;
-      if constexpr (!UP2X) {
-        v = praw[e][0];
-        if (fin_has) v = fmaf(v, psc[e], psh[e]);
-        v = act_apply(v, fin_act);
-      } else {
-        float q[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float t = praw[e][k];
-          if (fin_has) t = fmaf(t, psc[e], psh[e]);
-          q[k] = act_apply(t, fin_act);
-        }
-        v = (1.f - plh[e]) * ((1.f - plw[e]) * q[0] + plw[e] * q[1]) + plh[e] * ((1.f - plw[e]) * q[2] + plw[e] * q[3]);
-      }
-      if (PE * 256 == NPATCH || tid + 256 * e < NPATCH) {
-        if constexpr (S == 2) Ps[buf][p_lds[e]] = ((pok >> e) & 1u) ? v : 0.f;
-        else Ps[buf][tid + 256 * e] = ((pok >> e) & 1u) ? v : 0.f;
-      }
-    }
-  };
-
-  f32x16 acc[TM][2];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // B operand lane base for the wave's two 32-pixel MFMA column tiles (+ channel parity from the lane half)
-  int lb[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int p = wn * 64 + j * 32 + li;
-    lb[j] = (p / TW) * S * PW + (p % TW) + lk * PS;        // S == 2: the column index is halved by the de-interleave
-  }
-  const int nK = a.Cin / C3_CK;
-  issue(0);
-  finish(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nK; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nK) issue(kt + 1);
-    const float* P = Ps[buf];
-    // operands of k-step k2+1 are read into a second register set before the MFMAs of k-step k2 issue,
-    // so the LDS latency hides behind 4 x 64 MFMA cycles instead of stalling the wave every step
-    float av[2][TM], bv[2][2];
-    auto read_ops = [&](int k2, int slot) __attribute__((always_inline)) {
-      const int cp = k2 / NT, tap = k2 % NT, kh = tap / KW_, kw = tap % KW_;   // compile-time after unrolling
-      const int koff = (2 * cp) * PS + kh * DIL * PW + (S == 2 ? (kw & 1) * PWH + (kw >> 1) : kw * DIL);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[slot][i] = As[buf][2 * k2 + lk][wm * WTM + i * 32 + li];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bv[slot][j] = P[lb[j] + koff];
-    };
-    read_ops(0, 0);
-#pragma unroll
-    for (int k2 = 0; k2 < C3_KT / 2; ++k2) {
-      const int cur = k2 & 1;
-      if (k2 + 1 < C3_KT / 2) read_ops(k2 + 1, cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kt + 1 < nK) finish(buf ^ 1, kt + 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
-  const long long HW = (long long)a.OHs * a.OWs;
-  long long cbase[2];
-  bool cok[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int p = wn * 64 + j * 32 + li;
-    int gh = h0 + p / TW, gw = w0 + p % TW;
-    cok[j] = gh < a.Ho && gw < a.Wo;
-    cbase[j] = (long long)n * a.Cout * HW + (long long)(gh * a.os + a.ooh) * a.OWs + (gw * a.os + a.oow);
-  }
-  const bool want_stats = a.stats != nullptr;
-  float* s_sum = &As[0][0][0];   // [2][BM] per-wave-column partial sums (operand tiles are dead now)
-  float* s_sq = &As[1][0][0];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lrow = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      int row = m0 + lrow;
-      bool rok = row < a.Cout;
-      float bias = (a.bias && rok) ? a.bias[row] : 0.f;
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float v = acc[i][j][r] + bias;
-        if (rok && cok[j]) {
-          a.out[cbase[j] + (long long)row * HW] = v;
-          s += v;
-          q += v * v;
-        }
-      }
-      if (want_stats) {
-        s = half_sum(s);
-        q = half_sum(q);
-        if (li == 0) {
-          s_sum[wn * BM + lrow] = s;
-          s_sq[wn * BM + lrow] = q;
-        }
-      }
-    }
-  }
-  if (want_stats) {
-    __syncthreads();
-    for (int rr = tid; rr < BM; rr += 256) {
-      int row = m0 + rr;
-      if (row < a.Cout) {
-        atomicAdd(&a.stats[row], (double)(s_sum[rr] + s_sum[BM + rr]));
-        atomicAdd(&a.stats[a.Cout + row], (double)(s_sq[rr] + s_sq[BM + rr]));
-      }
-    }
-  }
-}
+#include "halo_kernel.h"
 
 // weight packing for this path.  Rows r = ((cpair*9 + tap)*2 + parity), column = output channel.
 //   mode 0 (forward): in-channel ci = 2*cpair+parity, value w[co][ci][tap],          column co
@@ -328,10 +36,18 @@ __global__ void c3_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // host side (called from conv.hip)
 // ---------------------------------------------------------------------------
 // forward: needs Cin % 4 == 0 and the source split on a chunk boundary; dgrad: Cout % 4 == 0
+// conv_flat.hip: flat-pixel tiles for the small square maps of the visual trunk
+int c3_flat_width(int H, int W, int dil);
+int c3_flat_launch(C3Args& a, int dil, hipStream_t st);
+static bool c3_flat(const avsep_conv_desc* d) {
+  return !d->up2x && d->C0 == d->Cin && c3_flat_width(d->H, d->W, d->dil) > 0 && (long long)d->N * d->H * d->W < 0x7fffffffLL &&
+         getenv("AVSEP_NO_FLAT") == nullptr;
+}
+
 bool c3_applicable(const avsep_conv_desc* d, int mode) {
   if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil)) return false;
   if (d->dil == 2 && d->up2x) return false;
-  if (d->W < 12 || d->H < 4 || d->N > 65535) return false;   // 14x14 maps (ResNet layer3/4) take the 8x16 tiles
+  if (!c3_flat(d) && (d->W < 12 || d->H < 4 || d->N > 65535)) return false;   // 7x7 maps only through the flat tiles
   if (mode == 0) return d->Cin % C3_CK == 0 && d->C0 % C3_CK == 0 && d->Cout > 4;
   return d->Cout % C3_CK == 0 && d->Cin >= 32;
 }
@@ -349,6 +65,8 @@ int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
 
 static int c3_launch(C3Args& a, hipStream_t st, int dil = 1) {
   a.Ho = a.H; a.Wo = a.W; a.padh = a.padw = dil; a.os = 1; a.ooh = a.oow = 0; a.OHs = a.H; a.OWs = a.W;
+  if (!a.up2x && a.C1 == 0 && c3_flat_width(a.H, a.W, dil) > 0 && getenv("AVSEP_NO_FLAT") == nullptr)
+    return c3_flat_launch(a, dil, st);
   const bool wide = a.W >= 32;
   a.tilesX = cdiv(a.W, wide ? 32 : 16);
   a.tilesY = cdiv(a.H, wide ? 4 : 8);
@@ -550,29 +268,27 @@ __device__ __forceinline__ float w3_src(const W3Args& a, int n, int c, int hs, i
   return v;
 }
 
-// one pixel tile of the wgrad GEMM for a wave that owns NTAP consecutive taps starting at tap0 (wave-uniform)
-template <int TH, int TW, int PW, int MAXT, int NTAP, int DIL = 1>
-__device__ __forceinline__ void w3_mfma_tile(const float* Ap, const float* Bp, int tap0, f32x16 (&acc)[MAXT]) {
-  int toff[NTAP];                                           // (kh*PW + kw) * dilation per owned tap
-#pragma unroll
-  for (int j = 0; j < NTAP; ++j) {
-    int tp = tap0 + j;
-    toff[j] = ((tp / 3) * PW + (tp % 3)) * DIL;
-  }
+// one pixel tile of the wgrad GEMM for a wave that owns the NTAP consecutive taps starting at TAP0.  TAP0 is a template
+// parameter so that every B address is ONE per-lane base register + an immediate (with a run-time tap0 each tap
+// needs its own address register and a v_add per read: measured 1.35 VALU instructions per MFMA in this loop, and the
+// f32 MFMA shares the vector ALUs).
+template <int TH, int TW, int PW, int MAXT, int TAP0, int NTAP, int DIL = 1>
+__device__ __forceinline__ void w3_mfma_tile(const float* Ap, const float* Bp, f32x16 (&acc)[MAXT]) {
+#pragma unroll 1
   for (int py = 0; py < TH; ++py) {
     const float* ar = Ap + py * TW;
     const float* br = Bp + py * PW;
     float av[2], bv[2][NTAP];                               // operands of the next k-step are read one step ahead
     av[0] = ar[0];
 #pragma unroll
-    for (int j = 0; j < NTAP; ++j) bv[0][j] = br[toff[j]];
+    for (int j = 0; j < NTAP; ++j) bv[0][j] = br[(((TAP0 + j) / 3) * PW + (TAP0 + j) % 3) * DIL];
 #pragma unroll 4
     for (int px = 0; px < TW; px += 2) {
       const int cur = (px >> 1) & 1;
       if (px + 2 < TW) {
         av[cur ^ 1] = ar[px + 2];
 #pragma unroll
-        for (int j = 0; j < NTAP; ++j) bv[cur ^ 1][j] = br[toff[j] + px + 2];
+        for (int j = 0; j < NTAP; ++j) bv[cur ^ 1][j] = br[(((TAP0 + j) / 3) * PW + (TAP0 + j) % 3) * DIL + px + 2];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -594,8 +310,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   constexpr int NP = W3_CC * PH * PW, PE = (NP + NT - 1) / NT;
   constexpr int NA4 = BM * NPIX / 4, AE = NA4 / NT;
   static_assert(NA4 % NT == 0, "A tile must split evenly");
-  __shared__ float As[2][BM * LDA];   // double buffered: one barrier per pixel tile
-  __shared__ float Ps[2][W3_CC * PS];
+  // ONE array, the patch first: ds_read offsets are 16-bit immediates, and the 4-5 B reads per k-step (patch) must
+  // stay below 64 KB so that they need no address arithmetic (the A tile behind it is read once per k-step)
+  __shared__ float smem[2 * W3_CC * PS + 2 * BM * LDA];
+  float (*Ps)[W3_CC * PS] = reinterpret_cast<float (*)[W3_CC * PS]>(smem);
+  float (*As)[BM * LDA] = reinterpret_cast<float (*)[BM * LDA]>(smem + 2 * W3_CC * PS);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
   const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
@@ -604,12 +323,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   const int t_begin = split * a.tiles_per_split, t_end = min(tiles_all, t_begin + a.tiles_per_split);
   const long long HW = (long long)a.H * a.W;
 
-  // BM=128: 4 row blocks x tap groups {0-4},{5-8};  BM=64: 2 row blocks x tap groups {0-2},{3,4},{5,6},{7,8}
+  // BM=128: 4 row blocks x tap groups {0-4},{5-8} (waves w and w+4 share a SIMD: 9 MFMAs per SIMD and k-step);
+  // BM=64: 2 row blocks x tap groups {0-2},{3,4},{5,6},{7,8}
   constexpr int RB = BM / 32, MAXT = (BM == 128) ? 5 : 3;
-  const int wrow = wave % RB, tg = wave / RB;
-  const int tap0 = __builtin_amdgcn_readfirstlane(BM == 128 ? (tg ? 4 : 0) : (tg == 0 ? 0 : 1 + 2 * tg));
-  const int ntap = __builtin_amdgcn_readfirstlane(BM == 128 ? 5 : (tg == 0 ? 3 : 2));
-  const int jskip = (BM == 128 && tg) ? 1 : 0;             // BM=128, second group: acc[0] duplicates tap 4
+  const int wrow = wave % RB, tg = __builtin_amdgcn_readfirstlane(wave / RB);
+  const int tap0 = BM == 128 ? (tg ? 5 : 0) : (tg == 0 ? 0 : 1 + 2 * tg);
+  const int ntap = BM == 128 ? (tg ? 4 : 5) : (tg == 0 ? 3 : 2);
   f32x16 acc[MAXT];
 #pragma unroll
   for (int j = 0; j < MAXT; ++j)
@@ -626,31 +345,30 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   const float* shs = first_src ? a.sh0 : a.sh1;
   const int act_s = first_src ? a.act0 : a.act1;
   const long long sHW = (long long)a.Hs * a.Ws;
-  int a_goff[AE], a_lds[AE], a_r[AE], a_c[AE];
-  bool a_rowok[AE];
+  // per staged element ONE packed word: LDS slot (bits 0-15) | tile row (16-19) | tile column (20-25) | valid (31).
+  // (separate registers for these cost ~26 VGPRs and pushed the 128-row instantiations into scratch)
+  static_assert(BM * LDA < 65536 && W3_CC * PS < 65536 && TH < 16 && PH < 16 && PW < 64, "packed staging word");
+  int a_goff[AE];
+  unsigned a_pk[AE];
 #pragma unroll
   for (int e = 0; e < AE; ++e) {
     int idx = tid + NT * e;
     int q = idx % (TW / 4), r = (idx / (TW / 4)) % TH, co = idx / (NPIX / 4);
-    a_rowok[e] = m0 + co < a.Cout;
     a_goff[e] = min(m0 + co, a.Cout - 1) * (int)HW + r * a.W + 4 * q;   // Cout*H*W < 2^31 is checked on the host
-    a_lds[e] = co * LDA + r * TW + 4 * q;
-    a_r[e] = r;
-    a_c[e] = 4 * q;
+    a_pk[e] = (unsigned)(co * LDA + r * TW + 4 * q) | (unsigned)r << 16 | (unsigned)(4 * q) << 20 |
+              (m0 + co < a.Cout ? 0x80000000u : 0u);
   }
-  int p_goff[PE], p_lds[PE], p_r[PE], p_col[PE];
+  int p_goff[PE];
+  unsigned p_pk[PE];
   float p_sc[PE], p_sh[PE];
-  bool p_chok[PE];
 #pragma unroll
   for (int e = 0; e < PE; ++e) {
     int idx = min(tid + NT * e, NP - 1);
     int cc = idx / (PH * PW), r = (idx % (PH * PW)) / PW, col = idx % PW;
-    p_chok[e] = (PE * NT == NP || tid + NT * e < NP) && c0 + cc < a.Cin;
+    const bool chok = (PE * NT == NP || tid + NT * e < NP) && c0 + cc < a.Cin;
     int cs = min(csrc0 + cc, Csrc - 1);
     p_goff[e] = cs * (int)sHW + (r - DIL) * a.Ws + (col - DIL);
-    p_lds[e] = cc * PS + r * PW + col;
-    p_r[e] = r - DIL;
-    p_col[e] = col - DIL;
+    p_pk[e] = (unsigned)(cc * PS + r * PW + col) | (unsigned)r << 16 | (unsigned)col << 20 | (chok ? 0x80000000u : 0u);
     p_sc[e] = scs ? scs[cs] : 1.f;
     p_sh[e] = scs ? shs[cs] : 0.f;
   }
@@ -664,11 +382,14 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
     amask = pmask = 0;
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
-      const bool ok = a_rowok[e] && h0 + a_r[e] < a.H && w0 + a_c[e] < a.W;
+      unsigned pk = a_pk[e];
+      asm volatile("" : "+v"(pk));          // opaque: keeps the decode inside the tile loop (LICM would re-expand it into registers)
+      const int a_r = (pk >> 16) & 15, a_c = (pk >> 20) & 63;
+      const bool ok = (pk >> 31) && h0 + a_r < a.H && w0 + a_c < a.W;
       if constexpr (!A2) {
         areg[e] = *reinterpret_cast<const f32x4*>(ok ? dyb + a_goff[e] : a.dy);
       } else {                 // the second pair of the quad may lie past the row end
-        const bool ok2 = ok && w0 + a_c[e] + 2 < a.W;
+        const bool ok2 = ok && w0 + a_c + 2 < a.W;
         const float2 lo = *reinterpret_cast<const float2*>(ok ? dyb + a_goff[e] : a.dy);
         const float2 hi = *reinterpret_cast<const float2*>(ok2 ? dyb + a_goff[e] + 2 : a.dy);
         areg[e] = f32x4{lo.x, lo.y, ok2 ? hi.x : 0.f, ok2 ? hi.y : 0.f};
@@ -677,7 +398,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
     }
 #pragma unroll
     for (int e = 0; e < PE; ++e) {
-      const bool ok = p_chok[e] && (unsigned)(h0 + p_r[e]) < (unsigned)a.H && (unsigned)(w0 + p_col[e]) < (unsigned)a.W;
+      unsigned pk = p_pk[e];
+      asm volatile("" : "+v"(pk));
+      const int p_r = (int)((pk >> 16) & 15) - DIL, p_col = (int)((pk >> 20) & 63) - DIL;
+      const bool ok = (pk >> 31) && (unsigned)(h0 + p_r) < (unsigned)a.H && (unsigned)(w0 + p_col) < (unsigned)a.W;
       praw[e] = *(ok ? xb + p_goff[e] : xsrc);
       pmask |= (unsigned)ok << e;
     }
@@ -686,13 +410,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
       const bool ok = (amask >> e) & 1u;
-      float* d = &As[buf][a_lds[e]];
+      unsigned pk = a_pk[e];
+      asm volatile("" : "+v"(pk));
+      float* d = &As[buf][pk & 0xffffu];
       d[0] = ok ? areg[e].x : 0.f; d[1] = ok ? areg[e].y : 0.f; d[2] = ok ? areg[e].z : 0.f; d[3] = ok ? areg[e].w : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < PE; ++e) {
       float v = act_apply(fmaf(praw[e], p_sc[e], p_sh[e]), act_s);
-      if (PE * NT == NP || tid + NT * e < NP) Ps[buf][p_lds[e]] = ((pmask >> e) & 1u) ? v : 0.f;
+      unsigned pk = p_pk[e];
+      asm volatile("" : "+v"(pk));
+      if (PE * NT == NP || tid + NT * e < NP) Ps[buf][pk & 0xffffu] = ((pmask >> e) & 1u) ? v : 0.f;
     }
   };
   // bilinear-upsampled virtual input: staged directly (4 corner loads per element do not fit the register pipeline)
@@ -730,15 +458,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
     if (t + 1 < t_end) issue(t + 1);
     const float* Ap = As[buf] + (wrow * 32 + li) * LDA + lk;
     const float* Bp = Ps[buf] + li * PS + lk;
-    // straight-line MFMA loops per tap-group size (a per-MFMA `if (j < ntap)` would put every MFMA in its own
-    // basic block and defeat the operand prefetch)
+    // one straight-line MFMA stream per tap group (wave-uniform switch; compile-time taps -> immediate LDS offsets)
     if constexpr (BM == 128) {
-      // both tap groups run 5 taps ({0..4} and {4..8}: tap 4 is computed twice, the copy is dropped in the
-      // epilogue) so the whole loop is one branch-free instruction stream; costs 10 instead of 9 MFMAs per step
-      w3_mfma_tile<TH, TW, PW, MAXT, MAXT, DIL>(Ap, Bp, tap0, acc);
+      if (tg == 0) w3_mfma_tile<TH, TW, PW, MAXT, 0, 5, DIL>(Ap, Bp, acc);
+      else w3_mfma_tile<TH, TW, PW, MAXT, 5, 4, DIL>(Ap, Bp, acc);
     } else {
-      if (ntap == MAXT) w3_mfma_tile<TH, TW, PW, MAXT, MAXT, DIL>(Ap, Bp, tap0, acc);
-      else w3_mfma_tile<TH, TW, PW, MAXT, MAXT - 1, DIL>(Ap, Bp, tap0, acc);
+      if (tg == 0) w3_mfma_tile<TH, TW, PW, MAXT, 0, 3, DIL>(Ap, Bp, acc);
+      else if (tg == 1) w3_mfma_tile<TH, TW, PW, MAXT, 3, 2, DIL>(Ap, Bp, acc);
+      else if (tg == 2) w3_mfma_tile<TH, TW, PW, MAXT, 5, 2, DIL>(Ap, Bp, acc);
+      else w3_mfma_tile<TH, TW, PW, MAXT, 7, 2, DIL>(Ap, Bp, acc);
     }
     if (t + 1 < t_end) {
       finish(buf ^ 1);
@@ -750,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   const int ci = c0 + li;
 #pragma unroll
   for (int j = 0; j < MAXT; ++j)
-    if (j < ntap && j >= jskip) {
+    if (j < ntap) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int co = m0 + wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;

@@ -46,6 +46,15 @@ CONV_CASES = [
     (24, 6, 64, 64, 136, 4, 2, 1, 1),      # 128-row M tiles (>= 384 workgroups), second M tile ragged
     (96, 4, 32, 32, 136, 4, 2, 1, 1),      # 8x16 tiles x 128 rows
     (3, 32, 34, 32, 64, 4, 2, 1, 1),       # 8x16 tiles x 64 rows, Ho = 17
+    # flat-pixel tiles (conv_flat.hip): 128 consecutive pixels of (n, h, w) per tile, tiles cross image boundaries
+    (5, 32, 7, 7, 40, 3, 1, 1, 1),         # 7x7 maps (resnet18fc layer4): up to 4 images per tile
+    (3, 16, 28, 28, 40, 3, 1, 1, 1),       # 28x28
+    (2, 16, 28, 28, 40, 3, 1, 2, 2),       # 28x28 dilated (dilate_scale 8, layer3)
+    (2, 8, 56, 56, 72, 3, 1, 1, 1),        # 56x56, two 64-row M tiles
+    (2, 16, 20, 14, 40, 3, 1, 1, 1),       # H > W
+    (130, 8, 14, 14, 136, 3, 1, 1, 1),     # 128-row M tiles (>= 384 workgroups), ragged second M tile, last pixel tile partial
+    (130, 8, 14, 14, 136, 3, 1, 2, 2),     # same, dilated
+    (8, 4, 56, 56, 136, 3, 1, 1, 1),       # 128-row M tiles at 56x56
 ]
 
 
