@@ -557,6 +557,16 @@ int c4_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
 int c4_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st);
 int c4_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
 size_t w3_workspace_floats(const avsep_conv_desc* d);
+// conv_bf16.hip: bf16-operand halo-patch kernels (desc.prec == AVSEP_PREC_BF16)
+bool bf_applicable(const avsep_conv_desc* d, int mode);
+size_t bf_packed_floats(const avsep_conv_desc* d, int mode);
+int bf_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
+int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st);
+int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
+// wgrad_bf16.hip
+bool wb_applicable(const avsep_conv_desc* d);
+size_t wb_workspace_floats(const avsep_conv_desc* d);
+int wb_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 static int check_desc(const avsep_conv_desc* d, bool fwd_only = false) {
   if (!d || !d->x0) return AVSEP_ERR_ARG;
@@ -573,6 +583,7 @@ static int check_desc(const avsep_conv_desc* d, bool fwd_only = false) {
   if (d->up2x && ((d->H & 1) || (d->W & 1))) return AVSEP_ERR_ARG;
   if ((d->scale0 == nullptr) != (d->shift0 == nullptr)) return AVSEP_ERR_ARG;
   if ((d->scale1 == nullptr) != (d->shift1 == nullptr)) return AVSEP_ERR_ARG;
+  if (d->prec != AVSEP_PREC_F32 && d->prec != AVSEP_PREC_BF16) return AVSEP_ERR_ARG;
   return AVSEP_OK;
 }
 
@@ -597,6 +608,7 @@ static inline int packed_ld(const avsep_conv_desc* d, int mode) { return roundup
 extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
   if (!d || (mode != 0 && mode != 1)) return 0;
   if (mode == 1 && smallci_applicable(d)) return (size_t)d->Cout * d->Cin * d->KH * d->KW;   // OIHW as is
+  if (bf_applicable(d, mode)) return bf_packed_floats(d, mode);
   if (c3_applicable(d, mode)) return c3_packed_floats(d, mode);
   if (c4_applicable(d, mode)) return c4_packed_floats(d, mode);
   return (size_t)packed_rows(d, mode) * packed_ld(d, mode);
@@ -611,6 +623,7 @@ extern "C" int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w,
       return AVSEP_ERR_LAUNCH;
     return AVSEP_OK;
   }
+  if (bf_applicable(d, mode)) return bf_pack(d, w, packed, mode, (hipStream_t)stream);
   if (c3_applicable(d, mode)) return c3_pack(d, w, packed, mode, (hipStream_t)stream);
   if (c4_applicable(d, mode)) return c4_pack(d, w, packed, mode, (hipStream_t)stream);
   int rows = packed_rows(d, mode), ld = packed_ld(d, mode);
@@ -642,7 +655,8 @@ static SplitPlan splitk_plan(long long tiles, int K) {
   return p;
 }
 static bool fwd_uses_igemm(const avsep_conv_desc* d, const double* stats) {
-  return !((!stats && (smallco_applicable(d) || head_applicable(d))) || c3_applicable(d, 0) || c4_applicable(d, 0));
+  return !((!stats && (smallco_applicable(d) || head_applicable(d))) || bf_applicable(d, 0) || c3_applicable(d, 0) ||
+           c4_applicable(d, 0));
 }
 static SplitPlan fwd_split(const avsep_conv_desc* d) {
   long long ncols = (long long)d->N * d->Ho * d->Wo;
@@ -665,7 +679,7 @@ extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cout * d->Ho * d->Wo * sizeof(float) : 0;
 }
 extern "C" size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d) {
-  if (check_desc(d) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1)) return 0;
+  if (check_desc(d) || bf_applicable(d, 1) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1)) return 0;
   SplitPlan p = dgrad_split(d);
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cin * d->H * d->W * sizeof(float) : 0;
 }
@@ -677,6 +691,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   if (!w_packed || !y) return AVSEP_ERR_ARG;
   if (!stats && smallco_applicable(d)) return smallco_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
   if (!stats && head_applicable(d)) return head_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
+  if (bf_applicable(d, 0)) return bf_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (c3_applicable(d, 0)) return c3_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (c4_applicable(d, 0)) return c4_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   CArgs a = make_args(d);
@@ -719,6 +734,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   if (rc) return rc;
   if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
   if (smallci_applicable(d)) return smallci_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
+  if (bf_applicable(d, 1)) return bf_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c3_applicable(d, 1)) return c3_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c4_applicable(d, 1)) return c4_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   CArgs a = make_args(d);
@@ -781,6 +797,7 @@ extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (check_desc(d)) return 0;
   if (smallco_applicable(d)) return smallco_wgrad_workspace_floats(d) * sizeof(float);
   if (head_applicable(d)) return head_wgrad_workspace_floats(d) * sizeof(float);
+  if (wb_applicable(d)) return wb_workspace_floats(d) * sizeof(float);
   if (w3_applicable(d)) return w3_workspace_floats(d) * sizeof(float);
   WgradPlan p = wgrad_plan(d);
   if (p.splits <= 1) return 0;
@@ -797,8 +814,9 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   if (need > workspace_bytes || (need && !workspace)) return AVSEP_ERR_WORKSPACE;
   if (smallco_applicable(d)) return smallco_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
   if (head_applicable(d)) return head_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
-  if (w3_applicable(d)) {
-    int rc3 = w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
+  if (wb_applicable(d) || w3_applicable(d)) {
+    int rc3 = wb_applicable(d) ? wb_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
+                               : w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
     if (rc3) return rc3;
     if (dbias) {
       hipLaunchKernelGGL(channel_sum_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, dy, d->N, d->Cout,

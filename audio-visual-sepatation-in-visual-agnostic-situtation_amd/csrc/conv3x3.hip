@@ -534,6 +534,11 @@ __global__ void w3_reduce_kernel(const float* __restrict__ ws, float* __restrict
 #pragma unroll
   for (int t = 0; t < 9; ++t) out[cc * 9 + t] = s[t];
 }
+int w3_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st) {
+  hipLaunchKernelGGL(w3_reduce_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, ws, dw, P, splits);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
 int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st) {
   W3Plan p = w3_plan(d);
   W3Args a{};

@@ -1,0 +1,186 @@
+// bf16-operand / fp32-accumulate convolutions (avsep_conv_desc.prec == AVSEP_PREC_BF16): host side of halo_bf16.h.
+//   3x3 / stride 1 / pad = dil (dil 1, 2): forward, and data gradient through flipped + transposed weights
+//     — the U-Net decoder convs (models/audio_net.py:75-76,85-87,96-98,180-182) and the ResNet BasicBlock convs
+//       (models/vision_net.py:84-92 over torchvision resnet18);
+//   4x4 / stride 2 / pad 1: forward (U-Net encoder, audio_net.py:57-58,170-171) and its data gradient as four 2x2-tap
+//     parity classes (see conv3x3.hip);
+//   3x3 / stride 2 / pad 1 forward (ResNet layer2.0 / layer3.0 conv1).
+// Packed weight image (bf16), written once per optimizer step by bf_pack_kernel and copied tile by tile into LDS by
+// LDS-DMA:  [K-tile kt (16 channels)][tap][m (padded to 128)][16 channels], the two 8-channel halves of a row swapped
+// when bit 3 of m is set (the LDS bank swizzle of halo_bf16.h, applied at pack time because the DMA cannot permute).
+#include <stdlib.h>
+
+#include "halo_bf16.h"
+
+// mode 0: forward  M = Cout, k-channel = ci, value w[m][c][tap]
+// mode 1: dgrad    M = Cin,  k-channel = co, value w[c][m][flip(tap)]           (KH x KW taps, stride 1)
+// mode 2: dgrad of a 4x4/s2 conv, 4 parity classes x 2x2 taps: class cls at image offset cls * (Kc/16)*4*ld rows;
+//         tap (th, tw) of class (ph, pw) -> (kh, kw) = (ph ? 2-2*th : 3-2*th, pw ? 2-2*tw : 3-2*tw)
+__global__ void bf_pack_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cout, int Cin, int KH, int KW,
+                               int ld, int ktiles, int mode) {
+  const int NT = mode == 2 ? 4 : KH * KW;
+  const long long rows = (long long)(mode == 2 ? 4 : 1) * ktiles * NT * ld;      // 32-byte rows
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (row, stored half)
+  if (i >= rows * 2) return;
+  const long long row = i >> 1;
+  const int hs = (int)(i & 1);
+  const int m = (int)(row % ld);
+  long long q = row / ld;
+  const int tap = (int)(q % NT); q /= NT;
+  const int kt = (int)(q % ktiles);
+  const int cls = (int)(q / ktiles);
+  const int h = hs ^ ((m >> 3) & 1);                                             // logical half stored in slot hs
+  const int KHW = KH * KW;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = kt * 16 + 8 * h + j;
+    float x = 0.f;
+    if (mode == 0) {
+      if (m < Cout && c < Cin) x = w[((long long)m * Cin + c) * KHW + tap];
+    } else if (mode == 1) {
+      if (m < Cin && c < Cout) x = w[((long long)c * Cin + m) * KHW + (KHW - 1 - tap)];
+    } else {
+      const int ph = cls >> 1, pw = cls & 1, th = tap >> 1, tw = tap & 1;
+      const int kh = ph ? 2 - 2 * th : 3 - 2 * th, kw = pw ? 2 - 2 * tw : 3 - 2 * tw;
+      if (m < Cin && c < Cout) x = w[((long long)c * Cin + m) * 16 + kh * 4 + kw];
+    }
+    v[j] = x;
+  }
+  u32x4 o = {bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
+  reinterpret_cast<u32x4*>(out)[i] = o;
+}
+
+static inline bool bf_enabled() { return getenv("AVSEP_NO_BF16_KERNELS") == nullptr; }
+
+// geometry classes served by convbf_kernel; mode 0 forward, 1 data gradient
+static int bf_class(const avsep_conv_desc* d) {
+  if (d->up2x || d->C0 != d->Cin) return 0;
+  if (d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil) return 3;
+  if (d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->dil == 1) return 4;
+  return 0;
+}
+static bool bf_flat(const avsep_conv_desc* d) { return d->H >= d->W && (d->W == 14 || d->W == 7) && (d->dil == 1 || d->W == 14); }
+
+bool bf_applicable(const avsep_conv_desc* d, int mode) {
+  if (d->prec != AVSEP_PREC_BF16 || !bf_enabled()) return false;
+  const int cls = bf_class(d);
+  if (!cls) return false;
+  const int kc = mode == 0 ? d->Cin : d->Cout, m = mode == 0 ? d->Cout : d->Cin;
+  if (kc % BF_CK != 0 || m < 32) return false;
+  if (mode == 0 && d->scale0 && d->Cin > BF_AFF_MAX) return false;
+  // 32-bit element offsets inside the staged tensor; grid dimension
+  const long long in_elems = mode == 0 ? (long long)d->N * d->Cin * d->H * d->W : (long long)d->N * d->Cout * d->Ho * d->Wo;
+  if (in_elems >= (1LL << 30) || d->N > 65535) return false;
+  if (cls == 3) return bf_flat(d) || (d->W >= 16 && d->H >= 4);
+  if (mode == 0) return d->Wo >= 16 && d->Ho >= 4;
+  return d->Wo >= 16 && d->Ho >= 4 && (d->H & 1) == 0 && (d->W & 1) == 0;
+}
+
+size_t bf_packed_floats(const avsep_conv_desc* d, int mode) {
+  const int kc = mode == 0 ? d->Cin : d->Cout, ld = roundup(mode == 0 ? d->Cout : d->Cin, 128);
+  const int NT = (bf_class(d) == 4 && mode == 1) ? 16 : d->KH * d->KW;           // 4 classes x 4 taps
+  return (size_t)(kc / BF_CK) * NT * ld * 8;                                      // 32-byte rows = 8 floats
+}
+
+int bf_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st) {
+  const int kc = mode == 0 ? d->Cin : d->Cout, ld = roundup(mode == 0 ? d->Cout : d->Cin, 128);
+  const int pmode = (bf_class(d) == 4 && mode == 1) ? 2 : mode;
+  const long long halves = (long long)bf_packed_floats(d, mode) / 4;
+  hipLaunchKernelGGL(bf_pack_kernel, dim3(cdiv(halves, 256)), dim3(256), 0, st, w, reinterpret_cast<unsigned*>(packed),
+                     d->Cout, d->Cin, d->KH, d->KW, ld, kc / BF_CK, pmode);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// ---- launch: tile choice ------------------------------------------------------------------------------------------
+// KH_/KW_/S_/DIL_ select the instantiation; a.Ho/Wo = output tile space.  256-pixel tiles x 128 rows (512 threads)
+// when that still yields >= 2 workgroups per CU-slot, else 128-pixel tiles; 64-row tiles for Cout <= 64.
+template <int KH_, int KW_, int S_, int DIL_>
+static int bf_launch_rect(C3Args& a, hipStream_t st) {
+  const bool wide = a.Wo >= 32;
+  // 16-tap weight tiles of 128 rows (2 x 64 KB) would not fit beside the stride-2 patch: 64-row tiles there
+  constexpr bool ONLY64 = KH_ * KW_ > 9;
+  const bool m64 = a.Cout <= 64 || ONLY64;
+  const int gm = cdiv(a.Cout, m64 ? 64 : 128);
+  const long long wg256 = (long long)gm * cdiv(a.Wo, wide ? 32 : 16) * cdiv(a.Ho, wide ? 8 : 16) * a.N;
+  const bool big = wg256 >= 512 && a.Ho >= (wide ? 8 : 16);
+  a.gridM = gm;
+  a.tilesX = cdiv(a.Wo, wide ? 32 : 16);
+  a.tilesY = cdiv(a.Ho, wide ? (big ? 8 : 4) : (big ? 16 : 8));
+  dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
+#define BF_L(TH_, TW_, BM_, NWN_) \
+  hipLaunchKernelGGL((convbf_kernel<TH_, TW_, BM_, KH_, KW_, S_, DIL_, 0, NWN_>), grid, dim3(128 * NWN_), 0, st, a)
+  if (m64) {
+    if (big) { if (wide) BF_L(8, 32, 64, 4); else BF_L(16, 16, 64, 4); }
+    else { if (wide) BF_L(4, 32, 64, 2); else BF_L(8, 16, 64, 2); }
+  } else if constexpr (!ONLY64) {
+    if (big) { if (wide) BF_L(8, 32, 128, 4); else BF_L(16, 16, 128, 4); }
+    else { if (wide) BF_L(4, 32, 128, 2); else BF_L(8, 16, 128, 2); }
+  }
+#undef BF_L
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+template <int FW_, int DIL_>
+static int bf_launch_flat(C3Args& a, hipStream_t st) {
+  const long long P = (long long)a.N * a.H * a.W;
+  const bool m64 = a.Cout <= 64;
+  a.gridM = cdiv(a.Cout, m64 ? 64 : 128);
+  const bool big = (long long)a.gridM * cdiv(P, 256) >= 512;
+  a.tilesX = cdiv(P, big ? 256 : 128);
+  a.tilesY = 1;
+  dim3 grid((unsigned)((long long)a.gridM * a.tilesX));
+#define BF_F(BM_, NWN_) \
+  hipLaunchKernelGGL((convbf_kernel<0, 0, BM_, 3, 3, 1, DIL_, FW_, NWN_>), grid, dim3(128 * NWN_), 0, st, a)
+  if (big) { if (m64) BF_F(64, 4); else BF_F(128, 4); }
+  else { if (m64) BF_F(64, 2); else BF_F(128, 2); }
+#undef BF_F
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+static int bf3_launch(C3Args& a, int dil, hipStream_t st) {
+  a.Ho = a.H; a.Wo = a.W; a.padh = a.padw = dil; a.os = 1; a.ooh = a.oow = 0; a.OHs = a.H; a.OWs = a.W;
+  if (a.H >= a.W && (a.W == 14 || a.W == 7)) {
+    if (a.W == 14) return dil == 1 ? bf_launch_flat<14, 1>(a, st) : bf_launch_flat<14, 2>(a, st);
+    return bf_launch_flat<7, 1>(a, st);
+  }
+  return dil == 1 ? bf_launch_rect<3, 3, 1, 1>(a, st) : bf_launch_rect<3, 3, 1, 2>(a, st);
+}
+
+int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st) {
+  C3Args a{};
+  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.C0 = d->Cin; a.C1 = 0; a.act0 = d->act0; a.Hs = d->H; a.Ws = d->W;
+  a.x0 = d->x0; a.sc0 = d->scale0; a.sh0 = d->shift0;
+  a.wp = wp; a.wp_ld = roundup(d->Cout, 128); a.out = y; a.bias = bias; a.stats = stats;
+  if (bf_class(d) == 3) return bf3_launch(a, d->dil, st);
+  a.Ho = d->Ho; a.Wo = d->Wo; a.padh = a.padw = 1; a.os = 1; a.ooh = a.oow = 0; a.OHs = d->Ho; a.OWs = d->Wo;
+  return bf_launch_rect<4, 4, 2, 1>(a, st);
+}
+
+int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st) {
+  if (bf_class(d) == 3) {
+    C3Args a{};
+    a.N = d->N; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
+    a.C0 = d->Cout; a.C1 = 0; a.Hs = d->H; a.Ws = d->W;
+    a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
+    return bf3_launch(a, d->dil, st);
+  }
+  const int ld = roundup(d->Cin, 128);
+  const size_t cls_floats = (size_t)(d->Cout / BF_CK) * 4 * ld * 8;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    C3Args a{};
+    a.N = d->N; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
+    a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
+    a.x0 = dy; a.wp = wp + cls * cls_floats; a.wp_ld = ld; a.out = dx;
+    a.Ho = d->H / 2; a.Wo = d->W / 2; a.padh = ph ? 0 : 1; a.padw = pw ? 0 : 1;
+    a.os = 2; a.ooh = ph; a.oow = pw; a.OHs = d->H; a.OWs = d->W;
+    int rc = bf_launch_rect<2, 2, 1, 1>(a, st);
+    if (rc) return rc;
+  }
+  return AVSEP_OK;
+}

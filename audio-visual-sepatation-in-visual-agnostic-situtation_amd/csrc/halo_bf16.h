@@ -22,6 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BF_CK = 16;   // input channels per K-tile = k extent of one 32x32x16 MFMA
+constexpr int BF_AFF_MAX = 1024;   // channels of a folded affine kept in LDS (host-checked)
 
 __device__ __forceinline__ unsigned bf_pack2(float lo, float hi) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -51,9 +52,11 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
   constexpr int A_CH = A_BYTES / 16, AE = (A_CH + NTHR - 1) / NTHR;       // 16-byte DMA pieces of the weight tile
   static_assert(A_CH % 64 == 0, "whole waves of LDS-DMA pieces");
   constexpr int WTM = BM / 2, TM = WTM / 32;                        // waves 2 (M) x NWN (N); wave N-tile = 64 pixels
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + 2 * A_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + 2 * A_BYTES + 2 * BF_AFF_MAX * 4];
   unsigned char* const Pb = smem;                                   // patch first: its per-tap offsets stay small
   unsigned char* const Ab = smem + 2 * P_BYTES;
+  float* const aff_sc = reinterpret_cast<float*>(smem + 2 * P_BYTES + 2 * A_BYTES);   // folded BatchNorm rows of all Cin channels
+  float* const aff_sh = aff_sc + BF_AFF_MAX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN, li = lane & 31, lk = lane >> 5;
@@ -95,7 +98,13 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
     pok |= (unsigned)ok << e;
   }
   float praw[PE][8];
-  f32x4 psc[PE][2], psh[PE][2];             // scale / shift of the slot's 8 channels for the K-tile in flight
+  if (has_aff) {                            // scale / shift rows -> LDS once (kept out of the register pipeline)
+    for (int c = tid; c < a.Cin; c += NTHR) {
+      aff_sc[c] = a.sc0[c];
+      aff_sh[c] = a.sh0[c];
+    }
+    __syncthreads();
+  }
 
   // weight tile: piece c of K-tile kt lives at  wp + ((kt*NT + c / (2*BM)) * ld + m0) * 32 B + (c % (2*BM)) * 16 B
   const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(a.wp);
@@ -122,12 +131,6 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
     for (int e = 0; e < PE; ++e) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) praw[e][j] = (xk + (long long)j * sHW)[p_off[e]];
-      if (has_aff) {
-        const f32x4* sp = reinterpret_cast<const f32x4*>(a.sc0 + kt * BF_CK + 8 * p_g[e]);
-        const f32x4* hp = reinterpret_cast<const f32x4*>(a.sh0 + kt * BF_CK + 8 * p_g[e]);
-        psc[e][0] = sp[0]; psc[e][1] = sp[1];
-        psh[e][0] = hp[0]; psh[e][1] = hp[1];
-      }
     }
   };
   auto finish = [&](int kt, int buf) __attribute__((always_inline)) {
@@ -135,10 +138,16 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
     for (int e = 0; e < PE; ++e) {
       float v[8];
       const bool ok = (pok >> e) & 1u;
+      f32x4 sc[2], sh[2];
+      if (has_aff) {
+        const f32x4* sp = reinterpret_cast<const f32x4*>(aff_sc + kt * BF_CK + 8 * p_g[e]);
+        const f32x4* hp = reinterpret_cast<const f32x4*>(aff_sh + kt * BF_CK + 8 * p_g[e]);
+        sc[0] = sp[0]; sc[1] = sp[1]; sh[0] = hp[0]; sh[1] = hp[1];
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float x = praw[e][j];
-        if (has_aff) x = fmaf(x, psc[e][j >> 2][j & 3], psh[e][j >> 2][j & 3]);
+        if (has_aff) x = fmaf(x, sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
         x = act_apply(x, a.act0);
         v[j] = ok ? x : 0.f;
       }

@@ -4,6 +4,7 @@ Only shape bookkeeping and output allocation happen here; all arithmetic is in
 libavsep_gfx950.so.  Tensors are dense fp32 NCHW on the current cuda device.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -15,6 +16,22 @@ def _f32(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+# Operand precision of the convolutions: "f32" (exact f32 MFMA, the reference's arithmetic) or "bf16" (operands rounded
+# to bf16 while they are staged, fp32 accumulation / BatchNorm statistics / outputs / master weights: BASELINE.json
+# configs[2]).  Geometries without a bf16 kernel run in f32 either way.
+PREC_BY_NAME = {"f32": 0, "fp32": 0, "bf16": 1}
+_precision = PREC_BY_NAME[os.environ.get("AVSEP_PRECISION", "f32")]
+
+
+def set_precision(name):
+    global _precision
+    _precision = PREC_BY_NAME[name]
+
+
+def get_precision():
+    return "bf16" if _precision else "f32"
+
+
 def out_size(h, k, s, p, d):
     return (h + 2 * p - d * (k - 1) - 1) // s + 1
 
@@ -23,7 +40,7 @@ class Conv:
     """Geometry + virtual-input description of one convolution call (avsep_conv_desc)."""
 
     def __init__(self, x0, cout, k, stride, pad, dil=1, x1=None, sc0=None, sh0=None, act0=0,
-                 sc1=None, sh1=None, act1=0, up2x=False):
+                 sc1=None, sh1=None, act1=0, up2x=False, prec=None):
         lib.require_gpu(x0)
         N, C0, Hs, Ws = x0.shape
         C1 = x1.shape[1] if x1 is not None else 0
@@ -37,6 +54,7 @@ class Conv:
         d.N, d.Cin, d.H, d.W, d.Cout, d.Ho, d.Wo = N, C0 + C1, H, W, cout, self.Ho, self.Wo
         d.KH, d.KW, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
         d.C0, d.act0, d.act1, d.up2x = C0, act0, act1, int(up2x)
+        d.prec = _precision if prec is None else PREC_BY_NAME[prec]
         d.x0, d.x1 = ptr(x0), ptr(x1)
         d.scale0, d.shift0, d.scale1, d.shift1 = ptr(sc0), ptr(sh0), ptr(sc1), ptr(sh1)
         self.d = d

@@ -24,7 +24,7 @@ class AvsepError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                "N Cin H W Cout Ho Wo KH KW stride pad dil C0 act0 act1 up2x".split()] + \
+                "N Cin H W Cout Ho Wo KH KW stride pad dil C0 act0 act1 up2x prec".split()] + \
                [(n, C.c_void_p) for n in "x0 x1 scale0 shift0 scale1 shift1".split()]
 
 

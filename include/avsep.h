@@ -34,6 +34,9 @@ extern "C" {
 #define AVSEP_ACT_TANH 4
 #define AVSEP_ACT_SOFTMAX2 5   /* softmax over a 2-channel dim (models/__init__.py:19-20) */
 
+#define AVSEP_PREC_F32 0
+#define AVSEP_PREC_BF16 1
+
 typedef void* avsep_stream_t;
 
 int avsep_version(void);
@@ -60,6 +63,9 @@ typedef struct avsep_conv_desc {
   int32_t C0;                  /* channels from x0; Cin-C0 from x1 (0 => x1 unused) */
   int32_t act0, act1;          /* AVSEP_ACT_NONE/RELU/LRELU02, applied after the affine */
   int32_t up2x;
+  int32_t prec;                /* AVSEP_PREC_F32 (0): exact f32 MFMA; AVSEP_PREC_BF16 (1): operands rounded to bf16 while they are
+                                  staged, fp32 accumulation / statistics / outputs (BASELINE.json configs[2]); geometries without a
+                                  bf16 kernel run in f32 */
   const float* x0;
   const float* x1;
   const float* scale0;         /* [C0] or NULL */

@@ -340,6 +340,18 @@ def test_shared_encoder_pair_equals_two_passes(dev, golden):
 
 @pytest.mark.parametrize("log_freq,backend", [(1, "torch"), (1, "hybrid"), (1, "hip"), (0, "hip")])
 def test_config1_full_size_step_vs_oracle(dev, log_freq, backend):
+    _full_size_step(dev, log_freq, backend, "f32", 1e-4)
+
+
+def test_config2_bf16_full_hip_step_vs_oracle(dev):
+    """BASELINE.json configs[2] arithmetic: bf16 conv operands (rounded while they are staged), fp32 accumulation, BatchNorm
+    statistics, loss, master weights and SGD; visual trunk on this library ("full HIP path").  Same full-size AV + AO
+    steps as configs[1], against the fp32 CPU oracle: the north-star bound  mask MSE <= 1e-4  must hold; the loss may
+    differ by the bf16 operand rounding (bound 2e-3 of the loss, measured value printed)."""
+    _full_size_step(dev, 1, "hip", "bf16", 2e-3)
+
+
+def _full_size_step(dev, log_freq, backend, prec, err_tol):
     """(log_freq 0 keeps the 512x256 tiles of configs[4]; backend "hip" runs the visual trunk on this library too.)
     BASELINE.json configs[0]/[1] shapes at batch 2: 65535-sample waveforms -> STFT 1022/256 -> 512x256 ->
     log-frequency warp to 256x256, 3 frames of 224x224 per source, unet7 (64 ngf) + hidsep(sig) + resnet18dilated,
@@ -349,6 +361,14 @@ def test_config1_full_size_step_vs_oracle(dev, log_freq, backend):
     import numpy as np
     P = _pkg()
     from oracle import nets as O, step as OS, criterion as OC, stft as OST
+    P.kernels.set_precision(prec)
+    try:
+        _full_size_step_body(dev, log_freq, backend, prec, err_tol, P, O, OS, OC, OST, np)
+    finally:
+        P.kernels.set_precision("f32")
+
+
+def _full_size_step_body(dev, log_freq, backend, prec, err_tol, P, O, OS, OC, OST, np):
     a = P.arguments.train_music_args()
     a.stft_pad_mode = "reflect"
     a.log_freq = log_freq
@@ -383,11 +403,12 @@ def test_config1_full_size_step_vs_oracle(dev, log_freq, backend):
             oerr, omatch, oouts = OS.train_step(owrap, cb, oopt, use_vis, a)
             mse = max(((x.detach().cpu() - y.detach()) ** 2).mean().item()
                       for x, y in zip(outs["pred_masks"], oouts["pred_masks"]))
+            print(f"full-size {prec}/{backend} wide={wide} {'AV' if use_vis else 'AO'}: err hip={err.item():.6f} "
+                  f"oracle={oerr:.6f} |d|={abs(err.item() - oerr):.2e} mask-MSE={mse:.2e}")
             assert mse <= 1e-4, f"mask MSE {mse} (wide={wide}, use_vis={use_vis})"
-            assert abs(err.item() - oerr) <= 1e-4 * max(1.0, abs(oerr)), (wide, use_vis, err.item(), oerr)
+            assert abs(err.item() - oerr) <= err_tol * max(1.0, abs(oerr)), (wide, use_vis, err.item(), oerr)
             if use_vis:
-                assert abs(match.item() - omatch) <= 1e-4
-            print(f"config1 wide={wide} {'AV' if use_vis else 'AO'}: err hip={err.item():.6f} oracle={oerr:.6f} mask-MSE={mse:.2e}")
+                assert abs(match.item() - omatch) <= max(1e-4, err_tol)
 
 
 def test_eval_path_vs_oracle(dev):

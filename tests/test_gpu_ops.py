@@ -85,6 +85,83 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert_close(db, dy.sum((0, 2, 3)), 2e-5, "dbias")
 
 
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+BF16_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, dil, affine+act (0 none, 1 ReLU, 2 LeakyReLU)
+    (2, 32, 12, 40, 144, 3, 1, 1, 1, 1),     # 4x32 tiles x 128 rows (+ ragged second M tile), ragged H / W
+    (2, 32, 12, 40, 136, 3, 1, 1, 1, 1),     # Cout % 16 != 0: the data gradient has no bf16 kernel and runs in exact f32
+    (2, 48, 19, 20, 48, 3, 1, 1, 1, 0),      # 8x16 tiles x 64 rows, three K-tiles
+    (70, 16, 16, 64, 144, 3, 1, 1, 1, 1),    # 8x32 tiles, 512-thread workgroups (>= 512 of them)
+    (130, 16, 32, 16, 144, 3, 1, 1, 1, 0),   # 16x16 tiles, 512 threads, 128 rows
+    (2, 32, 20, 40, 144, 3, 1, 2, 2, 1),     # dilated
+    (3, 32, 14, 14, 48, 3, 1, 1, 1, 1),      # flat 14x14, 128-pixel tiles crossing images
+    (3, 32, 14, 14, 48, 3, 1, 2, 2, 0),      # flat 14x14 dilated
+    (5, 32, 7, 7, 48, 3, 1, 1, 1, 1),        # flat 7x7
+    (700, 16, 14, 14, 144, 3, 1, 1, 1, 1),   # flat 14x14, 256-pixel tiles, 128 rows, last tile partial
+    (2, 32, 64, 64, 48, 4, 2, 1, 1, 2),      # 4x4 / stride 2 (U-Net encoder): forward + 4 parity-class data gradients
+    (2, 48, 40, 72, 144, 4, 2, 1, 1, 2),     # same, ragged tiles, three M tiles of 64 rows
+    (70, 16, 64, 64, 80, 4, 2, 1, 1, 0),     # same, 512-thread workgroups
+    (3, 48, 10, 72, 160, 3, 1, 1, 1, 1),     # weight gradient: 4x32 pixel tiles, ragged rows / columns / channel blocks
+    (4, 64, 18, 22, 40, 3, 1, 1, 1, 2),      # W % 4 == 2 (float2 staging), 32-wide tiles
+    (6, 32, 14, 14, 144, 3, 1, 2, 2, 1),     # dilated 14x14 (ResNet layer4): 16-wide tiles, rows 8-byte aligned
+    (2, 32, 12, 40, 48, 3, 1, 2, 2, 0),      # dilated, 32-wide 2-row tiles
+    (9, 64, 16, 16, 128, 3, 1, 1, 1, 0),     # several pixel tiles per slab, 16-wide
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_conv_bf16_operands(dev, case):
+    """avsep_conv_desc.prec = AVSEP_PREC_BF16: the kernel must equal a float64 convolution of the bf16-ROUNDED operands
+    (activation after the folded affine rounded to bf16, weights rounded to bf16) up to fp32 accumulation order; the
+    BatchNorm statistics are those of the fp32 result.  Against the unrounded float32 convolution the difference is the
+    bf16 operand rounding itself (2^-9 relative per operand): reported, bounded loosely."""
+    K = _pkg().kernels
+    N, Cin, H, W, Cout, k, s, p, d, aff = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    if aff:
+        # the kernel folds the affine with ONE rounding (fmaf): float64 product + sum rounded once to float32 is the same
+        # value; a separately rounded product would differ in the last float32 bit and flip bf16 roundings
+        v = (x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
+        v = F.relu(v) if aff == 1 else torch.where(v > 0, v, 0.2 * v)
+    else:
+        v = x
+    vr, wr = _bf16(v).requires_grad_(True), _bf16(w).requires_grad_(True)
+    y_ref = F.conv2d(vr, wr, b.double(), s, p, d)
+    dy = torch.randn(y_ref.shape, generator=g)
+    # the data gradient rounds dY and the weights; the reference for it is the conv-transpose of the rounded dY
+    dx_ref, dw_ref = torch.autograd.grad(y_ref, (vr, wr), _bf16(dy))
+    t = lambda z: z.to(dev)
+    cv = K.Conv(t(x), Cout, k, s, p, d, sc0=t(sc) if aff else None, sh0=t(sh) if aff else None, act0=aff, prec="bf16")
+    st = K.zeros_stats(Cout, t(x))
+    y = cv.fwd(cv.pack(t(w), 0), t(b), st)
+    assert_close(y, y_ref, 2e-5, "fwd vs rounded operands")
+    st_ref = torch.cat([y_ref.sum((0, 2, 3)), (y_ref ** 2).sum((0, 2, 3))])
+    assert_close(st, st_ref, 1e-5, "stats")
+    dx = cv.dgrad(cv.pack(t(w), 1), t(dy))
+    if Cout % 16 == 0 and Cin >= 32:
+        assert_close(dx, dx_ref, 2e-5, "dgrad vs rounded operands")
+    else:   # no bf16 data-gradient kernel for these channel counts: exact f32 arithmetic on the unrounded operands
+        v32 = v.clone().requires_grad_(True)
+        assert_close(dx, torch.autograd.grad(F.conv2d(v32, w, b, s, p, d), v32, dy)[0], 2e-5, "dgrad (f32 fallback)")
+    v32, w32 = v.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y32 = F.conv2d(v32, w32, b, s, p, d)
+    assert_close(y, y32, 2e-2, "fwd vs unrounded fp32 (bf16 operand rounding)")
+    # weight gradient: bf16 kernel (rounded dY and rounded activated input) where one exists, else exact f32
+    dw, db = cv.wgrad(t(dy), want_bias=True)
+    from conftest import rel_err
+    e_bf, e_32 = rel_err(dw, dw_ref), rel_err(dw, torch.autograd.grad(y32, w32, dy)[0])
+    has_bf16_wgrad = k == 3 and s == 1 and Cin >= 32 and Cout >= 32 and W >= 12 and W % 2 == 0
+    assert (e_bf if has_bf16_wgrad else e_32) <= 2e-5, (has_bf16_wgrad, e_bf, e_32)
+    assert_close(db, dy.sum((0, 2, 3)), 2e-5, "dbias")
+
+
 @pytest.mark.parametrize("up2x,H,W", [(False, 9, 7), (True, 9, 7), (False, 10, 36), (True, 10, 18), (True, 6, 10)])
 def test_conv_virtual_input(dev, up2x, H, W):
     """two-source concat + per-channel affine + LeakyReLU/ReLU (+ bilinear x2) folded into the gather;
