@@ -559,10 +559,12 @@ int c4_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
 size_t w3_workspace_floats(const avsep_conv_desc* d);
 // conv_bf16.hip: bf16-operand halo-patch kernels (desc.prec == AVSEP_PREC_BF16)
 bool bf_applicable(const avsep_conv_desc* d, int mode);
+size_t bf_workspace_bytes(const avsep_conv_desc* d, int mode);
 size_t bf_packed_floats(const avsep_conv_desc* d, int mode);
 int bf_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
-int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st);
-int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
+int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, void* ws, size_t ws_bytes,
+           hipStream_t st);
+int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
 // wgrad_bf16.hip
 bool wb_applicable(const avsep_conv_desc* d);
 size_t wb_workspace_floats(const avsep_conv_desc* d);
@@ -673,12 +675,30 @@ static SplitPlan dgrad_split(const avsep_conv_desc* d) {
   return splitk_plan(tiles, taps * d->Cout);
 }
 
+// split-K combines, shared with conv_bf16.hip
+int splitk_combine(const float* ws, long long slab, int S, const avsep_conv_desc* d, const float* bias, float* y, double* stats,
+                   hipStream_t st) {
+  int chunks = min(cdiv(1024, d->Cout), d->N);
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(splitk_combine_kernel, dim3(d->Cout, chunks), dim3(256), 0, st, ws, slab, S, d->N, d->Cout, d->Ho * d->Wo,
+                     bias, y, stats);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+int reduce_slabs(const float* ws, float* out, long long n, int S, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws, out, n, S);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
 extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
+  if (!check_desc(d, true) && bf_applicable(d, 0)) return bf_workspace_bytes(d, 0);
   if (check_desc(d, true) || !fwd_uses_igemm(d, (const double*)1)) return 0;
   SplitPlan p = fwd_split(d);
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cout * d->Ho * d->Wo * sizeof(float) : 0;
 }
 extern "C" size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d) {
+  if (!check_desc(d) && !smallci_applicable(d) && bf_applicable(d, 1)) return bf_workspace_bytes(d, 1);
   if (check_desc(d) || bf_applicable(d, 1) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1)) return 0;
   SplitPlan p = dgrad_split(d);
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cin * d->H * d->W * sizeof(float) : 0;
@@ -691,7 +711,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   if (!w_packed || !y) return AVSEP_ERR_ARG;
   if (!stats && smallco_applicable(d)) return smallco_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
   if (!stats && head_applicable(d)) return head_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
-  if (bf_applicable(d, 0)) return bf_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
+  if (bf_applicable(d, 0)) return bf_fwd(d, w_packed, bias, y, stats, workspace, workspace_bytes, (hipStream_t)stream);
   if (c3_applicable(d, 0)) return c3_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (c4_applicable(d, 0)) return c4_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   CArgs a = make_args(d);
@@ -734,7 +754,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   if (rc) return rc;
   if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
   if (smallci_applicable(d)) return smallci_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
-  if (bf_applicable(d, 1)) return bf_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
+  if (bf_applicable(d, 1)) return bf_dgrad(d, w_packed_dgrad, dy, dx, workspace, workspace_bytes, (hipStream_t)stream);
   if (c3_applicable(d, 1)) return c3_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c4_applicable(d, 1)) return c4_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   CArgs a = make_args(d);

@@ -60,7 +60,36 @@ static int bf_class(const avsep_conv_desc* d) {
   if (d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->dil == 1) return 4;
   return 0;
 }
-static bool bf_flat(const avsep_conv_desc* d) { return d->H >= d->W && (d->W == 14 || d->W == 7) && (d->dil == 1 || d->W == 14); }
+// flat-pixel tiles: the small square maps of the visual trunk (14x14, 7x7) and of the deep U-Net levels (8x8, 4x4)
+static int bf_flat_w(int H, int W, int dil) {
+  if (H < W) return 0;
+  if (dil == 1 && (W == 14 || W == 7 || W == 8 || W == 4)) return W;
+  if (dil == 2 && W == 14) return W;
+  return 0;
+}
+static bool bf_flat(const avsep_conv_desc* d) { return bf_flat_w(d->H, d->W, d->dil) > 0; }
+
+// split-K over the 16-channel K-tiles for layers whose output grid cannot fill the chip (deep U-Net levels: 4x4 / 8x8
+// maps with K = 9216): partial slabs in the workspace + the fp32 combine of conv.hip
+struct BfSplit { int splits, kts; };
+static BfSplit bf_split_plan(long long wgs, int nK) {
+  BfSplit p{1, 0};
+  if (wgs >= 384 || nK < 16) return p;
+  int s = cdiv(768, wgs), maxs = nK / 8;
+  if (s > maxs) s = maxs;
+  if (s > 32) s = 32;
+  if (s < 2) return p;
+  p.kts = cdiv(nK, s);
+  p.splits = cdiv(nK, p.kts);
+  if (p.splits < 2) { p.splits = 1; p.kts = 0; }
+  return p;
+}
+// workgroups of the unsplit flat launch (mirrors bf_launch_flat)
+static long long bf_flat_wgs(int M, long long P) {
+  const int gm = cdiv(M, M <= 64 ? 64 : 128);
+  const bool big = (long long)gm * cdiv(P, 256) >= 512;
+  return (long long)gm * cdiv(P, big ? 256 : 128);
+}
 
 bool bf_applicable(const avsep_conv_desc* d, int mode) {
   if (d->prec != AVSEP_PREC_BF16 || !bf_enabled()) return false;
@@ -73,8 +102,16 @@ bool bf_applicable(const avsep_conv_desc* d, int mode) {
   const long long in_elems = mode == 0 ? (long long)d->N * d->Cin * d->H * d->W : (long long)d->N * d->Cout * d->Ho * d->Wo;
   if (in_elems >= (1LL << 30) || d->N > 65535) return false;
   if (cls == 3) return bf_flat(d) || (d->W >= 16 && d->H >= 4);
-  if (mode == 0) return d->Wo >= 16 && d->Ho >= 4;
-  return d->Wo >= 16 && d->Ho >= 4 && (d->H & 1) == 0 && (d->W & 1) == 0;
+  if (mode == 0) return d->Wo >= 8 && d->Ho >= 4;               // 8-wide outputs (U-Net d5) use half of a 16-wide tile
+  return d->Wo >= 8 && d->Ho >= 4 && (d->H & 1) == 0 && (d->W & 1) == 0;
+}
+
+size_t bf_workspace_bytes(const avsep_conv_desc* d, int mode) {
+  if (bf_class(d) != 3 || !bf_flat(d)) return 0;
+  const int M = mode == 0 ? d->Cout : d->Cin, kc = mode == 0 ? d->Cin : d->Cout;
+  const long long P = (long long)d->N * d->H * d->W;
+  BfSplit sp = bf_split_plan(bf_flat_wgs(M, P), kc / BF_CK);
+  return sp.splits > 1 ? (size_t)sp.splits * M * P * sizeof(float) : 0;
 }
 
 size_t bf_packed_floats(const avsep_conv_desc* d, int mode) {
@@ -124,14 +161,14 @@ static int bf_launch_rect(C3Args& a, hipStream_t st) {
 }
 
 template <int FW_, int DIL_>
-static int bf_launch_flat(C3Args& a, hipStream_t st) {
+static int bf_launch_flat(C3Args& a, int splits, hipStream_t st) {
   const long long P = (long long)a.N * a.H * a.W;
   const bool m64 = a.Cout <= 64;
   a.gridM = cdiv(a.Cout, m64 ? 64 : 128);
   const bool big = (long long)a.gridM * cdiv(P, 256) >= 512;
   a.tilesX = cdiv(P, big ? 256 : 128);
   a.tilesY = 1;
-  dim3 grid((unsigned)((long long)a.gridM * a.tilesX));
+  dim3 grid((unsigned)((long long)a.gridM * a.tilesX), splits);
 #define BF_F(BM_, NWN_) \
   hipLaunchKernelGGL((convbf_kernel<0, 0, BM_, 3, 3, 1, DIL_, FW_, NWN_>), grid, dim3(128 * NWN_), 0, st, a)
   if (big) { if (m64) BF_F(64, 4); else BF_F(128, 4); }
@@ -141,33 +178,58 @@ static int bf_launch_flat(C3Args& a, hipStream_t st) {
   return AVSEP_OK;
 }
 
-static int bf3_launch(C3Args& a, int dil, hipStream_t st) {
+// 3x3 / stride 1; `ws` (may be null): split-K slabs, then *splits_out > 1 and the caller combines
+static int bf3_launch(C3Args& a, int dil, void* ws, size_t ws_bytes, int* splits_out, hipStream_t st) {
   a.Ho = a.H; a.Wo = a.W; a.padh = a.padw = dil; a.os = 1; a.ooh = a.oow = 0; a.OHs = a.H; a.OWs = a.W;
-  if (a.H >= a.W && (a.W == 14 || a.W == 7)) {
-    if (a.W == 14) return dil == 1 ? bf_launch_flat<14, 1>(a, st) : bf_launch_flat<14, 2>(a, st);
-    return bf_launch_flat<7, 1>(a, st);
+  *splits_out = 1;
+  const int fw = bf_flat_w(a.H, a.W, dil);
+  if (fw) {
+    const long long P = (long long)a.N * a.H * a.W;
+    BfSplit sp = bf_split_plan(bf_flat_wgs(a.Cout, P), a.Cin / BF_CK);
+    if (sp.splits > 1 && ws && ws_bytes >= (size_t)sp.splits * a.Cout * P * sizeof(float)) {
+      a.kts = sp.kts; a.slab = (long long)a.Cout * P; a.out = (float*)ws;
+      *splits_out = sp.splits;
+    } else {
+      sp.splits = 1;
+    }
+    if (fw == 14) return dil == 1 ? bf_launch_flat<14, 1>(a, sp.splits, st) : bf_launch_flat<14, 2>(a, sp.splits, st);
+    if (fw == 7) return bf_launch_flat<7, 1>(a, sp.splits, st);
+    if (fw == 8) return bf_launch_flat<8, 1>(a, sp.splits, st);
+    return bf_launch_flat<4, 1>(a, sp.splits, st);
   }
   return dil == 1 ? bf_launch_rect<3, 3, 1, 1>(a, st) : bf_launch_rect<3, 3, 1, 2>(a, st);
 }
+int splitk_combine(const float* ws, long long slab, int S, const avsep_conv_desc* d, const float* bias, float* y, double* stats,
+                   hipStream_t st);                                                   // conv.hip
+int reduce_slabs(const float* ws, float* out, long long n, int S, hipStream_t st);   // conv.hip
 
-int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st) {
+int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, void* ws, size_t ws_bytes,
+           hipStream_t st) {
   C3Args a{};
   a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.C0 = d->Cin; a.C1 = 0; a.act0 = d->act0; a.Hs = d->H; a.Ws = d->W;
   a.x0 = d->x0; a.sc0 = d->scale0; a.sh0 = d->shift0;
   a.wp = wp; a.wp_ld = roundup(d->Cout, 128); a.out = y; a.bias = bias; a.stats = stats;
-  if (bf_class(d) == 3) return bf3_launch(a, d->dil, st);
+  if (bf_class(d) == 3) {
+    int splits = 1;
+    int rc = bf3_launch(a, d->dil, ws, ws_bytes, &splits, st);
+    if (rc || splits == 1) return rc;
+    return splitk_combine((const float*)ws, a.slab, splits, d, bias, y, stats, st);
+  }
   a.Ho = d->Ho; a.Wo = d->Wo; a.padh = a.padw = 1; a.os = 1; a.ooh = a.oow = 0; a.OHs = d->Ho; a.OWs = d->Wo;
   return bf_launch_rect<4, 4, 2, 1>(a, st);
 }
 
-int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st) {
+int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
   if (bf_class(d) == 3) {
     C3Args a{};
     a.N = d->N; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->H; a.Ws = d->W;
     a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
-    return bf3_launch(a, d->dil, st);
+    int splits = 1;
+    int rc = bf3_launch(a, d->dil, ws, ws_bytes, &splits, st);
+    if (rc || splits == 1) return rc;
+    return reduce_slabs((const float*)ws, dx, a.slab, splits, st);
   }
   const int ld = roundup(d->Cin, 128);
   const size_t cls_floats = (size_t)(d->Cout / BF_CK) * 4 * ld * 8;

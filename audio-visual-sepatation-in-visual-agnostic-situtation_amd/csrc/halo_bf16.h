@@ -187,12 +187,18 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
     }
   }
 
-  const int nK = a.Cin / BF_CK;
-  issue(0, 0);
-  finish(0, 0);
+  int kt0 = 0, nK = a.Cin / BF_CK;
+  if (a.kts > 0) {                                  // split-K: this block reduces K-tiles [kt0, nK) of its slice
+    kt0 = blockIdx.y * a.kts;
+    nK = min(nK, kt0 + a.kts);
+  }
+  if (kt0 < nK) {
+    issue(kt0, 0);
+    finish(kt0, 0);
+  }
   __syncthreads();
-  for (int kt = 0; kt < nK; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < nK; ++kt) {
+    const int buf = (kt - kt0) & 1;
     if (kt + 1 < nK) issue(kt + 1, buf ^ 1);
     const unsigned char* Ak = Ab + buf * A_BYTES + a_lane;
     const unsigned char* Pk = Pb + buf * P_BYTES;
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
       cbase[j] = (long long)n * a.Cout * HW + (long long)(gh * a.os + a.ooh) * a.OWs + (gw * a.os + a.oow);
     }
   }
-  const bool want_stats = a.stats != nullptr;
+  const bool want_stats = a.stats != nullptr && a.kts == 0;
+  float* const outp = a.out + (a.kts > 0 ? (long long)blockIdx.y * a.slab : 0);   // partial slab: bias / statistics in the combine
   float* s_sum = reinterpret_cast<float*>(Ab);               // [NWN][BM] per-wave-column partial sums (operands are dead)
   float* s_sq = s_sum + NWN * BM;
 #pragma unroll
@@ -245,13 +252,13 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
       const int lrow = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
       const int row = m0 + lrow;
       const bool rok = row < a.Cout;
-      const float bias = (a.bias && rok) ? a.bias[row] : 0.f;
+      const float bias = (a.bias && rok && a.kts == 0) ? a.bias[row] : 0.f;
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float v = acc[i][j][r] + bias;
         if (rok && cok[j]) {
-          a.out[cbase[j] + (long long)row * HW] = v;
+          outp[cbase[j] + (long long)row * HW] = v;
           s += v;
           q += v * v;
         }

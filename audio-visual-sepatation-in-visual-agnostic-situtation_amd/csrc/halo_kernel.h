@@ -18,6 +18,10 @@ struct C3Args {
   int padh, padw;        // patch origin = tile origin * S - pad
   int os, ooh, oow;      // store position = (oh*os + ooh, ow*os + oow) in an [OHs x OWs] plane
   int OHs, OWs;
+  // split-K (bf16 kernels on layers whose output grid cannot fill the chip): blockIdx.y reduces K-tiles
+  // [y*kts, (y+1)*kts) into partial slab y of `out` (slab elements apart); 0 = no split
+  int kts;
+  long long slab;
 };
 
 constexpr int C3_CK = 4;            // input channels per K-tile of the 3x3 path (host-side packing constant)

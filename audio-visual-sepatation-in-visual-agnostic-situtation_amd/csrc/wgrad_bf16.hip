@@ -234,7 +234,8 @@ bool wb_applicable(const avsep_conv_desc* d) {
   if (d->prec != AVSEP_PREC_BF16 || !wb_enabled()) return false;
   if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil)) return false;
   if (d->up2x || d->C0 != d->Cin) return false;
-  return d->W >= 12 && d->H >= 2 && (d->W & 1) == 0 && d->Cout >= 32 && d->Cin >= 32 && d->N <= 65535 &&
+  // maps narrower than a 16-pixel k-step (U-Net u6 / u7: 8 / 4 wide) run with the unused columns zero-masked
+  return d->W >= 4 && d->H >= 2 && (d->W & 1) == 0 && d->Cout >= 32 && d->Cin >= 32 && d->N <= 65535 &&
          (long long)(d->Cout > d->Cin ? d->Cout : d->Cin) * d->H * d->W < 0x7fffffffLL;
 }
 
