@@ -53,6 +53,9 @@ _OTHER = [
     ("--max_silent", dict(type=float, default=0.67)), ("--val_repeat", dict(type=int, default=12)),
     ("--match_weight", dict(default=0.6, type=float)), ("--one_frame", dict(action="store_true", default=False)),
     ("--fix_vis", dict(action="store_true", default=False)), ("--att_type", dict(type=str, default="cos")),
+    # SoP++/main.py:674-679 reads args.train_steps (three stage boundaries) but no parser of the reference defines it;
+    # given, train.py runs the SoP++ variant (basis U-Net + attention module + synthesizer) on the 3-stage schedule
+    ("--train_steps", dict(nargs=3, type=int, default=None)),
 ]
 
 

@@ -1,0 +1,234 @@
+// SoP++ attention module core (reference: SoP++/attention_net.py:24-58 `att` + `av_infer_forward`, shared by AttModel and
+// MatchAtt): per sample and audio query s (S <= 4 pooled K-vectors a_s), the similarity map against the mixed visual
+// feature map mix[K, H*W], the match term, the clamp and the attention-weighted context vectors — one workgroup per
+// sample, ONE launch forward and ONE backward instead of ~15 ATen launches (K = 32, H*W = 14*28: latency only).
+//   m_s[hw]  = sigmoid(<a_s, mix[:,hw]> / sqrt(K))                      (att_type "sig", attention_net.py:33)
+//            | <a_s, mix[:,hw]> / (max(|a_s|,eps) * max(|mix[:,hw]|,eps)) (att_type "cos", F.cosine_similarity, :28)
+//   match[b] = -sum_s mean_hw m_s[hw]                                    (:44-47; the caller takes the batch mean)
+//   ctx_s[k] = mean_hw( mix[k,hw] * clamp(m_s[hw], 0, 1) )               (:49-55; "max_pool" there IS an average pool, :19)
+#include "common.h"
+
+#define ATT_EPS 1e-8f
+constexpr int ATT_MAXS = 4, ATT_MAXK = 128;
+
+struct AttArgs {
+  const float *a, *mix;      // a [B,S,K], mix [B,K,HW]
+  int B, S, K, HW, att;      // att: 0 cos, 1 sig
+};
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// maps_raw [B,S,HW] (before the clamp), ctx [B,S,K], match [B]
+__global__ __launch_bounds__(256) void att_infer_fwd_kernel(AttArgs p, float* __restrict__ maps_raw, float* __restrict__ ctx,
+                                                            float* __restrict__ match) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = p.S, K = p.K, HW = p.HW;
+  float* s_a = sm;                      // [S*K]
+  float* s_m = s_a + S * K;             // [S*HW] clamped maps
+  float* s_na = s_m + S * HW;           // [S]
+  float* s_red = s_na + ATT_MAXS;       // [4]
+  const float* mix = p.mix + (long long)b * K * HW;
+  for (int i = tid; i < S * K; i += 256) s_a[i] = p.a[(long long)b * S * K + i];
+  __syncthreads();
+  if (tid < S) {
+    float q = 0.f;
+    for (int k = 0; k < K; ++k) q = fmaf(s_a[tid * K + k], s_a[tid * K + k], q);
+    s_na[tid] = fmaxf(sqrtf(q), ATT_EPS);
+  }
+  __syncthreads();
+  const float inv_sqrt = 1.f / sqrtf((float)K);
+  float msum = 0.f;
+  for (int hw = tid; hw < HW; hw += 256) {
+    float d[ATT_MAXS], nv = 0.f;
+#pragma unroll
+    for (int s = 0; s < ATT_MAXS; ++s) d[s] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float v = mix[(long long)k * HW + hw];
+      nv = fmaf(v, v, nv);
+#pragma unroll
+      for (int s = 0; s < ATT_MAXS; ++s)
+        if (s < S) d[s] = fmaf(s_a[s * K + k], v, d[s]);
+    }
+    const float vn = fmaxf(sqrtf(nv), ATT_EPS);
+#pragma unroll
+    for (int s = 0; s < ATT_MAXS; ++s)
+      if (s < S) {
+        const float m = p.att == 1 ? 1.f / (1.f + expf(-d[s] * inv_sqrt)) : d[s] / (s_na[s] * vn);
+        maps_raw[((long long)b * S + s) * HW + hw] = m;
+        s_m[s * HW + hw] = fminf(fmaxf(m, 0.f), 1.f);
+        msum += m;
+      }
+  }
+  const float tot = block_sum(msum, s_red);     // includes the barrier that publishes s_m
+  if (tid == 0) match[b] = -tot / (float)HW;
+  // context vectors: wave w reduces rows k = w, w+4, ... of mix against the S clamped maps
+  for (int k = wave; k < K; k += 4) {
+    float c[ATT_MAXS];
+#pragma unroll
+    for (int s = 0; s < ATT_MAXS; ++s) c[s] = 0.f;
+    for (int hw = lane; hw < HW; hw += 64) {
+      const float v = mix[(long long)k * HW + hw];
+#pragma unroll
+      for (int s = 0; s < ATT_MAXS; ++s)
+        if (s < S) c[s] = fmaf(v, s_m[s * HW + hw], c[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < ATT_MAXS; ++s)
+      if (s < S) {
+        const float t = wave_sum(c[s]);
+        if (lane == 0) ctx[((long long)b * S + s) * K + k] = t / (float)HW;
+      }
+  }
+}
+
+// da [B,S,K], dmix [B,K,HW] from dctx [B,S,K], dmaps [B,S,HW] (gradient wrt the CLAMPED maps, may be null) and
+// dmatch [B] = d(loss)/d(match[b]) (may be null)
+__global__ __launch_bounds__(256) void att_infer_bwd_kernel(AttArgs p, const float* __restrict__ maps_raw,
+                                                            const float* __restrict__ dctx, const float* __restrict__ dmaps,
+                                                            const float* __restrict__ dmatch, float* __restrict__ da,
+                                                            float* __restrict__ dmix) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = p.S, K = p.K, HW = p.HW;
+  float* s_a = sm;                      // [S*K]
+  float* s_dc = s_a + S * K;            // [S*K] dctx / HW
+  float* s_g = s_dc + S * K;            // [S*HW] gradient wrt the dot product (sig) / wrt the map (cos)
+  float* s_mc = s_g + S * HW;           // [S*HW] clamped maps
+  float* s_nv = s_mc + S * HW;          // [HW]   |mix[:,hw]| (cos)
+  float* s_na = s_nv + HW;              // [S]
+  float* s_q = s_na + ATT_MAXS;         // [S]    sum_hw dm*m (cos, correction term of da)
+  float* s_red = s_q + ATT_MAXS;        // [4]
+  const float* mix = p.mix + (long long)b * K * HW;
+  for (int i = tid; i < S * K; i += 256) {
+    s_a[i] = p.a[(long long)b * S * K + i];
+    s_dc[i] = dctx[(long long)b * S * K + i] / (float)HW;
+  }
+  __syncthreads();
+  if (tid < S) {
+    float q = 0.f;
+    for (int k = 0; k < K; ++k) q = fmaf(s_a[tid * K + k], s_a[tid * K + k], q);
+    s_na[tid] = sqrtf(q);
+  }
+  __syncthreads();
+  const float inv_sqrt = 1.f / sqrtf((float)K);
+  const float cmatch = dmatch ? -dmatch[b] / (float)HW : 0.f;
+  float qs[ATT_MAXS];
+#pragma unroll
+  for (int s = 0; s < ATT_MAXS; ++s) qs[s] = 0.f;
+  // pass 1 (thread = hw): gradient reaching each map element, folded through the clamp and the attention function
+  for (int hw = tid; hw < HW; hw += 256) {
+    float dmc[ATT_MAXS], nv = 0.f;
+#pragma unroll
+    for (int s = 0; s < ATT_MAXS; ++s) dmc[s] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float v = mix[(long long)k * HW + hw];
+      nv = fmaf(v, v, nv);
+#pragma unroll
+      for (int s = 0; s < ATT_MAXS; ++s)
+        if (s < S) dmc[s] = fmaf(s_dc[s * K + k], v, dmc[s]);
+    }
+    s_nv[hw] = sqrtf(nv);
+#pragma unroll
+    for (int s = 0; s < ATT_MAXS; ++s)
+      if (s < S) {
+        const float m = maps_raw[((long long)b * S + s) * HW + hw];
+        float g = dmc[s] + (dmaps ? dmaps[((long long)b * S + s) * HW + hw] : 0.f);
+        g = (m >= 0.f && m <= 1.f) ? g : 0.f;       // torch.clamp passes the gradient on [min, max]
+        g += cmatch;
+        s_mc[s * HW + hw] = fminf(fmaxf(m, 0.f), 1.f);
+        if (p.att == 1) {
+          s_g[s * HW + hw] = g * m * (1.f - m) * inv_sqrt;             // d/d(dot)
+        } else {
+          s_g[s * HW + hw] = g;                                         // d/d(m); the quotient rule is applied below
+          qs[s] = fmaf(g, m, qs[s]);
+        }
+      }
+  }
+  __syncthreads();
+  if (p.att == 0) {
+#pragma unroll
+    for (int s = 0; s < ATT_MAXS; ++s) {
+      const float t = block_sum(qs[s], s_red);
+      if (tid == 0 && s < S) s_q[s] = t;
+    }
+    __syncthreads();
+  }
+  // pass 2 (wave = row k of mix): dmix[k,hw] and da[s,k]
+  for (int k = wave; k < K; k += 4) {
+    float acc[ATT_MAXS];
+#pragma unroll
+    for (int s = 0; s < ATT_MAXS; ++s) acc[s] = 0.f;
+    for (int hw = lane; hw < HW; hw += 64) {
+      const float v = mix[(long long)k * HW + hw];
+      float dv = 0.f;
+#pragma unroll
+      for (int s = 0; s < ATT_MAXS; ++s)
+        if (s < S) {
+          const float g = s_g[s * HW + hw];
+          dv = fmaf(s_dc[s * K + k], s_mc[s * HW + hw], dv);           // through ctx = mean(mix * clamp(m))
+          if (p.att == 1) {
+            dv = fmaf(g, s_a[s * K + k], dv);
+            acc[s] = fmaf(g, v, acc[s]);
+          } else {
+            // m = dot / (An * Vn), An = max(|a|,eps), Vn = max(|v|,eps)
+            const float An = fmaxf(s_na[s], ATT_EPS), nvv = s_nv[hw], Vn = fmaxf(nvv, ATT_EPS);
+            const float inv = 1.f / (An * Vn);
+            float t = s_a[s * K + k] * inv;
+            if (nvv > ATT_EPS) {
+              const float m = maps_raw[((long long)b * S + s) * HW + hw];
+              t -= m * v / (nvv * nvv);
+            }
+            dv = fmaf(g, t, dv);
+            acc[s] = fmaf(g, v * inv, acc[s]);
+          }
+        }
+      dmix[((long long)b * K + k) * HW + hw] = dv;
+    }
+#pragma unroll
+    for (int s = 0; s < ATT_MAXS; ++s)
+      if (s < S) {
+        float t = wave_sum(acc[s]);
+        if (p.att == 0 && s_na[s] > ATT_EPS) t -= s_q[s] * s_a[s * K + k] / (s_na[s] * s_na[s]);
+        if (lane == 0) da[((long long)b * S + s) * K + k] = t;
+      }
+  }
+}
+
+static int att_check(const float* a, const float* mix, int B, int S, int K, int HW, int att) {
+  if (!a || !mix || B <= 0 || B > 65535 || S < 1 || S > ATT_MAXS || K < 1 || K > ATT_MAXK || HW < 1 || HW > 4096) return AVSEP_ERR_ARG;
+  if (att != 0 && att != 1) return AVSEP_ERR_ARG;
+  return AVSEP_OK;
+}
+
+extern "C" int avsep_attmodel_infer_fwd(const float* a, const float* mix, int32_t B, int32_t S, int32_t K, int32_t HW, int32_t att,
+                                        float* maps_raw, float* ctx, float* match, avsep_stream_t stream) {
+  int rc = att_check(a, mix, B, S, K, HW, att);
+  if (rc) return rc;
+  if (!maps_raw || !ctx || !match) return AVSEP_ERR_ARG;
+  AttArgs p{a, mix, B, S, K, HW, att};
+  const size_t lds = (size_t)(S * K + S * HW + ATT_MAXS + 4) * sizeof(float);
+  hipLaunchKernelGGL(att_infer_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, p, maps_raw, ctx, match);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+extern "C" int avsep_attmodel_infer_bwd(const float* a, const float* mix, const float* maps_raw, const float* dctx,
+                                        const float* dmaps, const float* dmatch, int32_t B, int32_t S, int32_t K, int32_t HW,
+                                        int32_t att, float* da, float* dmix, avsep_stream_t stream) {
+  int rc = att_check(a, mix, B, S, K, HW, att);
+  if (rc) return rc;
+  if (!maps_raw || !dctx || !da || !dmix) return AVSEP_ERR_ARG;
+  AttArgs p{a, mix, B, S, K, HW, att};
+  const size_t lds = (size_t)(2 * S * K + 2 * S * HW + HW + 2 * ATT_MAXS + 4) * sizeof(float);
+  hipLaunchKernelGGL(att_infer_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, p, maps_raw, dctx, dmaps, dmatch,
+                     da, dmix);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}

@@ -875,6 +875,29 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   return AVSEP_OK;
 }
 
+extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t mode, int32_t with_stats) {
+  if (check_desc(d, mode == 0)) return "invalid";
+  if (mode == 0) {
+    if (!with_stats && smallco_applicable(d)) return "smallco_fwd";
+    if (!with_stats && head_applicable(d)) return "head_fwd_kernel";
+    if (bf_applicable(d, 0)) return "convbf_kernel";
+    if (c3_applicable(d, 0) || c4_applicable(d, 0)) return "conv3x3_kernel";
+    return "igemm_kernel<fwd>";
+  }
+  if (mode == 1) {
+    if (head_applicable(d)) return "head_dgrad_kernel";
+    if (smallci_applicable(d)) return "smallci_dgrad";
+    if (bf_applicable(d, 1)) return "convbf_kernel";
+    if (c3_applicable(d, 1) || c4_applicable(d, 1)) return "conv3x3_kernel";
+    return "igemm_kernel<dgrad>";
+  }
+  if (smallco_applicable(d)) return "smallco_wgrad";
+  if (head_applicable(d)) return "head_wgrad_kernel";
+  if (wb_applicable(d)) return "wgradbf_kernel";
+  if (w3_applicable(d)) return "wgrad3x3_kernel";
+  return "igemm_kernel<wgrad>";
+}
+
 // ---------------------------------------------------------------------------
 // fused decoder head (head.hip): dgrad of a conv over the virtual up2x(relu(affine(cat))) input, taken straight to
 // the two low-res sources

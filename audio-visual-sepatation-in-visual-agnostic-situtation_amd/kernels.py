@@ -84,6 +84,10 @@ class Conv:
         call("avsep_conv2d_dgrad", self.ref, ptr(w_packed_d), ptr(dy), ptr(dx), ptr(ws), nbytes)
         return dx
 
+    def kernel_name(self, mode, with_stats=True):
+        """Kernel family the library dispatches this call to (mode: "fwd" | "dgrad" | "wgrad")."""
+        return lib.load().avsep_conv_kernel_name(self.ref, {"fwd": 0, "dgrad": 1, "wgrad": 2}[mode], int(with_stats)).decode()
+
     def head_applicable(self):
         """True when this (up2x, Cout <= 4) conv takes the fused decoder-head kernels (csrc/head.hip)."""
         return bool(lib.load().avsep_conv2d_head_applicable(self.ref))

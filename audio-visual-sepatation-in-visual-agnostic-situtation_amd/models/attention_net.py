@@ -2,8 +2,11 @@
 ``AttModel`` ("Base") / ``MatchAtt``.  Parameter free; K-dimensional (K = num_channels, 32 by default)
 vectors against a 14x28 map: ~0.03 MMAC per sample, pure latency.
 
-Round-1 state: these two modules run on PyTorch-ROCm tensor operators on the GPU (like the visual trunk),
-not on a dedicated HIP kernel; the U-Net that feeds them and the synthesizer that consumes them are HIP.
+The core both modules share — similarity maps of the pooled audio queries against the mixed visual map, the match
+term, the clamp and the attention-weighted context vectors (`att` + `av_infer_forward`, :24-58) — is ONE HIP launch
+forward and one backward (csrc/attention.hip, one workgroup per sample); the remaining vector arithmetic (4-element
+pools of the [B,K,2,2] queries, the two-permutation cosine matching of [B,2,K] vectors) stays on a handful of tensor ops.
+There is no CPU path: the module raises on CPU tensors like every other entry point.
 Quirks kept: the attribute the reference calls ``max_pool`` is an AVERAGE pool (:19); the sigmoid kernel divides
 by sqrt(K) = sqrt(x.shape[2]) (:33); maps are clamped to [0,1] AFTER the match loss is taken (:49-51).
 """
@@ -11,9 +14,44 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import lib
+from ..lib import call, ptr
+
+_ATT = {"cos": 0, "sig": 1}
+
 
 def _pool(t):
     return t.mean(dim=(-2, -1))
+
+
+class _AttInferFn(torch.autograd.Function):
+    """(a [B,S,K], mix [B,K,H,W]) -> (ctx [B,S,K], clamped maps [B,S,H,W], match [B]) on csrc/attention.hip."""
+
+    @staticmethod
+    def forward(ctx_, a, mix, att):
+        B, S, K = a.shape
+        H, W = mix.shape[-2:]
+        a, mix = a.contiguous().float(), mix.contiguous().float()
+        raw = torch.empty((B, S, H, W), dtype=torch.float32, device=a.device)
+        ctx = torch.empty((B, S, K), dtype=torch.float32, device=a.device)
+        match = torch.empty((B,), dtype=torch.float32, device=a.device)
+        call("avsep_attmodel_infer_fwd", ptr(a), ptr(mix), B, S, K, H * W, att, ptr(raw), ptr(ctx), ptr(match))
+        ctx_.save_for_backward(a, mix, raw)
+        ctx_.att = att
+        return ctx, raw.clamp(0, 1), match
+
+    @staticmethod
+    def backward(ctx_, dctx, dmaps, dmatch):
+        a, mix, raw = ctx_.saved_tensors
+        B, S, K = a.shape
+        H, W = mix.shape[-2:]
+        da, dmix = torch.empty_like(a), torch.empty_like(mix)
+        dctx = dctx.contiguous().float() if dctx is not None else torch.zeros_like(a)
+        dmaps = dmaps.contiguous().float() if dmaps is not None else None
+        dmatch = dmatch.contiguous().float() if dmatch is not None else None
+        call("avsep_attmodel_infer_bwd", ptr(a), ptr(mix), ptr(raw), ptr(dctx), ptr(dmaps), ptr(dmatch), B, S, K, H * W,
+             ctx_.att, ptr(da), ptr(dmix))
+        return da, dmix, None
 
 
 class _AttBase(nn.Module):
@@ -21,18 +59,10 @@ class _AttBase(nn.Module):
         super().__init__()
         self.att_type = kwargs.get("att_type", "cos")
 
-    def _maps(self, a, v):
-        a5, v5 = a[..., None, None], v[:, None]
-        if self.att_type == "cos":
-            return F.cosine_similarity(a5, v5, dim=2)
-        return torch.sigmoid(torch.sum(a5 * v5 / (a.shape[2]) ** 0.5, dim=2))
-
     def _infer(self, a, mix):
-        maps = self._maps(a, mix)
-        match = -_pool(maps).sum(-1).mean().reshape(1)
-        maps = maps.clamp(0, 1)
-        ctx = _pool(mix[:, None] * maps[:, :, None])
-        return ctx, (match, maps)
+        lib.require_gpu(mix)
+        ctx, maps, match = _AttInferFn.apply(a, mix, _ATT[self.att_type])      # S <= 4, K <= 128, H*W <= 4096 (checked by the ABI)
+        return ctx, (match.mean().reshape(1), maps)
 
     def av_infer_forward(self, aud_feats, mix_vis_feats):
         return self._infer(torch.stack([_pool(f) for f in aud_feats], 1), mix_vis_feats)

@@ -91,6 +91,7 @@ class Unet(nn.Module):
         self.fuse_head = True    # decoder head (<= 4 output channels) on the fused kernels of csrc/head.hip
         if extra_size is None:
             self.fusion = fusion_net.get_fusion_net(fusion_type)(att_type=att_type)
+            self.fusion.num_src = fc_dim if 2 < fc_dim <= 4 else 2    # one output channel per source (num_channels == num_mix)
             lvl = _Level(ngf * 8, ngf * 8, ngf * 8, ngf * 16, "inner", None)
         else:
             # SoP++ variant (SoP++/audio_net.py:151-198): the bottleneck conv also emits 2*extra_size
@@ -154,7 +155,7 @@ class Unet(nn.Module):
             return feat, (extra,)
         draws = None
         if v is None:
-            draws = self.ao_draws if self.ao_draws is not None else (torch.rand(B) > 0.5)
+            draws = self.ao_draws if self.ao_draws is not None else self.fusion.draw(B)
             vs = []
         else:
             vs = [t.contiguous().float() for t in v]

@@ -1,12 +1,14 @@
 """Per-frame visual encoder (reference: models/vision_net.py:20-147 + torchvision resnet18).
 
 Three backends for the ResNet-18 trunk + fc conv, selected by ``net.backend`` (default from the environment
-variable AVSEP_VISION_BACKEND, else "hybrid"), all over the same parameter tensors:
-  "torch"  : the plain PyTorch-ROCm module graph (MIOpen convolutions and BatchNorm, ATen elementwise);
+variable AVSEP_VISION_BACKEND, else "hip"), all over the same parameter tensors:
+  "hip"    : the whole trunk on libavsep_gfx950.so (models/vision_hip.py) — the default: the full-HIP path of
+             BASELINE.json configs[2], in fp32 or with bf16 conv operands (kernels.set_precision);
   "hybrid" : MIOpen's NHWC convolutions (BASELINE.json configs[1]: "vision on PyTorch-ROCm") with everything between
              them — BatchNorm statistics, normalise + residual + ReLU and their backward — on this library's
-             channels-last kernels, as one autograd node (models/vision_hybrid.py); the fastest today;
-  "hip"    : the whole trunk on libavsep_gfx950.so (models/vision_hip.py).
+             channels-last kernels, as one autograd node (models/vision_hybrid.py); in fp32 MIOpen's convolutions are
+             still ~25 % faster than this library's on the ResNet shapes, so it is kept for comparison runs;
+  "torch"  : the plain PyTorch-ROCm module graph (MIOpen convolutions and BatchNorm, ATen elementwise).
 The temporal mean that feeds the fusion is a HIP kernel in every case.
 torchvision is not part of this image, so the standard ResNet-18 architecture is restated here
 with torchvision's child order, which keeps the reference's ``features.{0,1,4..7}.*`` /
@@ -63,7 +65,7 @@ class _TemporalMean(torch.autograd.Function):
 
 
 class _VisualBase(nn.Module):
-    backend = os.environ.get("AVSEP_VISION_BACKEND", "hybrid")
+    backend = os.environ.get("AVSEP_VISION_BACKEND", "hip")
 
     def _trunk(self, x):
         """fc(features(x)) for x [N,3,H,W]."""

@@ -60,13 +60,15 @@ class NetWrapper(torch.nn.Module):
         pred, sums, FT = mask_loss(feat_sound, self._gt_stack, weight, act, "bce")   # PIT always uses BCE
         mat = sums / FT                                                              # [B,2,2] target x prediction
         loss, perms = pit_select(mat)                    # winning permutation picked on the device (no host sync)
+        self._last_perms = perms
         err = loss.mean().to(torch.float32)
         pred_last = pred.permute(0, 2, 3, 1)                                          # B x F x T x C
         ordered = PitWrapper.reorder_tensor(pred_last, perms)
         gt = torch.stack(gt_masks, dim=-1)[:, 0]
-        w2 = torch.stack([weight[:, 0]] * 2, dim=-1)
-        return err, {"pred_masks": [ordered[..., i].unsqueeze(1) for i in range(2)],
-                     "gt_masks": [gt[..., i].unsqueeze(1) for i in range(2)],
+        S = len(gt_masks)        # main.py:103 hard-codes 2; more sources: one weight copy per target
+        w2 = torch.stack([weight[:, 0]] * S, dim=-1)
+        return err, {"pred_masks": [ordered[..., i].unsqueeze(1) for i in range(S)],
+                     "gt_masks": [gt[..., i].unsqueeze(1) for i in range(S)],
                      "mag_mix": mag_mix, "mags": mags, "weight": w2}
 
     # ------------------------------------------------------------------ main.py:113-148
@@ -168,7 +170,10 @@ class FlatSGD:
     RCCL call over xGMI (replacing DataParallel's broadcast + reduce, main.py:661) and the
     update is one fused HIP launch per group."""
 
-    def __init__(self, groups, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1, overlap=None):
+    def __init__(self, groups, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1, overlap=None,
+                 require_gpu=True):
+        """`require_gpu=False` only skips the device check so that the bucket / all-reduce logic (`reduce_gradients`) can be
+        exercised on CPU tensors over gloo (tests/test_dp_gloo.py); `step()` itself has no CPU path."""
         self.momentum, self.weight_decay = momentum, weight_decay
         self.world_size, self.process_group = world_size, process_group
         # Data parallel: the first group's gradients (the U-Net: 130 MB of the 180 MB) are complete as soon as its
@@ -186,7 +191,8 @@ class FlatSGD:
         if not params:
             raise ValueError("no parameters")
         dev = params[0].device
-        lib.require_gpu(params[0])
+        if require_gpu:
+            lib.require_gpu(params[0])
         total = sum(p.numel() for p in params)
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -296,10 +302,10 @@ class FlatSGD:
         for g, s in zip(self.param_groups, state["groups"]):
             g["lr"], g["started"] = s["lr"], s["started"]
 
-    def step(self, only=None):
-        """`only`: names of the groups that took part in this step's graph.  torch.optim.SGD skips a
-        parameter whose .grad is None (no weight decay, no momentum update); with the reference's
-        model.zero_grad() (set_to_none) that is every net_frame parameter on an audio-only step."""
+    def reduce_gradients(self, only=None):
+        """The data-parallel half of step(): fold stray .grad tensors back into the flat buffer, wait for the early
+        all-reduce of the first group (if it was issued) and sum the rest of the active range over the ranks with ONE
+        all-reduce.  Returns (active groups, scale): flat_grad[range] * scale is the mean gradient over the ranks."""
         self._collect()
         active = [g for g in self.param_groups
                   if (only is None or g["name"] in only) and g["range"][1] > g["range"][0] and not g.get("no_grad")]
@@ -315,6 +321,13 @@ class FlatSGD:
                 lo, hi = min(g["range"][0] for g in rest), max(g["range"][1] for g in rest)
                 dist.all_reduce(self.flat_grad[lo:hi], group=self.process_group)   # ONE RCCL sum over xGMI
             scale = 1.0 / self.world_size
+        return active, scale
+
+    def step(self, only=None):
+        """`only`: names of the groups that took part in this step's graph.  torch.optim.SGD skips a
+        parameter whose .grad is None (no weight decay, no momentum update); with the reference's
+        model.zero_grad() (set_to_none) that is every net_frame parameter on an audio-only step."""
+        active, scale = self.reduce_gradients(only)
         for g in active:
             a, b = g["range"]
             first = not g.get("started", False)

@@ -10,7 +10,7 @@ import torch
 
 from .models import activate
 from .models.criterion import PitWrapper
-from .net_wrapper import NetWrapper as _StepBase
+from .net_wrapper import FlatSGD, NetWrapper as _StepBase
 
 
 class NetWrapper(_StepBase):
@@ -115,3 +115,53 @@ class NetWrapper(_StepBase):
         if not use_vis:
             return self.ao_forward(data, args)
         return {1: self.train_av_forward1, 2: self.train_av_forward2, 3: self.train_av_forward3}[stage](data, args)
+
+
+# ---- the three-stage schedule and its optimizer (SoP++/main.py:593-606, 670-688) ------------------------------------------
+def stage_of(i, train_steps):
+    """SoP++/main.py:674-679: stage 1 while i < train_steps[0], stage 2 on [train_steps[0], train_steps[1]), stage 3 on
+    [train_steps[1], train_steps[2]] (both ends included).  Past train_steps[2] the reference leaves `stage` unbound
+    and dies with UnboundLocalError; here that is a ValueError that says why."""
+    t0, t1, t2 = train_steps
+    if i < t0:
+        return 1
+    if t0 <= i < t1:
+        return 2
+    if t1 <= i <= t2:
+        return 3
+    raise ValueError(f"iteration {i} is past the last stage boundary train_steps[2] = {t2}")
+
+
+def create_optimizer(nets, args, process_group=None, world_size=1):
+    """SoP++/main.py:593-606: SGD groups (sound, lr_sound), (synthesizer, lr_synthesizer), (attention module,
+    lr_synthesizer) and, unless --fix_vis, (frame features, lr_frame), (frame fc, lr_sound) — as one FlatSGD."""
+    net_sound, net_frame, net_synthesizer, net_pit = nets
+    nhwc = getattr(net_frame, "backend", None) in ("torch", "hybrid")
+    groups = [{"params": list(net_sound.parameters()), "lr": args.lr_sound, "name": "sound"},
+              {"params": list(net_synthesizer.parameters()), "lr": args.lr_synthesizer, "name": "synthesizer"},
+              {"params": list(net_pit.parameters()), "lr": args.lr_synthesizer, "name": "pit"}]
+    if not args.fix_vis:
+        groups += [{"params": list(net_frame.features.parameters()), "lr": args.lr_frame, "name": "frame_features",
+                    "channels_last": nhwc},
+                   {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound, "name": "frame_fc", "channels_last": nhwc}]
+    groups = [g for g in groups if any(p.requires_grad for p in g["params"])]     # AttModel / Bias may hold no parameters
+    return FlatSGD(groups, momentum=args.beta1, weight_decay=args.weight_decay, process_group=process_group,
+                   world_size=world_size)
+
+
+def train_step_3stage(model, batch, optimizer, use_vis, i, args):
+    """SoP++/main.py:670-688: zero_grad -> forward at the stage iteration i belongs to -> err.mean().backward() ->
+    optimizer.step(); returns (err.item(), match_loss.item() or None).  torch.optim.SGD skips parameters without a
+    gradient; FlatSGD reproduces that through its per-group `no_grad` detection (zero_grad(set_to_none) semantics)."""
+    torch.set_grad_enabled(True)
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    stage = stage_of(i, args.train_steps)
+    err, outputs = model.forward(batch, args, use_vis, stage)
+    err = err.mean()
+    err.backward()
+    optimizer.step()
+    optimizer.zero_grad()
+    match_loss = outputs["match_loss"].mean().item() if use_vis else None
+    return err.item(), match_loss

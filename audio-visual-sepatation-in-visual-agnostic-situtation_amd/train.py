@@ -24,7 +24,7 @@ import time
 import torch
 
 from . import checkpoint as ckpt
-from . import dataset, dp, evaluate as ev
+from . import dataset, dp, evaluate as ev, sopp
 from .arguments import ArgParser
 from .models import ModelBuilder
 from .net_wrapper import NetWrapper, adjust_learning_rate, create_optimizer, train_step
@@ -93,9 +93,22 @@ def main(args):
                                     fusion_type=args.fusion_type, att_type=args.att_type)
     net_frame = builder.build_frame(arch=args.arch_frame, fc_dim=args.vis_channels, pool_type=args.img_pool,
                                     weights=args.weights_frame)
-    nets = (net_sound.to(device), net_frame.to(device))
-    wrapper = NetWrapper(nets, builder.build_criterion(arch=args.loss, use_pit=True), builder.build_criterion(arch=args.loss))
-    optimizer = create_optimizer(nets, args, world_size=world)
+    three_stage = getattr(args, "train_steps", None) is not None
+    if three_stage:
+        # SoP++/main.py:722-747: basis U-Net (extra_size = num_channels), synthesizer, attention module; the AV steps
+        # walk through the three stages of SoP++/main.py:670-688 by iteration number
+        from .models.attention_net import get_attmodule
+        net_sound = builder.build_sound(arch=args.arch_sound, fc_dim=args.num_channels, weights=args.weights_sound,
+                                        extra_size=args.num_channels)
+        net_syn = builder.build_synthesizer(arch=args.arch_synthesizer, fc_dim=args.num_channels, weights=args.weights_synthesizer)
+        net_pit = get_attmodule(args)(att_type=args.att_type)
+        nets = (net_sound.to(device), net_frame.to(device), net_syn.to(device), net_pit.to(device))
+        wrapper = sopp.NetWrapper(nets, builder.build_criterion(arch=args.loss, use_pit=True), builder.build_criterion(arch=args.loss))
+        optimizer = sopp.create_optimizer(nets, args, world_size=world)
+    else:
+        nets = (net_sound.to(device), net_frame.to(device))
+        wrapper = NetWrapper(nets, builder.build_criterion(arch=args.loss, use_pit=True), builder.build_criterion(arch=args.loss))
+        optimizer = create_optimizer(nets, args, world_size=world)
     torch.manual_seed(args.seed + 1 + rank)                        # rank-local data order and AO swaps
 
     loader_val = dataset.make_loader(args.list_val, args, "val", args.batch_size, False, workers=min(4, args.workers))
@@ -128,7 +141,10 @@ def main(args):
         use_vis = av_ao_schedule(i, args)
         batch = dataset.to_device((av if use_vis else ao).next(), device)
         t_data += time.perf_counter() - tic
-        err, match_loss = train_step(wrapper, batch, optimizer, use_vis, args)      # one host sync, like the reference
+        if three_stage:
+            err, match_loss = sopp.train_step_3stage(wrapper, batch, optimizer, use_vis, i, args)
+        else:
+            err, match_loss = train_step(wrapper, batch, optimizer, use_vis, args)  # one host sync, like the reference
         t_iter += time.perf_counter() - tic
         err_total += err
         if use_vis:
@@ -160,7 +176,7 @@ def main(args):
             evaluate(wrapper, loader_val, history, i, args, True, device, world)
             evaluate(wrapper, loader_val, history, i, args, False, device, world)
             if rank == 0:
-                ckpt.checkpoint(nets, history, i, args, optimizer=optimizer)
+                ckpt.checkpoint(nets[:2], history, i, args, optimizer=optimizer)
         if i in args.lr_steps:
             adjust_learning_rate(optimizer, args)
     print("Training Done!")

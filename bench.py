@@ -1,19 +1,24 @@
 #!/usr/bin/env python
 """bench.py — mixtures/sec of the mix-and-separate AV train step on MI355X (BASELINE.json metric).
 
-Workload at every N (weak scaling): BASELINE.json configs[1] per GPU — 2-source mix, batch 32,
-65535-sample waveforms -> HIP STFT (1022/256) -> 512x256 magnitudes -> log-frequency warp to
-256x256 tiles, 3 RGB frames at 224^2 per source, fp32; one step = zero_grad + NetWrapper.forward
-(AV: visual encoder on 2x3 frames, TWO U-Net passes, fusion, BCE) + backward + SGD(momentum, wd)
-(reference main.py:557-569).  Inputs are resident in HBM before the timed region.
-The U-Net / fusion / loss / STFT / prepare / SGD run on libavsep_gfx950.so; the ResNet-18 frame
-encoder's convolutions run on PyTorch-ROCm/MIOpen (that is what configs[1] names), its BatchNorm / ReLU / residual
-glue on this library's channels-last kernels (the "hybrid" backend of models/vision_net.py).
+Headline (`value`): the FULL-HIP path in fp32 — every convolution of the step (audio U-Net AND the ResNet-18 frame
+encoder), STFT, prepare, fusion, loss, BatchNorm glue and SGD on libavsep_gfx950.so; no MIOpen / rocBLAS kernel in
+the timed region.  Workload at every N (weak scaling): BASELINE.json configs[2]'s shape per GPU — 2-source mix,
+batch 64, 65535-sample waveforms -> HIP STFT (1022/256) -> 512x256 magnitudes -> log-frequency warp to 256x256
+tiles, 3 RGB frames at 224^2 per source; one step = zero_grad + NetWrapper.forward (AV: visual encoder on 2x3
+frames, TWO U-Net passes over a shared encoder, fusion, BCE) + backward + SGD(momentum, wd) (reference
+main.py:557-569).  Inputs are resident in HBM before the timed region.  The reference computes in fp32, so fp32 is
+the headline arithmetic; the same run then times, outside the headline's timed region and explicitly labelled:
+  * "bf16": configs[2] as BASELINE.json names it — bf16 conv operands (rounded while they are staged into LDS), fp32
+    accumulation / BatchNorm statistics / loss / master weights / SGD — with the loss difference to the fp32 path;
+  * "f32_miopen_hybrid": round 1's configs[1] path (visual convolutions on PyTorch-ROCm/MIOpen), for comparison only;
+  * the audio-only step and the 1:1 AV/AO alternation the shipped flags produce.
 
 Launch: python bench.py --gpus N --steps K --warmup W   (N>1: under torch.distributed.run).
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -25,8 +30,9 @@ if ROOT not in sys.path:
 
 import torch
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
-BATCH_PER_GPU = 32
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense matrix peaks (f32 MFMA; bf16 MFMA, no sparsity)
+PEAK_HBM_GBS = 8000.0                           # HBM3E spec
+BATCH_PER_GPU = 64
 
 
 def step_args(P):
@@ -35,7 +41,7 @@ def step_args(P):
     return a
 
 
-def build(P, dev, seed):
+def build(P, dev, seed, backend):
     torch.manual_seed(seed)
     a = step_args(P)
     mb = P.ModelBuilder()
@@ -44,74 +50,86 @@ def build(P, dev, seed):
     frm = mb.build_frame(arch=a.arch_frame, fc_dim=a.vis_channels, pool_type=a.img_pool, weights="")
     crit_ao, crit_av = mb.build_criterion(a.loss, use_pit=True), mb.build_criterion(a.loss)
     snd, frm = snd.to(dev), frm.to(dev)
+    frm.backend = backend
     return a, snd, frm, P.NetWrapper((snd, frm), crit_ao, crit_av)
 
 
-class ConvTimer:
-    """HIP-event pairs around every implicit-GEMM conv launch (events are recorded on torch's current
-    stream, which is the stream handed to the C ABI), with the algorithmic FLOPs of each launch."""
+class KernelTimer:
+    """HIP-event pairs around every conv launch and every ReLU+bilinear-upsample launch of the step (events are
+    recorded on torch's current stream, which is the stream handed to the C ABI), with the algorithmic FLOPs / HBM
+    bytes of each launch.  The kernel family of a conv call is asked from the library (avsep_conv_kernel_name)."""
 
     def __init__(self, K):
         self.K, self.rec, self.on = K, [], False
         for name in ("fwd", "dgrad", "wgrad", "dgrad_up2x"):
-            self._wrap(name)
+            self._wrap_conv(name)
+        for name in ("fwd", "bwd"):
+            self._wrap_cat(name)
 
-    def _wrap(self, name):
+    def _time(self, orig, args, kw, family, mode, flops, nbytes):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(*args, **kw)
+        e1.record()
+        self.rec.append((mode, flops, e0, e1, family, nbytes))
+        return out
+
+    def _wrap_conv(self, name):
         orig, timer = getattr(self.K.Conv, name), self
 
         def wrapped(cv, *a, **kw):
             if not timer.on:
                 return orig(cv, *a, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(cv, *a, **kw)
-            e1.record()
-            flops = 2.0 * cv.N * cv.Ho * cv.Wo * cv.Cout * cv.Cin * cv.KH * cv.KW
-            # algorithmic HBM bytes: each of the three operands (input, output/cotangent, weights) touched once
-            nbytes = 4.0 * (cv.N * cv.Cin * cv.H * cv.W + cv.N * cv.Cout * cv.Ho * cv.Wo + cv.Cout * cv.Cin * cv.KH * cv.KW)
             mode = "dgrad" if name == "dgrad_up2x" else name
-            timer.rec.append((mode, flops, e0, e1, kernel_family(cv, mode), nbytes))
-            return out
+            with_stats = bool(len(a) > 2 and a[2] is not None) or kw.get("stats") is not None
+            family = "head_dgrad_kernel" if name == "dgrad_up2x" else cv.kernel_name(mode, with_stats)
+            flops = 2.0 * cv.N * cv.Ho * cv.Wo * cv.Cout * cv.Cin * cv.KH * cv.KW
+            wts = cv.Cout * cv.Cin * cv.KH * cv.KW
+            if family.startswith("head_"):
+                # the hi-res 128-channel input is never materialised: low-res sources (+ their gradients) and the logits
+                lo = cv.N * cv.Cin * cv.H * cv.W // 4
+                nbytes = 4.0 * ((2 * lo if mode == "dgrad" else lo) + cv.N * cv.Cout * cv.Ho * cv.Wo + wts)
+            else:   # each of the three operands (input, output / cotangent, weights) touched once
+                nbytes = 4.0 * (cv.N * cv.Cin * cv.H * cv.W + cv.N * cv.Cout * cv.Ho * cv.Wo + wts)
+            return timer._time(orig, (cv,) + a, kw, family, mode, flops, nbytes)
         setattr(self.K.Conv, name, wrapped)
 
-    def summary(self):
-        tot_ms, tot_fl, by, fam = 0.0, 0.0, {}, {}
-        for name, fl, e0, e1, family, nbytes in self.rec:
-            ms = e0.elapsed_time(e1)
-            tot_ms += ms
-            tot_fl += fl
-            for table, key in ((by, name), (fam, family)):
-                b = table.setdefault(key, [0.0, 0.0, 0, 0.0])
-                b[0] += ms; b[1] += fl; b[2] += 1; b[3] += nbytes
-        return tot_ms, tot_fl, by, fam
+    def _wrap_cat(self, name):
+        orig, timer = getattr(self.K.Cat, name), self
 
+        def wrapped(cat, *a, **kw):
+            if not timer.on:
+                return orig(cat, *a, **kw)
+            N, C0, C1, H, W = cat.shape
+            src = N * ((C0 if not cat.bcast0 else 0) + C1) * H * W + (N * C0 if cat.bcast0 else 0)
+            hi = N * (C0 + C1) * 4 * H * W
+            # forward: read the sources, write the hi-res tensor; backward: read its gradient (+ the sources for the
+            # ReLU mask / BatchNorm sums), write the source gradients
+            nbytes = 4.0 * (src + hi) if name == "fwd" else 4.0 * (hi + 2 * src)
+            return timer._time(orig, (cat,) + a, kw, "relu_up2x_" + name, "glue", 0.0, nbytes)
+        setattr(self.K.Cat, name, wrapped)
 
-def kernel_family(cv, mode):
-    """Which HIP kernel a Conv call dispatches to (mirrors the predicates in csrc/conv.hip)."""
-    k3 = cv.KH == 3 and cv.KW == 3 and cv.d.stride == 1 and cv.d.pad == 1 and cv.d.dil == 1
-    if getattr(cv, "head", False):
-        return "head_" + mode + "_kernel"
-    if k3 and cv.Cout <= 4 and mode in ("fwd", "wgrad") and cv.W % 16 == 0:
-        return "smallco_" + mode
-    if k3 and cv.W >= 12 and cv.H >= 4:
-        if mode == "fwd" and cv.Cin % 4 == 0 and cv.d.C0 % 4 == 0 and cv.Cout > 4:
-            return "conv3x3_kernel"
-        if mode == "dgrad" and cv.Cout % 4 == 0 and cv.Cin >= 32:
-            return "conv3x3_kernel"
-        if mode == "wgrad" and cv.Cout > 4 and cv.Cin >= 32 and cv.W % 2 == 0:
-            return "wgrad3x3_kernel"
-    if cv.KH == 4 and cv.KW == 4 and cv.d.stride == 2 and cv.d.pad == 1 and cv.Wo >= 16 and cv.Ho >= 4:
-        if mode == "fwd" and cv.Cin % 2 == 0 and cv.Cout >= 32:
-            return "conv3x3_kernel"           # the same halo-patch kernel, KS = 4 / S = 2 instantiation
-        if mode == "dgrad" and cv.Cout % 8 == 0 and cv.Cin >= 32 and cv.H % 2 == 0 and cv.W % 2 == 0:
-            return "conv3x3_kernel"           # 4 parity-class launches of the KS = 2 instantiation
-    return "igemm_kernel<%s>" % mode
+    def summary(self, steps):
+        fam = {}
+        for mode, fl, e0, e1, family, nbytes in self.rec:
+            b = fam.setdefault(family, {"ms": 0.0, "flops": 0.0, "n": 0, "bytes": 0.0, "modes": set()})
+            b["ms"] += e0.elapsed_time(e1); b["flops"] += fl; b["n"] += 1; b["bytes"] += nbytes; b["modes"].add(mode)
+        self.rec = []
+        out = {}
+        for k, b in fam.items():
+            ms = b["ms"] / steps
+            out[k] = {"ms_per_step": ms, "launches_per_step": b["n"] / steps,
+                      "gflop_per_step": b["flops"] / steps / 1e9,
+                      "tflops": b["flops"] / (b["ms"] * 1e-3) / 1e12 if b["ms"] and b["flops"] else 0.0,
+                      "algorithmic_gbytes_per_step": b["bytes"] / steps / 1e9,
+                      "algorithmic_gb_per_s": b["bytes"] / (b["ms"] * 1e-3) / 1e9 if b["ms"] else 0.0}
+        return out
 
 
 def pmc_traffic(family):
     """PMC-measured HBM traffic of one kernel family, from the committed summary of the rocprofv3 --pmc passes
     (counters cannot be read from inside the process; the summary is regenerated by profiles/summarise_pmc.py)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -119,15 +137,36 @@ def pmc_traffic(family):
     row = table.get("kernels", {}).get(family)
     if row is None:
         return None
-    return {"traffic_bytes_per_step": row.get("traffic_bytes_per_step"),
+    return {"traffic_bytes_per_step": row.get("traffic_bytes_per_step"), "batch": table.get("batch"),
             "source": "profiles/pmc_traffic.json: " + table.get("command", "")}
 
 
+def physical_cores():
+    """Physical cores among the CPUs this process may run on (hyper-thread siblings counted once)."""
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    cores, cur = set(), {}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().split("\n") + [""]:
+                if ":" in line:
+                    k, v = [t.strip() for t in line.split(":", 1)]
+                    cur[k] = v
+                elif cur:
+                    if int(cur.get("processor", -1)) in allowed:
+                        cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                    cur = {}
+    except OSError:
+        pass
+    return max(1, len(cores) or len(allowed))
+
+
 def cpu_baseline(P, seed):
-    """The oracle (CPU restatement pinned to the reference) timed on this host's cores: AV train step,
-    batch 2 (BASELINE configs[0]), 1 warm-up + 3 timed steps (~10-30 s of CPU work)."""
+    """The oracle (CPU restatement pinned to the reference) timed on this host's cores: batch 2 (BASELINE configs[0]),
+    AV and AO train steps separately, 1 warm-up + 5 timed steps each, median; torch threads = physical cores."""
     from oracle import nets as O, step as OS, criterion as OC, stft as OST
     import numpy as np
+    cores = physical_cores()
+    torch.set_num_threads(cores)
     a = step_args(P)
     torch.manual_seed(seed)
     snd = O.build_sound(a.arch_sound, a.num_channels, a.fusion_type, a.att_type)
@@ -142,14 +181,87 @@ def cpu_baseline(P, seed):
                 for src in raw["audios"]]
         mix = torch.from_numpy(np.stack([OST.stft_mag_phase(w.numpy())[0] for w in raw["audio_mix"]]))[:, None]
         return {"mag_mix": mix, "mags": mags, "frames": raw["frames"]}
-    times = []
-    for it in range(4):
-        t0 = time.perf_counter()
-        OS.train_step(wrap, batch(), opt, True, a)
-        times.append(time.perf_counter() - t0)
-    med = sorted(times[1:])[1]
-    return {"value": B / med, "unit": "mixtures/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle AV train step (STFT+fwd+bwd+SGD), batch {B}, 1 warm-up + 3 timed steps, median {med:.2f} s/step"}
+
+    def median_step(use_vis):
+        times = []
+        for _ in range(6):
+            t0 = time.perf_counter()
+            OS.train_step(wrap, batch(), opt, use_vis, a)
+            times.append(time.perf_counter() - t0)
+        return sorted(times[1:])[2]
+    av, ao = median_step(True), median_step(False)
+    return {"value": B / av, "unit": "mixtures/s", "cores": cores, "kind": "port",
+            "ao_value": B / ao, "av_ao_1to1_blend": 2.0 / (av / B + ao / B),
+            "sample": f"oracle train step (STFT+fwd+bwd+SGD) on {cores} threads (= physical cores), batch {B}, 1 warm-up + 5 timed "
+                      f"steps each, medians: AV {av:.2f} s/step, AO {ao:.2f} s/step"}
+
+
+def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer=None, use_vis=True):
+    """Build the model from `seed`, run `warmup` untimed + `steps` timed train steps; returns the measurements."""
+    import torch.distributed as dist
+    P.kernels.set_precision(prec)
+    a, snd, frm, wrap = build(P, dev, seed, backend)
+    opt = P.create_optimizer((snd, frm), a, world_size=world)
+    raw = P.synth.make_batch(B, a.num_mix, a.num_frames, 224, a.audLen, seed=seed + 1 + rank, device=dev)
+
+    def batch():
+        return {"audios": list(raw["audios"]), "audio_mix": raw["audio_mix"], "frames": list(raw["frames"])}
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    first = None
+    for _ in range(max(warmup, 1)):          # at least one untimed step: its loss (identical init) compares precisions
+        err, match, _ = P.net_wrapper.train_step_async(wrap, batch(), opt, use_vis, a)
+        if first is None:
+            first = (float(err), float(match) if match is not None else None)
+    sync()
+    if timer is not None:
+        timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        err, match, _ = P.net_wrapper.train_step_async(wrap, batch(), opt, use_vis, a)
+    sync()
+    dt = time.perf_counter() - t0
+    if timer is not None:
+        timer.on = False
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    res = {"value": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "loss": float(err),
+           "match_loss": float(match) if match is not None else None,
+           "first_step_loss": first[0] if first else None, "first_step_match_loss": first[1] if first else None}
+    del wrap, opt, snd, frm, raw
+    gc.collect()
+    torch.cuda.empty_cache()
+    P.kernels.set_precision("f32")
+    return res
+
+
+def roofline_of(kernels, prec, step_ms, B_total_per_gpu):
+    """dominant MFMA kernel + whole-step fraction + the HBM-bound families, from a KernelTimer summary."""
+    mfma = {k: v for k, v in kernels.items() if v["gflop_per_step"] > 0 and not k.startswith(("head_", "smallc"))}
+    dom = max(mfma, key=lambda k: mfma[k]["ms_per_step"])
+    d = mfma[dom]
+    # a kernel family computes in bf16 only if it is one of the bf16 kernels; the rest of a bf16 step is exact f32
+    peak = PEAK_TFLOPS["bf16"] if dom in ("convbf_kernel", "wgradbf_kernel") else PEAK_TFLOPS["f32"]
+    tot_fl = sum(v["gflop_per_step"] for v in kernels.values())
+    tot_ms = sum(v["ms_per_step"] for k, v in kernels.items() if v["gflop_per_step"] > 0)
+    roof = {"bound": "mfma", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak,
+            "traffic": None, "kernel": dom, "launches_per_step": d["launches_per_step"],
+            "avg_launch_ms": d["ms_per_step"] / d["launches_per_step"],
+            "algorithmic_gflop_per_launch": d["gflop_per_step"] / d["launches_per_step"],
+            "algorithmic_bytes_per_launch": d["algorithmic_gbytes_per_step"] * 1e9 / d["launches_per_step"]}
+    step = {"algorithmic_gflop_per_step": tot_fl, "ms_per_step": step_ms, "achieved": tot_fl / step_ms,   # GFLOP/ms = TFLOP/s
+            "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s", "frac": tot_fl / step_ms / PEAK_TFLOPS[prec],
+            "conv_kernel_ms_per_step": tot_ms, "all_convs_tflops": tot_fl / tot_ms if tot_ms else 0.0}
+    hbm = {k: {"ms_per_step": v["ms_per_step"], "achieved": v["algorithmic_gb_per_s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": v["algorithmic_gb_per_s"] / PEAK_HBM_GBS, "bound": "hbm"}
+           for k, v in kernels.items() if k.startswith(("head_", "relu_up2x", "smallc"))}
+    return roof, step, hbm
 
 
 def main():
@@ -157,10 +269,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (configs[1]: 32)")
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (configs[2]: 64)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"], help="arithmetic of the HEADLINE run")
+    ap.add_argument("--backend", default="hip", choices=["hip", "hybrid", "torch"], help="visual trunk of the headline run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ao", action="store_true", help="time the audio-only step instead (extra, not the headline)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the untimed AO-step / blend extras (profiling runs)")
+    ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
     o = ap.parse_args()
 
     import avsep_amd as P
@@ -171,92 +284,59 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     import torch.distributed as dist
 
-    seed = 1234
-    a, snd, frm, wrap = build(P, dev, seed)                 # identical replicas: same seed on every rank
-    opt = P.create_optimizer((snd, frm), a, world_size=world)
-    B = o.batch
-    raw = P.synth.make_batch(B, a.num_mix, a.num_frames, 224, a.audLen, seed=seed + 1 + rank, device=dev)
-    use_vis = not o.ao
-
-    def batch():
-        return {"audios": list(raw["audios"]), "audio_mix": raw["audio_mix"], "frames": list(raw["frames"])}
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    timer = ConvTimer(P.kernels)
-    for _ in range(o.warmup):
-        P.net_wrapper.train_step_async(wrap, batch(), opt, use_vis, a)
-    sync()
-    timer.on = True
-    t0 = time.perf_counter()
-    for _ in range(o.steps):
-        err, match, _ = P.net_wrapper.train_step_async(wrap, batch(), opt, use_vis, a)
-    sync()
-    dt = time.perf_counter() - t0
-    timer.on = False
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = t.item()
-    conv_ms, conv_fl, by, fam = timer.summary()
-    # extra (outside the timed region, not part of `value`): the audio-only step and the 1:1 AV/AO alternation
-    # the shipped flags produce (iter_per_av 2: AV on even iterations, scripts/train_MUSIC.sh:10-11,50)
-    ao_rate = None
-    if not o.ao and world == 1 and not o.no_extra:
-        for _ in range(2):
-            P.net_wrapper.train_step_async(wrap, batch(), opt, False, a)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(4):
-            P.net_wrapper.train_step_async(wrap, batch(), opt, False, a)
-        torch.cuda.synchronize()
-        ao_rate = 4 * B / (time.perf_counter() - t1)
+    seed, B = 1234, o.batch
+    timer = KernelTimer(P.kernels)
+    head = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup, timer)
+    kernels = timer.summary(o.steps)
+    extras = {}
+    if world == 1 and not o.no_extra:
+        other = "bf16" if o.precision == "f32" else "f32"
+        r = run_config(P, dev, world, seed, rank, other, "hip", B, o.steps, o.warmup, timer)
+        k2 = timer.summary(o.steps)
+        roof2, step2, _ = roofline_of(k2, other, r["ms_per_step"], B)
+        r.update({"dtype": other, "roofline": roof2, "roofline_step": step2,
+                  "first_step_loss_abs_diff_vs_headline": abs(r["first_step_loss"] - head["first_step_loss"]),
+                  "workload": "same step, conv operands rounded to bf16 while staged, fp32 accumulate / BatchNorm statistics / "
+                              "loss / master weights / SGD (BASELINE configs[2])" if other == "bf16" else "same step in fp32",
+                  "by_kernel": {k: {"ms_per_step": round(v["ms_per_step"], 3), "tflops": round(v["tflops"], 1)} for k, v in k2.items()}})
+        extras[other] = r
+        hyb = run_config(P, dev, world, seed, rank, "f32", "hybrid", min(B, 32), max(3, o.steps // 2), 2)
+        extras["f32_miopen_hybrid"] = dict(hyb, workload="round-1 configs[1] path at batch %d: visual convolutions on PyTorch-ROCm/"
+                                           "MIOpen, HIP BatchNorm glue; comparison only, not this build's kernels" % min(B, 32))
+        ao = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, max(3, o.steps // 2), 2, use_vis=False)
+        extras["ao_step_mixtures_per_s"] = ao["value"]
+        extras["av_ao_1to1_blend_mixtures_per_s"] = 2.0 / (1.0 / head["value"] + 1.0 / ao["value"])
 
     if rank == 0:
-        ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        dom = max(fam, key=lambda k: fam[k][0])                    # the kernel with the most time per step
-        d_ms, d_fl, d_n, d_bytes = fam[dom]
-        d_ach = d_fl / (d_ms * 1e-3) / 1e12
-        traffic = pmc_traffic(dom)
+        roof, roof_step, hbm = roofline_of(kernels, o.precision, head["ms_per_step"], B)
+        traffic = pmc_traffic(roof["kernel"])
+        if traffic and traffic["traffic_bytes_per_step"]:
+            scale = B / float(traffic["batch"] or B)               # PMC passes may run at another batch: bytes scale with it
+            roof["traffic"] = traffic["traffic_bytes_per_step"] * scale / roof["launches_per_step"]
+            roof["traffic_source"] = traffic["source"]
+        vis = {"hip": "visual trunk on this library (no MIOpen kernel in the step)",
+               "hybrid": "visual convolutions on PyTorch-ROCm/MIOpen with HIP BatchNorm/ReLU glue",
+               "torch": "visual trunk on PyTorch-ROCm"}[o.backend]
         out = {
-            "metric": "mixtures/sec (train step, 2-src MUSIC shape)", "value": world * B * o.steps / dt,
+            "metric": "mixtures/sec (train step, 2-src MUSIC shape)", "value": head["value"],
             "unit": "mixtures/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,
-            "ms_per_step": dt / o.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("AO" if o.ao else "AV") + " train step: 2-source mix, batch %d/GPU, 65535-sample "
-                       "waveforms -> STFT 1022/256 -> 256x256 log-freq tiles, 3x224^2 frames/source, unet7+hidsep(sig)+"
-                       "resnet18dilated, BCE, SGD; HIP STFT+prepare+U-Net+fusion+loss+SGD, visual convolutions on PyTorch-ROCm/"
-                       "MIOpen with HIP BatchNorm/ReLU glue (BASELINE configs[1])" % B,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": o.precision, "data": "synthetic",
+            "config": {"workload": "full HIP path, AV train step: 2-source mix, batch %d/GPU (BASELINE configs[2] shape), 65535-sample "
+                       "waveforms -> HIP STFT 1022/256 -> 256x256 log-freq tiles, 3x224^2 frames/source, unet7+hidsep(sig)+"
+                       "resnet18dilated, BCE, SGD; %s arithmetic; %s" % (B, o.precision, vis),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "loss": float(err), "match_loss": float(match) if match is not None else None,
-            "extra": None if ao_rate is None else {
-                "ao_step_mixtures_per_s": ao_rate,
-                "av_ao_1to1_blend_mixtures_per_s": 2.0 / (1.0 / (world * B * o.steps / dt) + 1.0 / ao_rate)},
-            # dominant kernel = the HIP kernel with the largest time per step; achieved = its algorithmic FLOPs per
-            # launch / its average launch duration (HIP events on the launch stream, inside the timed region)
-            "roofline": {"bound": "mfma", "achieved": d_ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": d_ach / PEAK_F32_MFMA_TFLOPS,
-                         # HBM bytes per launch from rocprofv3 PMC passes of this same command (2*FETCH_SIZE + WRITE_SIZE,
-                         # the gfx950 correction of MI355X_MICROARCH.md); measured offline, see profiles/summarise_pmc.py
-                         # (per conv call like `achieved`: a 4x4/s2 data gradient is 4 kernel launches, one per parity class)
-                         "traffic": (traffic["traffic_bytes_per_step"] / (d_n / max(o.steps, 1))
-                                     if traffic and traffic["traffic_bytes_per_step"] else None),
-                         "traffic_source": traffic["source"] if traffic else None,
-                         "algorithmic_bytes_per_launch": d_bytes / max(d_n, 1), "kernel": dom,
-                         "launches_per_step": d_n / max(o.steps, 1), "avg_launch_ms": d_ms / max(d_n, 1),
-                         "algorithmic_gflop_per_launch": d_fl / max(d_n, 1) / 1e9},
-            "roofline_all_convs": {"achieved": ach, "frac": ach / PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "launches_per_step": len(timer.rec) / max(o.steps, 1),
-                                   "kernel_ms_per_step": conv_ms / max(o.steps, 1),
-                                   "algorithmic_gflop_per_step": conv_fl / max(o.steps, 1) / 1e9,
-                                   "by_kernel": {k: {"ms_per_step": v[0] / o.steps, "tflops": v[1] / (v[0] * 1e-3) / 1e12 if v[0] else 0.0,
-                                                     "launches": v[2] // max(o.steps, 1)} for k, v in fam.items()},
-                                   "by_mode": {k: {"ms_per_step": v[0] / o.steps, "tflops": v[1] / (v[0] * 1e-3) / 1e12 if v[0] else 0.0,
-                                                   "launches": v[2] // max(o.steps, 1)} for k, v in by.items()}},
+            "loss": head["loss"], "match_loss": head["match_loss"], "first_step_loss": head["first_step_loss"],
+            # dominant kernel = the MFMA kernel family with the largest time per step; achieved = its algorithmic FLOPs /
+            # its HIP-event time (events on the launch stream, inside the timed region)
+            "roofline": roof,
+            # whole step: algorithmic conv FLOPs executed per step / wall time per step / peak
+            "roofline_step": roof_step,
+            # the VALU / HBM-bound kernels of the conv path: algorithmic bytes / HIP-event time against the HBM peak
+            "roofline_hbm_kernels": hbm,
+            "by_kernel": {k: {"ms_per_step": round(v["ms_per_step"], 3), "tflops": round(v["tflops"], 1),
+                              "launches_per_step": v["launches_per_step"]} for k, v in kernels.items()},
+            "extra": extras or None,
         }
         if world == 1 and not o.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, seed)

@@ -104,9 +104,27 @@ int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, flo
  * avsep_conv2d_dgrad followed by avsep_relu_up2x_bwd (g0 [N,C0,H/2,W/2] accumulated in place when acc0, g1
  * [N,C1,H/2,W/2], bstats1[2*C1] += BatchNorm-backward sums of source 1).  w is OIHW. */
 int32_t avsep_conv2d_head_applicable(const avsep_conv_desc* d);
+/* Name of the kernel family avsep_conv2d_fwd (mode 0, `with_stats` as it will be called), _dgrad (mode 1) or _wgrad
+ * (mode 2) dispatches this descriptor to ("convbf_kernel", "wgradbf_kernel", "conv3x3_kernel", "wgrad3x3_kernel",
+ * "igemm_kernel<fwd|dgrad|wgrad>", "head_*_kernel", "smallco_*", "smallci_dgrad"): measurement bookkeeping
+ * (bench.py groups its HIP-event timings by it), static strings, never freed. */
+const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t mode, int32_t with_stats);
 int avsep_conv2d_dgrad_up2x(const avsep_conv_desc* d, const float* w, const float* dy, float* g0,
                             float* g1, const float* mean1, const float* invstd1, double* bstats1,
                             int32_t acc0, avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * SoP++ attention module core (SoP++/attention_net.py:24-58: `att` + `av_infer_forward`, shared by AttModel / MatchAtt):
+ * a [B,S,K] pooled audio queries (S <= 4, K <= 128), mix [B,K,HW] mixed visual map (HW <= 4096), att 0 = cos, 1 = sig.
+ *   maps_raw [B,S,HW] similarity maps BEFORE the clamp; ctx [B,S,K] = mean_hw(mix * clamp(maps,0,1));
+ *   match [B] = -sum_s mean_hw maps_raw (the module's match term is its batch mean).
+ * Backward: dctx [B,S,K], dmaps [B,S,HW] (wrt the clamped maps; may be NULL), dmatch [B] (may be NULL) -> da, dmix.
+ * ------------------------------------------------------------------------- */
+int avsep_attmodel_infer_fwd(const float* a, const float* mix, int32_t B, int32_t S, int32_t K, int32_t HW, int32_t att,
+                             float* maps_raw, float* ctx, float* match, avsep_stream_t stream);
+int avsep_attmodel_infer_bwd(const float* a, const float* mix, const float* maps_raw, const float* dctx,
+                             const float* dmaps, const float* dmatch, int32_t B, int32_t S, int32_t K, int32_t HW,
+                             int32_t att, float* da, float* dmix, avsep_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * The same BatchNorm / ReLU / residual pieces for channels-last activations ([N,H,W,C] viewed as [M, C];

@@ -4,6 +4,7 @@ Plain PyTorch (CPU, fp32) restatement; TEST INFRASTRUCTURE ONLY (see package
 docstring).  Module/parameter names reproduce the reference's ``state_dict``
 keys so the same weights load into the reference, the oracle and the HIP path.
 """
+import itertools
 import math
 
 import torch
@@ -39,6 +40,20 @@ def _attend(kind, a, v, scale_dim):
     raise ValueError(kind)
 
 
+def ao_permute_n(x, draws, C):
+    """BUILD-DEFINED generalisation of the audio-only swap to C > 2 sources (no reference counterpart: the reference
+    hard-codes two blocks, fusion_net.py:93-104).  draws: long[B], index of a permutation of the C audio blocks in
+    itertools order; slot c receives block perm[c]; channels beyond C*(D//C) of the tile are zero (remainder rule of
+    `Fusion._coloc_n`)."""
+    B, D, Fq, T = x.shape
+    Dc = D // C
+    g = torch.amax(x, dim=(2, 3))[:, :C * Dc].view(B, C, Dc)
+    table = torch.tensor(list(itertools.permutations(range(C))))
+    sel = torch.gather(g, 1, table[draws.long()][:, :, None].expand(B, C, Dc))
+    tiles = torch.cat([sel.reshape(B, C * Dc), x.new_zeros(B, D - C * Dc)], 1)
+    return torch.cat([tiles.reshape(B, D, 1, 1).expand(B, D, Fq, T), x], 1)
+
+
 def ao_swap(x, draws):
     """fusion_net.py:93-104 (identical in CoLoc/CoLoc_Sel/MixVis).
 
@@ -72,14 +87,52 @@ class Fusion(nn.Module):
         self.att_type = att_type
         self.ao_draws = None  # tests may pin the AO random draw
 
+    num_src = 2     # audio blocks of the audio-only path (the AV path reads it off len(v_ls))
+
     def forward(self, x, v_ls):
         if v_ls is None:
             B = x.shape[0]
+            if self.num_src > 2:
+                draws = self.ao_draws if self.ao_draws is not None else \
+                    torch.randint(0, math.factorial(self.num_src), (B,))
+                return ao_permute_n(x, draws, self.num_src), (None, None)
             draws = self.ao_draws if self.ao_draws is not None else (torch.rand(B) > 0.5)
             return ao_swap(x, draws), (None, None)
         if self.fusion_type == "MixVis":
             return self._mixvis(x, v_ls)
+        if len(v_ls) > 2:
+            if self.fusion_type != "hidsep":
+                raise NotImplementedError("only CoLoc (hidsep) is generalised beyond two sources")
+            return self._coloc_n(x, v_ls)
         return self._coloc(x, v_ls, select=(self.fusion_type == "CoLoc_Sel"))
+
+    def _coloc_n(self, x, v_ls):
+        """BUILD-DEFINED generalisation of CoLoc (fusion_net.py:35-72) to C = len(v_ls) > 2 sources — BASELINE.json
+        configs[4]; the reference hard-codes C = P = 2 (`x_t = stack((x_p1, x_p2))`) and has no counterpart.  Rules:
+          * Dc = D // C channels per audio block; the blocks are the FIRST C*Dc pooled channels, the D - C*Dc remainder
+            channels take no part in the matching and their tile channels are zero, so the fused tensor keeps the
+            reference's 2*D channels (the U-Net's parameter shapes do not depend on C);
+          * all C! permutations in itertools order: maps[b,p,c] = att(a[perm_p[c]], v_c); scores[b,p] = sum_c max maps;
+          * best = FIRST maximum (torch.sort on two entries gives the same winner absent ties);
+            match_loss = mean_b(-score_best + sum of the other scores); att_maps = maps[b, best];
+          * f_c = max_{h,w}(v_c * att_maps_c), tiled.
+        With C = 2 this is `_coloc(select=False)` (asserted by tests/test_oracle_golden.py against the reference goldens)."""
+        B, D, Fq, T = x.shape
+        C = len(v_ls)
+        Dc = D // C
+        a = torch.amax(x, dim=(2, 3))[:, :C * Dc].view(B, C, Dc)
+        table = torch.tensor(list(itertools.permutations(range(C))))            # [P,C]
+        perms = a[:, table]                                                       # [B,P,C,Dc]
+        v = torch.stack(v_ls, 1)                                                  # [B,C,Dc,H,W]
+        maps = _attend(self.att_type, perms, v[:, None], Dc)                      # [B,P,C,H,W]
+        scores = torch.amax(maps, dim=(3, 4)).sum(-1)                             # [B,P]
+        best = scores.argmax(1)                                                   # first maximum
+        srt_best = scores.gather(1, best[:, None])[:, 0]
+        match_loss = (-srt_best + (scores.sum(1) - srt_best)).mean(0)
+        att = maps[torch.arange(B), best]                                         # [B,C,H,W]
+        f = torch.amax(v * att[:, :, None], dim=(3, 4))                           # [B,C,Dc]
+        tiles = torch.cat([f.reshape(B, C * Dc), x.new_zeros(B, D - C * Dc)], 1)
+        return torch.cat([tiles.reshape(B, D, 1, 1).expand(B, D, Fq, T), x], 1), (match_loss, att)
 
     def _coloc(self, x, v_ls, select):
         # fusion_net.py:35-72 (CoLoc) / 127-190 (CoLoc_Sel); C = P = 2.
@@ -179,6 +232,7 @@ class Unet(nn.Module):
         self.extra_size = extra_size
         if extra_size is None:
             fusion = Fusion(fusion_type, att_type)
+            fusion.num_src = fc_dim if 2 < fc_dim <= 4 else 2      # one output channel per source (num_channels == num_mix)
             lvl = _Level(ngf * 8, ngf * 8, ngf * 8, ngf * 16, "inner", None, fusion)
         else:  # SoP++ variant (SoP++/audio_net.py:151-198): no fusion, wider bottleneck conv
             lvl = _Level(ngf * 8, ngf * 8 + 2 * extra_size, ngf * 8, ngf * 8, "inner", None, None)

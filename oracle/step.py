@@ -65,12 +65,13 @@ class NetWrapper(torch.nn.Module):
         feat, *_ = self.net_sound(log_mag_mix, None)
         pred = activate(feat, args.output_activation).permute(0, 2, 3, 1)
         gt = torch.stack(gt_masks, -1)[:, 0]
-        w2 = torch.stack([weight[:, 0]] * 2, -1)
+        S = len(gt_masks)      # main.py:103 hard-codes 2; build-defined generalisation: one weight copy per target
+        w2 = torch.stack([weight[:, 0]] * S, -1)
         err, perms = self.crit_ao(pred, gt, w2)
         err = err.mean()
         ordered = self.crit_ao.reorder_tensor(pred, perms)
-        return err, {"pred_masks": [ordered[..., i].unsqueeze(1) for i in range(2)],
-                     "gt_masks": [gt[..., i].unsqueeze(1) for i in range(2)],
+        return err, {"pred_masks": [ordered[..., i].unsqueeze(1) for i in range(S)],
+                     "gt_masks": [gt[..., i].unsqueeze(1) for i in range(S)],
                      "mag_mix": mag_mix, "mags": mags, "weight": w2, "perms": perms}
 
     def visual(self, frames, args):

@@ -308,6 +308,63 @@ def test_sopp_variant_vs_oracle(dev, golden):
         assert_close(dict(snd.named_parameters())[k].grad, dict(osnd.named_parameters())[k].grad, 3e-3, f"stage {stage} bottleneck conv grad")
 
 
+def test_sopp_three_stage_schedule_vs_oracle(dev):
+    """SoP++/main.py:670-688 + :593-606: train_step_3stage picks the AV stage from the iteration number (stage 1 below
+    train_steps[0], 2 below train_steps[1], 3 up to train_steps[2]) and steps the SoP++ optimizer groups; six
+    iterations (AV on the even ones, as the shipped flags schedule them) against the oracle's stage forwards driven by
+    the same rule + torch.optim.SGD over the reference's groups: every loss, then the parameters."""
+    P = _pkg()
+    from avsep_amd import sopp as PS
+    from oracle import nets as O, criterion as OC, sopp as OSP
+    torch.manual_seed(19)
+    gen = torch.Generator().manual_seed(19)
+    K = 8
+    osnd = O.Unet(fc_dim=K, num_downs=5, ngf=8, extra_size=K)
+    O.wide_init(osnd, gen)
+    ofrm = O.VisualNet(fc_dim=K, pool_type="maxpool", dilate_scale=16)
+    osyn, opit = O.InnerProd(K), OSP.AttModule("AttModel", "sig")
+    snd = P.models.Unet(fc_dim=K, num_downs=5, ngf=8, extra_size=K)
+    frm = P.models.ResnetDilated(None, fc_dim=K, pool_type="maxpool")
+    syn = P.ModelBuilder().build_synthesizer("linear", fc_dim=K)
+    snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict()); syn.load_state_dict(osyn.state_dict())
+    snd, frm, syn = snd.to(dev), frm.to(dev), syn.to(dev)
+    args = _args(sound_activation="no", fusion_type="Base", att_type="sig", lr_synthesizer=1e-3, train_steps=[2, 4, 6])
+    pit = P.models.get_attmodule(args)(att_type="sig").to(dev)
+    mb = P.ModelBuilder()
+    wrap = PS.NetWrapper((snd, frm, syn, pit), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
+    owrap = OSP.SopNetWrapper((osnd, ofrm, osyn, opit), OC.build_criterion("bce", True), OC.build_criterion("bce"))
+    opt = PS.create_optimizer((snd, frm, syn, pit), args)
+    groups = [{"params": osnd.parameters(), "lr": args.lr_sound}, {"params": osyn.parameters(), "lr": args.lr_synthesizer}]
+    if list(opit.parameters()):
+        groups.append({"params": opit.parameters(), "lr": args.lr_synthesizer})
+    groups += [{"params": ofrm.features.parameters(), "lr": args.lr_frame}, {"params": ofrm.fc.parameters(), "lr": args.lr_sound}]
+    oopt = torch.optim.SGD(groups, momentum=args.beta1, weight_decay=args.weight_decay)
+    srcs = [torch.rand(2, 1, 64, 64, generator=gen) ** 2 for _ in range(2)]
+    frames = [torch.randn(2, 3, 2, 64, 64, generator=gen) for _ in range(2)]
+
+    def batch(d):
+        return {"mag_mix": (srcs[0] + srcs[1]).to(d), "mags": [s.clone().to(d) for s in srcs], "frames": [f.to(d) for f in frames]}
+    assert [PS.stage_of(i, args.train_steps) for i in range(7)] == [1, 1, 2, 2, 3, 3, 3]
+    with pytest.raises(ValueError):
+        PS.stage_of(7, args.train_steps)
+    for i in range(7):
+        use_vis = i % 2 == 0
+        err, match = PS.train_step_3stage(wrap, batch(dev), opt, use_vis, i, args)
+        owrap.train()
+        oopt.zero_grad(set_to_none=True)
+        oerr, oouts = owrap(batch("cpu"), args, use_vis, PS.stage_of(i, args.train_steps))
+        oerr.mean().backward()
+        oopt.step()
+        assert abs(err - oerr.mean().item()) < 3e-4 * max(1.0, abs(err)), (i, err, oerr.mean().item())
+        if use_vis:
+            assert abs(match - oouts["match_loss"].mean().item()) < 3e-4
+    osd = osnd.state_dict()
+    for k, v in snd.state_dict().items():
+        if v.dtype.is_floating_point and "running" not in k:
+            assert_close(v, osd[k], 3e-3, "after 7 three-stage steps: " + k)
+    assert_close(syn.scale, osyn.scale, 1e-3, "synthesizer scale")
+
+
 def test_shared_encoder_pair_equals_two_passes(dev, golden):
     """forward_pair (one encoder, two decoders) == two forward() calls: outputs, every gradient, and the
     BatchNorm running statistics (two momentum updates)."""
@@ -349,6 +406,63 @@ def test_config2_bf16_full_hip_step_vs_oracle(dev):
     steps as configs[1], against the fp32 CPU oracle: the north-star bound  mask MSE <= 1e-4  must hold; the loss may
     differ by the bf16 operand rounding (bound 2e-3 of the loss, measured value printed)."""
     _full_size_step(dev, 1, "hip", "bf16", 2e-3)
+
+
+def test_config5_three_sources_five_frames_step_vs_oracle(dev):
+    """BASELINE.json configs[4]: 3-source mix, 512x256 STFT tiles (log_freq 0), 5 frames per source.  The reference
+    hard-codes two sources (fusion_net.py:35,43-46; main.py:103,109); the N-source generalisation is build-defined
+    (DESIGN.md §9), restated in the oracle (Fusion._coloc_n, ao_permute_n, per-target PIT weights) and pinned to the
+    reference at N = 2 by tests/test_oracle_golden.py.  Here the HIP path (3 x 5 frames through the visual trunk, two
+    U-Net passes with reversed / natural visual order, 3! PIT permutations on the audio-only step) meets that oracle
+    at full tile size: loss, match loss, mask MSE <= 1e-4."""
+    import numpy as np
+    P = _pkg()
+    from oracle import nets as O, step as OS, criterion as OC, stft as OST
+    a = P.arguments.train_music_args()
+    a.stft_pad_mode = "reflect"
+    a.log_freq, a.num_mix, a.num_frames, a.num_channels = 0, 3, 5, 3
+    a.vis_channels = 512 // 3                                    # remainder rule: 2 bottleneck channels stay unmatched
+    raw = P.synth.make_batch(2, a.num_mix, a.num_frames, 224, a.audLen, seed=78)
+    mags = [torch.from_numpy(np.stack([OST.stft_mag_phase(w.numpy())[0] for w in src]))[:, None] for src in raw["audios"]]
+    mix = torch.from_numpy(np.stack([OST.stft_mag_phase(w.numpy())[0] for w in raw["audio_mix"]]))[:, None]
+    torch.manual_seed(12)
+    gen = torch.Generator().manual_seed(12)
+    osnd = O.build_sound(a.arch_sound, a.num_channels, a.fusion_type, a.att_type)
+    O.wide_init(osnd, gen)
+    ofrm = O.build_frame(a.arch_frame, a.vis_channels, a.img_pool)
+    mb = P.ModelBuilder()
+    snd = mb.build_sound(arch=a.arch_sound, fc_dim=a.num_channels, fusion_type=a.fusion_type, att_type=a.att_type)
+    frm = mb.build_frame(arch=a.arch_frame, fc_dim=a.vis_channels, pool_type=a.img_pool)
+    assert [tuple(v.shape) for v in snd.state_dict().values()][:-2] == \
+        [tuple(v.shape) for v in mb.build_sound(arch=a.arch_sound, fc_dim=2, fusion_type=a.fusion_type,
+                                                 att_type=a.att_type).state_dict().values()][:-2], \
+        "only the last conv (one logit per source) may depend on the number of sources"
+    snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict())
+    snd, frm = snd.to(dev), frm.to(dev)
+    frm.backend = "hip"
+    wrap = P.NetWrapper((snd, frm), mb.build_criterion(a.loss, use_pit=True), mb.build_criterion(a.loss))
+    opt = P.create_optimizer((snd, frm), a)
+    owrap = OS.NetWrapper((osnd, ofrm), OC.build_criterion(a.loss, True), OC.build_criterion(a.loss))
+    oopt = OS.create_optimizer((osnd, ofrm), a)
+    for use_vis in (True, False):
+        draws = torch.tensor([4, 1])                              # permutation indices (itertools order) of the AO step
+        snd.ao_draws = draws
+        osnd.levels()[-1].fusion.ao_draws = draws
+        gb = {"audios": [w.to(dev) for w in raw["audios"]], "audio_mix": raw["audio_mix"].to(dev),
+              "frames": [f.to(dev) for f in raw["frames"]]}
+        cb = {"mag_mix": mix.clone(), "mags": [m.clone() for m in mags], "frames": raw["frames"]}
+        err, match, outs = P.net_wrapper.train_step_async(wrap, gb, opt, use_vis, a)
+        oerr, omatch, oouts = OS.train_step(owrap, cb, oopt, use_vis, a)
+        assert len(outs["pred_masks"]) == 3 and outs["pred_masks"][0].shape == (2, 1, 512, 256)
+        mse = max(((x.detach().cpu() - y.detach()) ** 2).mean().item()
+                  for x, y in zip(outs["pred_masks"], oouts["pred_masks"]))
+        print(f"configs[4] 3 sources {'AV' if use_vis else 'AO'}: err hip={err.item():.6f} oracle={oerr:.6f} mask-MSE={mse:.2e}")
+        assert mse <= 1e-4, mse
+        assert abs(err.item() - oerr) <= 1e-4 * max(1.0, abs(oerr)), (use_vis, err.item(), oerr)
+        if use_vis:
+            assert abs(match.item() - omatch) <= 1e-4
+        else:
+            assert list(oouts["perms"]) == list(wrap._last_perms), "PIT must pick the same permutation of the 3 sources"
 
 
 def _full_size_step(dev, log_freq, backend, prec, err_tol):
@@ -623,6 +737,26 @@ def test_loader_to_gpu_step(dev, tmp_path):
         assert err == err and 0.0 < err < 5.0, err
 
 
+def _dp_setup(P, dev, world, shard):
+    """Identical replica (seed 3) + the shard's slice of the global batch (seed 20 + shard)."""
+    a = _args(log_freq=0)
+    torch.manual_seed(3)
+    snd = P.models.Unet(fc_dim=2, num_downs=5, ngf=8, fusion_type="hidsep", att_type="sig").to(dev)
+    frm = P.models.ResnetDilated(None, fc_dim=32, pool_type="maxpool").to(dev)
+    snd.ao_draws = torch.tensor([True, False])              # pin the audio-only coin: replicas and reference agree
+    mb = P.ModelBuilder()
+    wrap = P.NetWrapper((snd, frm), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
+    opt = P.create_optimizer((snd, frm), a, world_size=world)
+    return a, snd, frm, wrap, opt
+
+
+def _dp_batch(dev, shard):
+    gen = torch.Generator().manual_seed(20 + shard)
+    srcs = [torch.rand(2, 1, 64, 64, generator=gen) ** 2 for _ in range(2)]
+    frames = [torch.randn(2, 3, 1, 64, 64, generator=gen) for _ in range(2)]
+    return {"mag_mix": (srcs[0] + srcs[1]).to(dev), "mags": [s.clone().to(dev) for s in srcs], "frames": [f.to(dev) for f in frames]}
+
+
 def _dp_worker(rank, world, port, out, overlap):
     import os
     import sys
@@ -632,32 +766,56 @@ def _dp_worker(rank, world, port, out, overlap):
     import avsep_amd as P
     import torch.distributed as dist
     r, w, dev = P.dp.init_from_env()
-    a = _args(log_freq=0)
-    torch.manual_seed(3)                                    # identical replicas
-    snd = P.models.Unet(fc_dim=2, num_downs=5, ngf=8, fusion_type="hidsep", att_type="sig").to(dev)
-    frm = P.models.ResnetDilated(None, fc_dim=32, pool_type="maxpool").to(dev)
-    mb = P.ModelBuilder()
-    wrap = P.NetWrapper((snd, frm), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
-    opt = P.create_optimizer((snd, frm), a, world_size=w)
-    gen = torch.Generator().manual_seed(20 + rank)          # rank-local shard of the global batch
-    srcs = [torch.rand(2, 1, 64, 64, generator=gen) ** 2 for _ in range(2)]
-    frames = [torch.randn(2, 3, 1, 64, 64, generator=gen) for _ in range(2)]
+    a, snd, frm, wrap, opt = _dp_setup(P, dev, w, rank)
+    reduced, orig = [], opt.reduce_gradients
+
+    def spy(only=None):                                      # the mean gradient every rank is about to apply
+        active, scale = orig(only)
+        reduced.append(((opt.flat_grad * scale).cpu(), [list(g["range"]) for g in active]))
+        return active, scale
+    opt.reduce_gradients = spy
     losses = []
     for it in range(4):
-        b = {"mag_mix": (srcs[0] + srcs[1]).to(dev), "mags": [s.clone().to(dev) for s in srcs],
-             "frames": [f.to(dev) for f in frames]}
-        err, _, _ = P.net_wrapper.train_step_async(wrap, b, opt, it % 2 == 0, a)
+        err, _, _ = P.net_wrapper.train_step_async(wrap, _dp_batch(dev, rank), opt, it % 2 == 0, a)
         losses.append(float(err))
     flat = torch.cat([p.detach().reshape(-1) for p in list(snd.parameters()) + list(frm.parameters())]).cpu()
-    torch.save({"losses": losses, "params": flat, "early": opt.early_reductions}, f"{out}.{overlap}.{rank}")
+    torch.save({"losses": losses, "params": flat, "early": opt.early_reductions, "reduced": reduced[:2]}, f"{out}.{overlap}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _dp_reference(dev):
+    """Single process: the two shards' gradients computed one after the other from the same parameters (BatchNorm
+    statistics stay per shard, as on two ranks), their MEAN, then the SGD update with that mean — for an AV step and the
+    AO step that follows it.  Returns [(mean flat gradient, active ranges)] in FlatSGD's buffer order."""
+    P = _pkg()
+    a, snd, frm, wrap, opt = _dp_setup(P, dev, 1, 0)
+    out = []
+    for use_vis in (True, False):
+        grads = []
+        for shard in range(2):
+            opt.zero_grad()
+            wrap.train()
+            err, _ = wrap.forward(_dp_batch(dev, shard), a, use_vis)
+            err.mean().backward()
+            opt._collect()
+            grads.append(opt.flat_grad.clone())
+        mean = (grads[0] + grads[1]) / 2
+        opt.flat_grad.copy_(mean)
+        only = None if use_vis else ("sound",)
+        ranges = [list(g["range"]) for g in opt.param_groups if only is None or g["name"] in only]
+        out.append((mean.cpu(), ranges))
+        opt.step(only=only)                                  # what the two ranks apply; zero_grad() must not run first
+    return out
+
+
 def test_data_parallel_two_ranks_early_allreduce(dev, tmp_path):
-    """N > 1 path on the GPU (2 ranks sharing the device over gloo; RCCL refuses two ranks on one GPU): replicas stay
-    identical, and issuing the U-Net's gradient all-reduce early (overlapping the visual backward) gives the same
-    parameters as the single all-reduce in step()."""
+    """N > 1 path on the GPU (2 ranks sharing the device over gloo; RCCL refuses two ranks on one GPU), REAL model:
+      * the gradient every rank applies (flat buffer after FlatSGD.reduce_gradients, x 1/world) equals the MEAN of the
+        two shards' single-process gradients to <= 1e-5, for an AV step (all three parameter groups) and for the AO step
+        after it (U-Net group only) — what DataParallel's err.mean() at main.py:562 computes;
+      * replicas stay identical, and issuing the U-Net's all-reduce early (overlapping the visual backward) gives the
+        same parameters as the single all-reduce in step()."""
     import socket
     import torch.multiprocessing as mp
     res = {}
@@ -672,6 +830,15 @@ def test_data_parallel_two_ranks_early_allreduce(dev, tmp_path):
     assert_close(res["1"][0]["params"], res["0"][0]["params"], 1e-5, "overlapped vs single all-reduce")
     for x, y in zip(res["0"][0]["losses"], res["1"][0]["losses"]):
         assert abs(x - y) < 1e-5
+    ref = _dp_reference(dev)
+    for overlap in ("0", "1"):
+        for rank in range(2):
+            for step, ((got, ranges), (want, want_ranges)) in enumerate(zip(res[overlap][rank]["reduced"], ref)):
+                assert ranges == want_ranges, (overlap, rank, step, ranges, want_ranges)
+                for lo, hi in ranges:
+                    assert_close(got[lo:hi], want[lo:hi], 1e-5,
+                                 f"all-reduced gradient vs mean of the shard gradients (overlap {overlap}, rank {rank}, "
+                                 f"{'AV' if step == 0 else 'AO'} step, range {lo}:{hi})")
 
 
 @pytest.mark.parametrize("ftype,att,loss,binary,weighted,log_freq", [

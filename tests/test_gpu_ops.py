@@ -640,3 +640,33 @@ def test_channels_last_stem_tail(dev, N, C, H, W):
     assert_close(dy, yr.grad, 2e-5, "gradient wrt the conv output (through batch statistics)")
     assert_close(dgamma, bn.weight.grad, 2e-5, "dgamma")
     assert_close(dbeta, bn.bias.grad, 2e-5, "dbeta")
+
+
+@pytest.mark.parametrize("att", ["sig", "cos"])
+@pytest.mark.parametrize("B,S,K,H,W", [(3, 2, 32, 14, 28), (2, 3, 8, 5, 7), (1, 4, 128, 20, 40)])
+def test_attmodel_core_kernel(dev, att, B, S, K, H, W):
+    """csrc/attention.hip (SoP++/attention_net.py:24-58: similarity maps, match term, clamp, context vectors) against the
+    same formula in float64 torch with autograd: values and the gradients wrt the audio queries and the visual map,
+    with cotangents on all three outputs.  The cos maps are scaled into (-1.5, 1.5) by the test so that the clamp's
+    inactive branch is exercised too."""
+    from avsep_amd.models.attention_net import _AttInferFn, _ATT
+    g = torch.Generator().manual_seed(B * 100 + K)
+    a = torch.randn(B, S, K, generator=g) * (1.0 if att == "sig" else 1.0)
+    mix = torch.randn(B, K, H, W, generator=g)
+    a64, m64 = a.double().requires_grad_(True), mix.double().requires_grad_(True)
+    a5, v5 = a64[..., None, None], m64[:, None]
+    if att == "cos":
+        maps = F.cosine_similarity(a5, v5, dim=2)
+    else:
+        maps = torch.sigmoid(torch.sum(a5 * v5 / K ** 0.5, dim=2))
+    match = -maps.mean(dim=(-2, -1)).sum(-1)
+    mc = maps.clamp(0, 1)
+    ctx = (m64[:, None] * mc[:, :, None]).mean(dim=(-2, -1))
+    c_ctx, c_maps, c_match = (torch.randn(t.shape, generator=g) for t in (ctx, mc, match))
+    ((ctx * c_ctx.double()).sum() + (mc * c_maps.double()).sum() + (match * c_match.double()).sum()).backward()
+    ad, md = a.to(dev).requires_grad_(True), mix.to(dev).requires_grad_(True)
+    ctx_d, maps_d, match_d = _AttInferFn.apply(ad, md, _ATT[att])
+    ((ctx_d * c_ctx.to(dev)).sum() + (maps_d * c_maps.to(dev)).sum() + (match_d * c_match.to(dev)).sum()).backward()
+    assert_close(ctx_d, ctx, 2e-5, "ctx"); assert_close(maps_d, mc, 2e-5, "maps"); assert_close(match_d, match, 2e-5, "match")
+    assert_close(ad.grad, a64.grad, 5e-5, "d queries")
+    assert_close(md.grad, m64.grad, 5e-5, "d visual map")

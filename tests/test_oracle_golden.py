@@ -61,6 +61,49 @@ def test_fusion(golden):
     assert torch.equal(O.ao_swap(G["ao.x"], torch.zeros(4, dtype=torch.bool)), G["ao.y_allzero"])
 
 
+def test_n_source_generalisation_reduces_to_the_reference(golden):
+    """BASELINE.json configs[4] (3 sources) is beyond the reference (C = 2 is hard-coded, fusion_net.py:35,43-46); the
+    build-defined generalisation (oracle Fusion._coloc_n / ao_permute_n / per-target PIT weights) must BE the reference's
+    CoLoc when C = 2: checked against the reference-generated goldens, values and gradients."""
+    G = golden("fusion")
+    for att in ("cos", "sig"):
+        tag = f"hidsep.{att}"
+        x = G[f"{tag}.x"].clone().requires_grad_(True)
+        vs = [G[f"{tag}.v{i}"].clone().requires_grad_(True) for i in range(2)]
+        y, (ml, maps) = O.Fusion("hidsep", att)._coloc_n(x, vs)
+        ((y * G[f"{tag}.cot"]).sum() + 0.7 * ml.sum() + 0.01 * (maps ** 2).sum()).backward()
+        assert_close(y, G[f"{tag}.y"], 2e-5, tag)
+        assert_close(ml.reshape(-1), G[f"{tag}.match"], 2e-5, tag)
+        assert_close(maps, G[f"{tag}.maps"], 2e-5, tag)
+        assert_close(x.grad, G[f"{tag}.dx"], 2e-5, tag)
+        for i in range(2):
+            assert_close(vs[i].grad, G[f"{tag}.dv{i}"], 2e-5, tag)
+    # three sources: shapes, the remainder rule (D = 32 -> Dc = 10, channels 30..31 of the tile are zero) and the
+    # defining properties: the winning permutation's score is the largest, a permutation of the visual inputs permutes
+    # the attended vectors and leaves the match loss unchanged
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 32, 2, 2, generator=gen)
+    vs = [torch.rand(4, 10, 3, 5, generator=gen) for _ in range(3)]
+    fu = O.Fusion("hidsep", "sig")
+    y, (ml, maps) = fu(x, vs)
+    assert y.shape == (4, 64, 2, 2) and maps.shape == (4, 3, 3, 5)
+    assert torch.equal(y[:, 30:32], torch.zeros(4, 2, 2, 2)) and torch.equal(y[:, 32:], x)
+    y2, (ml2, maps2) = fu(x, [vs[2], vs[0], vs[1]])
+    assert_close(ml2.reshape(1), ml.reshape(1), 1e-6)
+    assert_close(y2[:, 0:10], y[:, 20:30], 1e-6); assert_close(y2[:, 10:20], y[:, 0:10], 1e-6)
+    fu.num_src = 3
+    draws = torch.tensor([0, 3, 5, 1])
+    ya = O.ao_permute_n(x, draws, 3)
+    g = torch.amax(x, dim=(2, 3))
+    import itertools
+    table = list(itertools.permutations(range(3)))
+    for b in range(4):
+        for c in range(3):
+            blk = table[int(draws[b])][c]
+            assert torch.equal(ya[b, 10 * c:10 * c + 10, 0, 0], g[b, 10 * blk:10 * blk + 10])
+    assert torch.equal(ya[:, 30:32], torch.zeros(4, 2, 2, 2))
+
+
 def test_unet(golden):
     G = golden("unet")
     for tag, downs, ngf, ftype, att in [("u5", 5, 8, "hidsep", "sig"), ("u6sel", 6, 4, "CoLoc_Sel", "sig")]:
