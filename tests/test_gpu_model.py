@@ -357,7 +357,8 @@ def test_sopp_three_stage_schedule_vs_oracle(dev):
         oopt.step()
         assert abs(err - oerr.mean().item()) < 3e-4 * max(1.0, abs(err)), (i, err, oerr.mean().item())
         if use_vis:
-            assert abs(match - oouts["match_loss"].mean().item()) < 3e-4
+            om = oouts.get("match_loss")                     # stage 1 has no matching term
+            assert abs(match - (0.0 if om is None else om.mean().item())) < 3e-4
     osd = osnd.state_dict()
     for k, v in snd.state_dict().items():
         if v.dtype.is_floating_point and "running" not in k:
@@ -702,6 +703,32 @@ def test_checkpoint_resume_on_gpu(dev, tmp_path):
     for (k, p), (_, q) in zip(snd.named_parameters(), snd2.named_parameters()):
         # atomics-order noise only (a dropped momentum buffer shows as ~1e-1); BN biases here are ~1e-9 (pure noise)
         assert (q - p).abs().max().item() <= 1e-4 * max(p.abs().max().item(), 1e-3), k
+
+
+def test_loader_workers_after_gpu_init(dev, tmp_path):
+    """DataLoader WORKERS (fork()ed children) after this process has initialised HIP and launched kernels: the collate
+    runs GPU-free in the children (no pin_memory / hipHostMalloc on an inherited HIP runtime), the parent's pin thread
+    pins the batches, and they are identical to the workers=0 batches (train.py's default path is --workers 32)."""
+    P = _pkg()
+    from test_dataset import _make_disk_dataset
+    from avsep_amd import dataset as PD
+    x = torch.ones(8, device=dev)
+    P.kernels.channel_stats(torch.rand(2, 4, 8, 8, device=dev), P.kernels.zeros_stats(4, x))   # HIP is live in this process
+    torch.cuda.synchronize()
+    lst = _make_disk_dataset(str(tmp_path))
+    a = P.ArgParser().parse_train_arguments(
+        ["--num_frames", "2", "--stride_frames", "2", "--imgSize", "64", "--audLen", "16383", "--margin", "1.0",
+         "--train_repeat", "1"], verbose=False)
+    got = {}
+    for workers in (0, 2):
+        loader = PD.make_loader([lst], a, "val", batch_size=2, shuffle=False, workers=workers)
+        got[workers] = [b for _, b in zip(range(3), loader)]
+    for b0, b2 in zip(got[0], got[2]):
+        assert b2["audio_mix"].is_pinned() and b2["frames"][0].is_pinned()
+        assert torch.equal(b0["audio_mix"], b2["audio_mix"]) and torch.equal(b0["frames"][1], b2["frames"][1])
+        assert b0["id"] == b2["id"]
+        dev_b = PD.to_device(b2, dev)
+        assert torch.equal(dev_b["audios"][0].cpu(), b0["audios"][0])
 
 
 def test_loader_to_gpu_step(dev, tmp_path):
