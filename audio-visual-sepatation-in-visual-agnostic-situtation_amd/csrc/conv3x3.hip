@@ -528,7 +528,8 @@ __global__ void w3_reduce_kernel(const float* __restrict__ ws, float* __restrict
   float s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
-  for (int z = 0; z < S; ++z)
+#pragma unroll 4
+  for (int z = 0; z < S; ++z)       // 4 slabs x 9 planes of independent loads in flight per thread
 #pragma unroll
     for (int t = 0; t < 9; ++t) s[t] += ws[((long long)z * 9 + t) * P + cc];
 #pragma unroll

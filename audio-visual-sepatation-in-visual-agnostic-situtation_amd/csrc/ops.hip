@@ -972,6 +972,88 @@ extern "C" int avsep_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int32
   return AVSEP_OK;
 }
 
+// ---- stem tail backward, fused: MaxPool(3,2,1) backward + ReLU mask + BatchNorm backward of the stem conv output -----
+// (vision_net.py:111-117 children 1-3 behind conv1).  g = dL/d(pooled) [N,C,Ho,Wo], idx = arg-max positions of the
+// forward, y = RAW conv output [N,C,H,W], pre = scale*y + shift.  dz[pos] = [pre > 0] * sum of g over the windows that
+// chose pos.  The separate kernels wrote dz (616 MB at 192 frames), re-read it for the ReLU mask + statistics and again
+// for dy = p*dz + q*y + r: 1.8 ms per call; fused: the statistics are taken over the POOLED grid (linear in g), the
+// apply pass writes dy directly: one read of y, one write of dy.
+// pass 1: bstats[c] += sum dz, bstats[C+c] += sum dz * xhat   (grid: C x N, one plane per block)
+__global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_stats_kernel(const float* __restrict__ g, const int* __restrict__ idx,
+                                                                        const float* __restrict__ y, const float* __restrict__ scale,
+                                                                        const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                        const float* __restrict__ invstd, int C, int HW, int HoWo,
+                                                                        double* __restrict__ bstats) {
+  const int c = blockIdx.x, n = blockIdx.y;
+  const long long plane = (long long)n * C + c;
+  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+  const float* gp = g + plane * HoWo;
+  const int* ip = idx + plane * HoWo;
+  const float* yp = y + plane * HW;
+  float s1 = 0.f, s2 = 0.f;
+  for (int o = threadIdx.x; o < HoWo; o += 256) {
+    const float yv = yp[ip[o]];
+    if (fmaf(yv, sc, sh) > 0.f) {
+      const float gv = gp[o];
+      s1 += gv;
+      s2 = fmaf(gv, (yv - mu) * is, s2);
+    }
+  }
+  double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+  __shared__ double sh_[8];
+  if ((threadIdx.x & 63) == 0) { sh_[threadIdx.x >> 6] = d1; sh_[4 + (threadIdx.x >> 6)] = d2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&bstats[c], sh_[0] + sh_[1] + sh_[2] + sh_[3]);
+    atomicAdd(&bstats[C + c], sh_[4] + sh_[5] + sh_[6] + sh_[7]);
+  }
+}
+// pass 2: dy[i] = p * ([pre > 0] * sum_{windows that chose i} g) + q * y[i] + r
+__global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_apply_kernel(const float* __restrict__ g, const int* __restrict__ idx,
+                                                                        const float* __restrict__ y, const float* __restrict__ scale,
+                                                                        const float* __restrict__ shift, const float* __restrict__ pqr,
+                                                                        int C, int NC, int H, int W, int Ho, int Wo,
+                                                                        float* __restrict__ dy) {
+  const long long total = (long long)NC * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int w = (int)(i % W), h = (int)((i / W) % H);
+    const long long nc = i / ((long long)W * H);
+    const int c = (int)(nc % C), self = h * W + w;
+    const float yv = y[i];
+    float s = 0.f;
+    if (fmaf(yv, scale[c], shift[c]) > 0.f) {
+      for (int ho = h / 2; ho <= (h + 1) / 2 && ho < Ho; ++ho)
+        for (int wo = w / 2; wo <= (w + 1) / 2 && wo < Wo; ++wo) {
+          const long long o = (nc * Ho + ho) * Wo + wo;
+          if (idx[o] == self) s += g[o];
+        }
+    }
+    dy[i] = fmaf(pqr[c], s, fmaf(pqr[C + c], yv, pqr[2 * C + c]));
+  }
+}
+extern "C" int avsep_maxpool_bn_relu_bwd_stats(const float* g, const int32_t* idx, const float* y, const float* scale,
+                                               const float* shift, const float* mean, const float* invstd, int32_t N, int32_t C,
+                                               int32_t H, int32_t W, double* bstats, avsep_stream_t stream) {
+  if (!g || !idx || !y || !scale || !shift || !mean || !invstd || !bstats) return AVSEP_ERR_ARG;
+  if (N <= 0 || N > 65535 || C <= 0 || H <= 0 || W <= 0) return AVSEP_ERR_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bn_relu_bwd_stats_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, g, idx, y, scale, shift,
+                     mean, invstd, C, H * W, Ho * Wo, bstats);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+extern "C" int avsep_maxpool_bn_relu_bwd_apply(const float* g, const int32_t* idx, const float* y, const float* scale,
+                                               const float* shift, const float* pqr, int32_t N, int32_t C, int32_t H, int32_t W,
+                                               float* dy, avsep_stream_t stream) {
+  if (!g || !idx || !y || !scale || !shift || !pqr || !dy || N <= 0 || C <= 0 || H <= 0 || W <= 0) return AVSEP_ERR_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * C * H * W;
+  hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply_kernel, dim3((int)min((total + 255) / 256, (long long)262144)), dim3(256), 0,
+                     (hipStream_t)stream, g, idx, y, scale, shift, pqr, C, N * C, H, W, Ho, Wo, dy);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
 __global__ __launch_bounds__(256) void temporal_mean_fwd_kernel(const float* __restrict__ x, int B, int T, long long CHW,
                                                                 float* __restrict__ y) {
   const long long total = (long long)B * CHW;

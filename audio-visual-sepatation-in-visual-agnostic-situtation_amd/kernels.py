@@ -330,6 +330,21 @@ def maxpool3x3s2_bwd(dy, idx, H, W):
     return dx
 
 
+def maxpool_bn_relu_bwd_stats(g, idx, y, bnrow, bstats):
+    """BatchNorm-backward sums of the stem tail taken over the pooled grid (see avsep.h); bstats is accumulated into."""
+    N, Cc, H, W = y.shape
+    call("avsep_maxpool_bn_relu_bwd_stats", ptr(g), ptr(idx), ptr(y), ptr(bnrow[0]), ptr(bnrow[1]), ptr(bnrow[2]), ptr(bnrow[3]),
+         N, Cc, H, W, ptr(bstats))
+
+
+def maxpool_bn_relu_bwd_apply(g, idx, y, bnrow, pqr):
+    """dL/d(raw stem conv output) from dL/d(pooled): max-pool backward + ReLU mask + folded BatchNorm backward in one pass."""
+    N, Cc, H, W = y.shape
+    dy = torch.empty_like(y)
+    call("avsep_maxpool_bn_relu_bwd_apply", ptr(g), ptr(idx), ptr(y), ptr(bnrow[0]), ptr(bnrow[1]), ptr(pqr), N, Cc, H, W, ptr(dy))
+    return dy
+
+
 class Stft:
     """librosa-style STFT/iSTFT plan (bases built once on the device)."""
 

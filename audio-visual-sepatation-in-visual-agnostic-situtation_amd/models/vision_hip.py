@@ -137,11 +137,13 @@ def block_backward(R, g, grads):
 
 
 def stem_backward(f, S, g, grads):
-    y0 = S["y0"]
-    g = K.maxpool3x3s2_bwd(g, S["idx"], y0.shape[2], y0.shape[3])
-    pqr0 = _relu_bn_back(grads, g, y0, S["bn0"], f[1])
-    K.bn_bwd_apply_(g, y0, pqr0)
-    _acc(grads, f[0].weight, S["cv0"].wgrad(g)[0])                  # the frames need no gradient
+    y0, bn0 = S["y0"], S["bn0"]
+    g = g.contiguous()
+    bst = K.zeros_stats(y0.shape[1], y0)
+    K.maxpool_bn_relu_bwd_stats(g, S["idx"], y0, bn0, bst)          # sums over the pooled grid: dz is never written
+    pqr0 = _bn_back(grads, f[1], bn0, bst, y0.numel() // y0.shape[1])
+    dy0 = K.maxpool_bn_relu_bwd_apply(g, S["idx"], y0, bn0, pqr0)   # pool backward + ReLU mask + BatchNorm backward
+    _acc(grads, f[0].weight, S["cv0"].wgrad(dy0)[0])                # the frames need no gradient
 
 
 def trunk_backward(net, S, dout, grads):

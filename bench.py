@@ -126,10 +126,10 @@ class KernelTimer:
         return out
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, prec="f32"):
     """PMC-measured HBM traffic of one kernel family, from the committed summary of the rocprofv3 --pmc passes
     (counters cannot be read from inside the process; the summary is regenerated by profiles/summarise_pmc.py)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if prec == "f32" else "pmc_traffic_%s.json" % prec)
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -241,6 +241,15 @@ def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer
     return res
 
 
+def add_traffic(roof, prec, B):
+    traffic = pmc_traffic(roof["kernel"], prec)
+    if traffic and traffic["traffic_bytes_per_step"]:
+        scale = B / float(traffic["batch"] or B)                   # PMC passes may run at another batch: bytes scale with it
+        roof["traffic"] = traffic["traffic_bytes_per_step"] * scale / roof["launches_per_step"]
+        roof["traffic_source"] = traffic["source"]
+    return roof
+
+
 def roofline_of(kernels, prec, step_ms, B_total_per_gpu):
     """dominant MFMA kernel + whole-step fraction + the HBM-bound families, from a KernelTimer summary."""
     mfma = {k: v for k, v in kernels.items() if v["gflop_per_step"] > 0 and not k.startswith(("head_", "smallc"))}
@@ -294,6 +303,7 @@ def main():
         r = run_config(P, dev, world, seed, rank, other, "hip", B, o.steps, o.warmup, timer)
         k2 = timer.summary(o.steps)
         roof2, step2, _ = roofline_of(k2, other, r["ms_per_step"], B)
+        add_traffic(roof2, other, B)
         r.update({"dtype": other, "roofline": roof2, "roofline_step": step2,
                   "first_step_loss_abs_diff_vs_headline": abs(r["first_step_loss"] - head["first_step_loss"]),
                   "workload": "same step, conv operands rounded to bf16 while staged, fp32 accumulate / BatchNorm statistics / "
@@ -309,11 +319,7 @@ def main():
 
     if rank == 0:
         roof, roof_step, hbm = roofline_of(kernels, o.precision, head["ms_per_step"], B)
-        traffic = pmc_traffic(roof["kernel"])
-        if traffic and traffic["traffic_bytes_per_step"]:
-            scale = B / float(traffic["batch"] or B)               # PMC passes may run at another batch: bytes scale with it
-            roof["traffic"] = traffic["traffic_bytes_per_step"] * scale / roof["launches_per_step"]
-            roof["traffic_source"] = traffic["source"]
+        add_traffic(roof, o.precision, B)
         vis = {"hip": "visual trunk on this library (no MIOpen kernel in the step)",
                "hybrid": "visual convolutions on PyTorch-ROCm/MIOpen with HIP BatchNorm/ReLU glue",
                "torch": "visual trunk on PyTorch-ROCm"}[o.backend]

@@ -312,6 +312,16 @@ int avsep_maxpool3x3s2_fwd(const float* x, const float* scale, const float* shif
                            int32_t NC, int32_t H, int32_t W, float* y, int32_t* idx, avsep_stream_t stream);
 int avsep_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int32_t NC, int32_t H, int32_t W,
                            float* dx, avsep_stream_t stream);
+/* Stem tail backward, fused (vision_net.py:111-117: conv1 -> bn1 -> relu -> maxpool): from g = dL/d(pooled), the forward's
+ * arg-max positions idx and the RAW conv output y with its BatchNorm rows (scale, shift, mean, invstd):
+ *   _stats: bstats[2*C] (pre-zeroed) += (sum dz, sum dz*xhat), dz = relu'(scale*y+shift) * maxpool_backward(g);
+ *   avsep_bn_bwd_coeffs turns them into (p,q,r);  _apply: dy = p*dz + q*y + r.  dz is never materialised. */
+int avsep_maxpool_bn_relu_bwd_stats(const float* g, const int32_t* idx, const float* y, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, int32_t N, int32_t C,
+                                    int32_t H, int32_t W, double* bstats, avsep_stream_t stream);
+int avsep_maxpool_bn_relu_bwd_apply(const float* g, const int32_t* idx, const float* y, const float* scale,
+                                    const float* shift, const float* pqr, int32_t N, int32_t C, int32_t H, int32_t W,
+                                    float* dy, avsep_stream_t stream);
 /* y[b,c,hw] = mean_t x[b*T+t,c,hw]  (vision_net.py:134-135) and its transpose. */
 int avsep_temporal_mean_fwd(const float* x, int32_t B, int32_t T, int32_t CHW, float* y,
                             avsep_stream_t stream);

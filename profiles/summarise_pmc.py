@@ -2,7 +2,8 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
-    python profiles/summarise_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write "<the bench command>" <steps run>
+    python profiles/summarise_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write "<the bench command>" <steps run> \
+        [<batch per GPU> [<output json, default profiles/pmc_traffic.json>]]
 
 Both counters are in KiB.  Correction applied (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE tallies the
 128-byte read requests at 64 bytes, so reads = 2 * FETCH_SIZE; WRITE_SIZE is exact.  The calibration rows of the
@@ -26,8 +27,9 @@ def per_kernel(directory):
 
 
 def family(name):
-    for key in ("conv3x3_kernel", "wgrad3x3_kernel", "smallco_fwd", "smallco_wgrad", "smallci_dgrad", "relu_up2x_fwd",
-                "relu_up2x_bwd", "bn_bwd_apply_kernel", "affine_act_bwd_kernel", "sgd_kernel"):
+    for key in ("convbf_kernel", "wgradbf_kernel", "conv3x3_kernel", "wgrad3x3_kernel", "head_fwd_kernel", "head_wgrad_kernel",
+                "head_dgrad_kernel", "smallco_fwd", "smallco_wgrad", "smallci_dgrad", "relu_up2x_fwd",
+                "relu_up2x_bwd", "bn_bwd_apply_kernel", "affine_act_bwd_kernel", "sgd_kernel", "w3_reduce_kernel"):
         if key in name:
             return key
     if "igemm_kernel<" in name:
@@ -48,6 +50,7 @@ def main():
             fams[k][2] += len(vals); fams[k][3] += sum(vals)
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # train steps in each pass (warm-up + timed)
     out = {"command": sys.argv[3] if len(sys.argv) > 3 else "", "steps_per_pass": steps,
+           "batch": int(sys.argv[5]) if len(sys.argv) > 5 else None,
            "unit": "bytes per kernel launch (average over the family's launches); *_per_step = family total / steps",
            "correction": "reads = 2 * FETCH_SIZE KiB (gfx950), writes = WRITE_SIZE KiB", "kernels": {}}
     for k, (nf, sf, nw, sw) in sorted(fams.items()):
@@ -58,10 +61,12 @@ def main():
                              "write_size_kib": sw / nw, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                              "traffic_bytes_per_launch": rd + wr,
                              "traffic_bytes_per_step": (rd + wr) * nf / steps if steps else None}
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
+    dst = sys.argv[6] if len(sys.argv) > 6 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps(out["kernels"].get("conv3x3_kernel"), indent=1))
+    for k in ("conv3x3_kernel", "convbf_kernel", "wgradbf_kernel"):
+        if k in out["kernels"]:
+            print(k, json.dumps(out["kernels"][k]))
 
 
 if __name__ == "__main__":
