@@ -569,6 +569,10 @@ int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
 bool wb_applicable(const avsep_conv_desc* d);
 size_t wb_workspace_floats(const avsep_conv_desc* d);
 int wb_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
+// wgrad4_bf16.hip
+bool w4b_applicable(const avsep_conv_desc* d);
+size_t w4b_workspace_floats(const avsep_conv_desc* d);
+int w4b_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 static int check_desc(const avsep_conv_desc* d, bool fwd_only = false) {
   if (!d || !d->x0) return AVSEP_ERR_ARG;
@@ -818,6 +822,7 @@ extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (smallco_applicable(d)) return smallco_wgrad_workspace_floats(d) * sizeof(float);
   if (head_applicable(d)) return head_wgrad_workspace_floats(d) * sizeof(float);
   if (wb_applicable(d)) return wb_workspace_floats(d) * sizeof(float);
+  if (w4b_applicable(d)) return w4b_workspace_floats(d) * sizeof(float);
   if (w3_applicable(d)) return w3_workspace_floats(d) * sizeof(float);
   WgradPlan p = wgrad_plan(d);
   if (p.splits <= 1) return 0;
@@ -834,9 +839,10 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   if (need > workspace_bytes || (need && !workspace)) return AVSEP_ERR_WORKSPACE;
   if (smallco_applicable(d)) return smallco_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
   if (head_applicable(d)) return head_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
-  if (wb_applicable(d) || w3_applicable(d)) {
+  if (wb_applicable(d) || w4b_applicable(d) || w3_applicable(d)) {
     int rc3 = wb_applicable(d) ? wb_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
-                               : w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
+              : w4b_applicable(d) ? w4b_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
+                                  : w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
     if (rc3) return rc3;
     if (dbias) {
       hipLaunchKernelGGL(channel_sum_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, dy, d->N, d->Cout,
@@ -894,6 +900,7 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
   if (smallco_applicable(d)) return "smallco_wgrad";
   if (head_applicable(d)) return "head_wgrad_kernel";
   if (wb_applicable(d)) return "wgradbf_kernel";
+  if (w4b_applicable(d)) return "wgrad4bf_kernel";
   if (w3_applicable(d)) return "wgrad3x3_kernel";
   return "igemm_kernel<wgrad>";
 }

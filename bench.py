@@ -256,7 +256,7 @@ def roofline_of(kernels, prec, step_ms, B_total_per_gpu):
     dom = max(mfma, key=lambda k: mfma[k]["ms_per_step"])
     d = mfma[dom]
     # a kernel family computes in bf16 only if it is one of the bf16 kernels; the rest of a bf16 step is exact f32
-    peak = PEAK_TFLOPS["bf16"] if dom in ("convbf_kernel", "wgradbf_kernel") else PEAK_TFLOPS["f32"]
+    peak = PEAK_TFLOPS["bf16"] if dom in ("convbf_kernel", "wgradbf_kernel", "wgrad4bf_kernel") else PEAK_TFLOPS["f32"]
     tot_fl = sum(v["gflop_per_step"] for v in kernels.values())
     tot_ms = sum(v["ms_per_step"] for k, v in kernels.items() if v["gflop_per_step"] > 0)
     roof = {"bound": "mfma", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak,

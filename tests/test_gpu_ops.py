@@ -113,6 +113,9 @@ BF16_CASES = [
     (4, 512, 4, 4, 160, 3, 1, 1, 1, 1),      # flat 4x4, K = 4608: split-K slabs + combine (bias, stats) / slab reduce
     (6, 256, 8, 8, 144, 3, 1, 1, 1, 0),      # flat 8x8, two K splits
     (4, 32, 16, 16, 48, 4, 2, 1, 1, 2),      # 4x4 / stride 2 with 8-wide outputs (U-Net d5)
+    (3, 64, 24, 64, 160, 4, 2, 1, 1, 2),     # 4x4 / stride 2 weight gradient: 2x32 output tiles, ragged rows, two M tiles
+    (5, 32, 32, 32, 48, 4, 2, 1, 1, 1),      # same, 4x16 output tiles (16-wide outputs)
+    (2, 48, 20, 72, 40, 4, 2, 1, 1, 0),      # same, ragged channel blocks (48 = 32 + 16) and columns (Wo = 36)
 ]
 
 
@@ -161,7 +164,8 @@ def test_conv_bf16_operands(dev, case):
     dw, db = cv.wgrad(t(dy), want_bias=True)
     from conftest import rel_err
     e_bf, e_32 = rel_err(dw, dw_ref), rel_err(dw, torch.autograd.grad(y32, w32, dy)[0])
-    has_bf16_wgrad = k == 3 and s == 1 and Cin >= 32 and Cout >= 32 and W >= 4 and W % 2 == 0
+    has_bf16_wgrad = (k == 3 and s == 1 and Cin >= 32 and Cout >= 32 and W >= 4 and W % 2 == 0) or \
+        (k == 4 and s == 2 and Cin >= 32 and Cout >= 32 and W >= 32 and W % 8 == 0)
     assert (e_bf if has_bf16_wgrad else e_32) <= 2e-5, (has_bf16_wgrad, e_bf, e_32)
     assert_close(db, dy.sum((0, 2, 3)), 2e-5, "dbias")
 
