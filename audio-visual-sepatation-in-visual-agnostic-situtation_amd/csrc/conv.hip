@@ -556,6 +556,12 @@ size_t c4_packed_floats(const avsep_conv_desc* d, int mode);
 int c4_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
 int c4_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st);
 int c4_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
+// conv_misc.hip: 3x3/s2 and 1x1 convolutions of the visual trunk on the halo-patch kernel (fp32)
+bool cm_applicable(const avsep_conv_desc* d, int mode);
+size_t cm_packed_floats(const avsep_conv_desc* d, int mode);
+int cm_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
+int cm_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st);
+int cm_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
 size_t w3_workspace_floats(const avsep_conv_desc* d);
 // conv_bf16.hip: bf16-operand halo-patch kernels (desc.prec == AVSEP_PREC_BF16)
 bool bf_applicable(const avsep_conv_desc* d, int mode);
@@ -617,6 +623,7 @@ extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
   if (bf_applicable(d, mode)) return bf_packed_floats(d, mode);
   if (c3_applicable(d, mode)) return c3_packed_floats(d, mode);
   if (c4_applicable(d, mode)) return c4_packed_floats(d, mode);
+  if (cm_applicable(d, mode)) return cm_packed_floats(d, mode);
   return (size_t)packed_rows(d, mode) * packed_ld(d, mode);
 }
 
@@ -632,6 +639,7 @@ extern "C" int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w,
   if (bf_applicable(d, mode)) return bf_pack(d, w, packed, mode, (hipStream_t)stream);
   if (c3_applicable(d, mode)) return c3_pack(d, w, packed, mode, (hipStream_t)stream);
   if (c4_applicable(d, mode)) return c4_pack(d, w, packed, mode, (hipStream_t)stream);
+  if (cm_applicable(d, mode)) return cm_pack(d, w, packed, mode, (hipStream_t)stream);
   int rows = packed_rows(d, mode), ld = packed_ld(d, mode);
   long long total = (long long)rows * ld;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed,
@@ -662,7 +670,7 @@ static SplitPlan splitk_plan(long long tiles, int K) {
 }
 static bool fwd_uses_igemm(const avsep_conv_desc* d, const double* stats) {
   return !((!stats && (smallco_applicable(d) || head_applicable(d))) || bf_applicable(d, 0) || c3_applicable(d, 0) ||
-           c4_applicable(d, 0));
+           c4_applicable(d, 0) || cm_applicable(d, 0));
 }
 static SplitPlan fwd_split(const avsep_conv_desc* d) {
   long long ncols = (long long)d->N * d->Ho * d->Wo;
@@ -703,7 +711,9 @@ extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
 }
 extern "C" size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (!check_desc(d) && !smallci_applicable(d) && bf_applicable(d, 1)) return bf_workspace_bytes(d, 1);
-  if (check_desc(d) || bf_applicable(d, 1) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1)) return 0;
+  if (check_desc(d) || bf_applicable(d, 1) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1) ||
+      cm_applicable(d, 1))
+    return 0;
   SplitPlan p = dgrad_split(d);
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cin * d->H * d->W * sizeof(float) : 0;
 }
@@ -718,6 +728,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   if (bf_applicable(d, 0)) return bf_fwd(d, w_packed, bias, y, stats, workspace, workspace_bytes, (hipStream_t)stream);
   if (c3_applicable(d, 0)) return c3_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (c4_applicable(d, 0)) return c4_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
+  if (cm_applicable(d, 0)) return cm_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.wp = w_packed; a.wp_ld = packed_ld(d, 0); a.out = y; a.bias = bias; a.stats = stats;
   a.M = d->Cout; a.K = d->Cin * d->KH * d->KW;
@@ -761,6 +772,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   if (bf_applicable(d, 1)) return bf_dgrad(d, w_packed_dgrad, dy, dx, workspace, workspace_bytes, (hipStream_t)stream);
   if (c3_applicable(d, 1)) return c3_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c4_applicable(d, 1)) return c4_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
+  if (cm_applicable(d, 1)) return cm_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   CArgs a = make_args(d);
   a.wp = w_packed_dgrad; a.wp_ld = packed_ld(d, 1); a.dy = dy; a.out = dx;
   a.M = d->Cin;
@@ -887,14 +899,14 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
     if (!with_stats && smallco_applicable(d)) return "smallco_fwd";
     if (!with_stats && head_applicable(d)) return "head_fwd_kernel";
     if (bf_applicable(d, 0)) return "convbf_kernel";
-    if (c3_applicable(d, 0) || c4_applicable(d, 0)) return "conv3x3_kernel";
+    if (c3_applicable(d, 0) || c4_applicable(d, 0) || cm_applicable(d, 0)) return "conv3x3_kernel";
     return "igemm_kernel<fwd>";
   }
   if (mode == 1) {
     if (head_applicable(d)) return "head_dgrad_kernel";
     if (smallci_applicable(d)) return "smallci_dgrad";
     if (bf_applicable(d, 1)) return "convbf_kernel";
-    if (c3_applicable(d, 1) || c4_applicable(d, 1)) return "conv3x3_kernel";
+    if (c3_applicable(d, 1) || c4_applicable(d, 1) || cm_applicable(d, 1)) return "conv3x3_kernel";
     return "igemm_kernel<dgrad>";
   }
   if (smallco_applicable(d)) return "smallco_wgrad";

@@ -16,19 +16,29 @@
 // mode 1: dgrad    M = Cin,  k-channel = co, value w[c][m][flip(tap)]           (KH x KW taps, stride 1)
 // mode 2: dgrad of a 4x4/s2 conv, 4 parity classes x 2x2 taps: class cls at image offset cls * (Kc/16)*4*ld rows;
 //         tap (th, tw) of class (ph, pw) -> (kh, kw) = (ph ? 2-2*th : 3-2*th, pw ? 2-2*tw : 3-2*tw)
+// mode 3: dgrad of a 3x3/s2/p1 conv: class (ph, pw) has (ph ? 2 : 1) x (pw ? 2 : 1) taps (1, 2, 2, 4 = 9 in all, the
+//         class images follow each other); tap th -> kh = ph ? 2-2*th : 1 reads dY row a + th for input row 2a + ph
 __global__ void bf_pack_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cout, int Cin, int KH, int KW,
                                int ld, int ktiles, int mode) {
-  const int NT = mode == 2 ? 4 : KH * KW;
-  const long long rows = (long long)(mode == 2 ? 4 : 1) * ktiles * NT * ld;      // 32-byte rows
+  int NT = mode == 2 ? 4 : KH * KW;
+  const long long rows = (long long)(mode == 2 ? 4 : 1) * ktiles * NT * ld;      // 32-byte rows (mode 3: 9 taps in all)
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (row, stored half)
   if (i >= rows * 2) return;
-  const long long row = i >> 1;
+  long long row = i >> 1;
   const int hs = (int)(i & 1);
+  int cls = 0;
+  if (mode == 3) {                                                               // classes of 1, 2, 2, 4 taps
+    const long long unit = (long long)ktiles * ld;
+    if (row < unit) { cls = 0; NT = 1; }
+    else if (row < 3 * unit) { cls = 1; NT = 2; row -= unit; }
+    else if (row < 5 * unit) { cls = 2; NT = 2; row -= 3 * unit; }
+    else { cls = 3; NT = 4; row -= 5 * unit; }
+  }
   const int m = (int)(row % ld);
   long long q = row / ld;
   const int tap = (int)(q % NT); q /= NT;
   const int kt = (int)(q % ktiles);
-  const int cls = (int)(q / ktiles);
+  if (mode == 2) cls = (int)(q / ktiles);
   const int h = hs ^ ((m >> 3) & 1);                                             // logical half stored in slot hs
   const int KHW = KH * KW;
   float v[8];
@@ -40,10 +50,14 @@ __global__ void bf_pack_kernel(const float* __restrict__ w, unsigned* __restrict
       if (m < Cout && c < Cin) x = w[((long long)m * Cin + c) * KHW + tap];
     } else if (mode == 1) {
       if (m < Cin && c < Cout) x = w[((long long)c * Cin + m) * KHW + (KHW - 1 - tap)];
-    } else {
+    } else if (mode == 2) {
       const int ph = cls >> 1, pw = cls & 1, th = tap >> 1, tw = tap & 1;
       const int kh = ph ? 2 - 2 * th : 3 - 2 * th, kw = pw ? 2 - 2 * tw : 3 - 2 * tw;
       if (m < Cin && c < Cout) x = w[((long long)c * Cin + m) * 16 + kh * 4 + kw];
+    } else {
+      const int ph = cls >> 1, pw = cls & 1, ntw = pw ? 2 : 1, th = tap / ntw, tw = tap % ntw;
+      const int kh = ph ? 2 - 2 * th : 1, kw = pw ? 2 - 2 * tw : 1;
+      if (m < Cin && c < Cout) x = w[((long long)c * Cin + m) * 9 + kh * 3 + kw];
     }
     v[j] = x;
   }
@@ -58,6 +72,8 @@ static int bf_class(const avsep_conv_desc* d) {
   if (d->up2x || d->C0 != d->Cin) return 0;
   if (d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil) return 3;
   if (d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->dil == 1) return 4;
+  if (d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 && d->dil == 1) return 5;      // ResNet layer2.0 / layer3.0 conv1
+  if (d->KH == 1 && d->KW == 1 && (d->stride == 1 || d->stride == 2) && d->pad == 0) return 1;  // ResNet downsample convs
   return 0;
 }
 // flat-pixel tiles: the small square maps of the visual trunk (14x14, 7x7) and of the deep U-Net levels (8x8, 4x4)
@@ -102,6 +118,7 @@ bool bf_applicable(const avsep_conv_desc* d, int mode) {
   const long long in_elems = mode == 0 ? (long long)d->N * d->Cin * d->H * d->W : (long long)d->N * d->Cout * d->Ho * d->Wo;
   if (in_elems >= (1LL << 30) || d->N > 65535) return false;
   if (cls == 3) return bf_flat(d) || (d->W >= 16 && d->H >= 4);
+  if (cls == 1) return d->Wo >= 8 && d->Ho >= 4 && (d->stride == 1 || mode == 0 || ((d->H & 1) == 0 && (d->W & 1) == 0));
   if (mode == 0) return d->Wo >= 8 && d->Ho >= 4;               // 8-wide outputs (U-Net d5) use half of a 16-wide tile
   return d->Wo >= 8 && d->Ho >= 4 && (d->H & 1) == 0 && (d->W & 1) == 0;
 }
@@ -116,13 +133,13 @@ size_t bf_workspace_bytes(const avsep_conv_desc* d, int mode) {
 
 size_t bf_packed_floats(const avsep_conv_desc* d, int mode) {
   const int kc = mode == 0 ? d->Cin : d->Cout, ld = roundup(mode == 0 ? d->Cout : d->Cin, 128);
-  const int NT = (bf_class(d) == 4 && mode == 1) ? 16 : d->KH * d->KW;           // 4 classes x 4 taps
+  const int NT = (bf_class(d) == 4 && mode == 1) ? 16 : d->KH * d->KW;           // 4x4/s2 dgrad: 4 classes x 4 taps; 3x3/s2: 1+2+2+4
   return (size_t)(kc / BF_CK) * NT * ld * 8;                                      // 32-byte rows = 8 floats
 }
 
 int bf_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st) {
   const int kc = mode == 0 ? d->Cin : d->Cout, ld = roundup(mode == 0 ? d->Cout : d->Cin, 128);
-  const int pmode = (bf_class(d) == 4 && mode == 1) ? 2 : mode;
+  const int pmode = (mode == 1 && bf_class(d) == 4) ? 2 : (mode == 1 && bf_class(d) == 5) ? 3 : mode;
   const long long halves = (long long)bf_packed_floats(d, mode) / 4;
   hipLaunchKernelGGL(bf_pack_kernel, dim3(cdiv(halves, 256)), dim3(256), 0, st, w, reinterpret_cast<unsigned*>(packed),
                      d->Cout, d->Cin, d->KH, d->KW, ld, kc / BF_CK, pmode);
@@ -216,8 +233,12 @@ int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
     if (rc || splits == 1) return rc;
     return splitk_combine((const float*)ws, a.slab, splits, d, bias, y, stats, st);
   }
-  a.Ho = d->Ho; a.Wo = d->Wo; a.padh = a.padw = 1; a.os = 1; a.ooh = a.oow = 0; a.OHs = d->Ho; a.OWs = d->Wo;
-  return bf_launch_rect<4, 4, 2, 1>(a, st);
+  a.Ho = d->Ho; a.Wo = d->Wo; a.padh = a.padw = d->pad; a.os = 1; a.ooh = a.oow = 0; a.OHs = d->Ho; a.OWs = d->Wo;
+  switch (bf_class(d)) {
+    case 4: return bf_launch_rect<4, 4, 2, 1>(a, st);
+    case 5: return bf_launch_rect<3, 3, 2, 1>(a, st);
+    default: return d->stride == 1 ? bf_launch_rect<1, 1, 1, 1>(a, st) : bf_launch_rect<1, 1, 2, 1>(a, st);
+  }
 }
 
 int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -232,16 +253,38 @@ int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
     return reduce_slabs((const float*)ws, dx, a.slab, splits, st);
   }
   const int ld = roundup(d->Cin, 128);
-  const size_t cls_floats = (size_t)(d->Cout / BF_CK) * 4 * ld * 8;
+  const int bcls = bf_class(d);
+  if (bcls == 1) {            // 1x1: dX at the sampled positions = W^T dY; stride 2 leaves the other positions zero
+    C3Args a{};
+    a.N = d->N; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;
+    a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
+    a.x0 = dy; a.wp = wp; a.wp_ld = ld; a.out = dx;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.padh = a.padw = 0; a.os = d->stride; a.ooh = a.oow = 0; a.OHs = d->H; a.OWs = d->W;
+    if (d->stride == 2 && hipMemsetAsync(dx, 0, (size_t)d->N * d->Cin * d->H * d->W * sizeof(float), st) != hipSuccess)
+      return AVSEP_ERR_LAUNCH;
+    return bf_launch_rect<1, 1, 1, 1>(a, st);
+  }
+  const size_t unit_floats = (size_t)(d->Cout / BF_CK) * ld * 8;        // one tap of one class image
+  size_t off = 0;
   for (int cls = 0; cls < 4; ++cls) {
     const int ph = cls >> 1, pw = cls & 1;
     C3Args a{};
     a.N = d->N; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
-    a.x0 = dy; a.wp = wp + cls * cls_floats; a.wp_ld = ld; a.out = dx;
-    a.Ho = d->H / 2; a.Wo = d->W / 2; a.padh = ph ? 0 : 1; a.padw = pw ? 0 : 1;
+    a.x0 = dy; a.wp = wp + off; a.wp_ld = ld; a.out = dx;
+    a.Ho = d->H / 2; a.Wo = d->W / 2;
     a.os = 2; a.ooh = ph; a.oow = pw; a.OHs = d->H; a.OWs = d->W;
-    int rc = bf_launch_rect<2, 2, 1, 1>(a, st);
+    int rc;
+    if (bcls == 4) {          // 4x4/s2: every class is a 2x2-tap conv, pad 1 | 0 for parity 0 | 1
+      a.padh = ph ? 0 : 1; a.padw = pw ? 0 : 1;
+      rc = bf_launch_rect<2, 2, 1, 1>(a, st);
+      off += 4 * unit_floats;
+    } else {                  // 3x3/s2: (ph ? 2 : 1) x (pw ? 2 : 1) taps over dY rows a .. a + 1, no padding
+      a.padh = a.padw = 0;
+      rc = ph ? (pw ? bf_launch_rect<2, 2, 1, 1>(a, st) : bf_launch_rect<2, 1, 1, 1>(a, st))
+              : (pw ? bf_launch_rect<1, 2, 1, 1>(a, st) : bf_launch_rect<1, 1, 1, 1>(a, st));
+      off += (size_t)(ph ? 2 : 1) * (pw ? 2 : 1) * unit_floats;
+    }
     if (rc) return rc;
   }
   return AVSEP_OK;

@@ -24,10 +24,12 @@ struct W4Args {
 
 constexpr int W4_BM = 128, W4_BC = 32;
 
-template <int TH, int TW>
+// KS = 4: the U-Net encoder convs; KS = 3: the 3x3 / stride 2 / pad 1 convs of ResNet layer2.0 / layer3.0 (same planes,
+// taps kw = 0..2 and kh = 0..2 only).
+template <int TH, int TW, int KS = 4>
 __global__ __launch_bounds__(256) void wgrad4bf_kernel(W4Args a) {
-  constexpr int NT = 256;
-  constexpr int NPIX = TH * TW, PR = 2 * TH + 2;                        // output pixels / input rows of a tile
+  constexpr int NT = 256, NTAP = KS * KS;
+  constexpr int NPIX = TH * TW, PR = 2 * TH + KS - 2;                   // output pixels / input rows of a tile
   constexpr int A_ROW = NPIX * 2 + 16;                                  // bytes per co row: 16 x odd
   constexpr int PL_EL = TW + 16, PLB = PL_EL * 2, ROWB = 2 * PLB;       // plane: 8 | TW | 8 elements; row = E plane, O plane
   constexpr int CH_RAW = PR * ROWB;
@@ -46,9 +48,9 @@ __global__ __launch_bounds__(256) void wgrad4bf_kernel(W4Args a) {
   const long long HW = (long long)a.H * a.W, HoWo = (long long)a.Ho * a.Wo;
   const bool has_aff = a.sc0 != nullptr;
 
-  f32x16 acc[16];
+  f32x16 acc[NTAP];
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
+  for (int j = 0; j < NTAP; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void wgrad4bf_kernel(W4Args a) {
       for (int q = 0; q < TW / 16; ++q) {
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ap + (r * TW + 16 * q) * 2);
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
+        for (int kh = 0; kh < KS; ++kh) {
           // plane elements around m = 16q + 8*lk of input row 2r + kh; interior plane index i sits at element 8 + i
           const unsigned char* row = Bp + (2 * r + kh) * ROWB + (16 * q) * 2;
           const u32x4 e_mid = *reinterpret_cast<const u32x4*>(row + 16);            // E[m .. m+7]        (kw = 1)
@@ -182,10 +184,11 @@ __global__ __launch_bounds__(256) void wgrad4bf_kernel(W4Args a) {
                             __builtin_amdgcn_alignbit(e_mid.w, e_mid.z, 16), __builtin_amdgcn_alignbit(e_hi.x, e_mid.w, 16)};   // E[m+1 ..]
           const u32x4 f0 = {__builtin_amdgcn_alignbit(o_mid.x, o_lo.y, 16), __builtin_amdgcn_alignbit(o_mid.y, o_mid.x, 16),
                             __builtin_amdgcn_alignbit(o_mid.z, o_mid.y, 16), __builtin_amdgcn_alignbit(o_mid.w, o_mid.z, 16)};  // O[m-1 ..]
-          acc[kh * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, f0), acc[kh * 4 + 0], 0, 0, 0);
-          acc[kh * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, e_mid), acc[kh * 4 + 1], 0, 0, 0);
-          acc[kh * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, o_mid), acc[kh * 4 + 2], 0, 0, 0);
-          acc[kh * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, f3), acc[kh * 4 + 3], 0, 0, 0);
+          acc[kh * KS + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, f0), acc[kh * KS + 0], 0, 0, 0);
+          acc[kh * KS + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, e_mid), acc[kh * KS + 1], 0, 0, 0);
+          acc[kh * KS + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, o_mid), acc[kh * KS + 2], 0, 0, 0);
+          if constexpr (KS == 4)
+            acc[kh * KS + 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, f3), acc[kh * KS + 3], 0, 0, 0);
         }
       }
     }
@@ -194,11 +197,11 @@ __global__ __launch_bounds__(256) void wgrad4bf_kernel(W4Args a) {
   }
   const int ci = c0 + li;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < NTAP; ++j) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (co < a.Cout && ci < a.Cin) a.out[(((long long)split * 16 + j) * a.Cout + co) * a.Cin + ci] = acc[j][r];
+      if (co < a.Cout && ci < a.Cin) a.out[(((long long)split * NTAP + j) * a.Cout + co) * a.Cin + ci] = acc[j][r];
     }
   }
 }
@@ -223,7 +226,8 @@ static inline bool w4_enabled() { return getenv("AVSEP_NO_BF16_KERNELS") == null
 
 bool w4b_applicable(const avsep_conv_desc* d) {
   if (d->prec != AVSEP_PREC_BF16 || !w4_enabled()) return false;
-  if (!(d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->dil == 1) || d->up2x || d->C0 != d->Cin) return false;
+  const bool k4 = d->KH == 4 && d->KW == 4, k3 = d->KH == 3 && d->KW == 3;
+  if (!((k4 || k3) && d->stride == 2 && d->pad == 1 && d->dil == 1) || d->up2x || d->C0 != d->Cin) return false;
   return d->Wo >= 16 && d->Ho >= 2 && (d->W & 3) == 0 && (d->Wo & 3) == 0 && d->Cout >= 32 && d->Cin >= 32 && d->N <= 65535 &&
          (long long)d->Cout * d->Ho * d->Wo < 0x7fffffffLL && (long long)d->Cin * d->H * d->W < 0x7fffffffLL;
 }
@@ -244,7 +248,8 @@ static W4Plan w4_plan(const avsep_conv_desc* d) {
   p.splits = (int)((tiles + p.tps - 1) / p.tps);
   return p;
 }
-size_t w4b_workspace_floats(const avsep_conv_desc* d) { return (size_t)w4_plan(d).splits * d->Cout * d->Cin * 16; }
+size_t w4b_workspace_floats(const avsep_conv_desc* d) { return (size_t)w4_plan(d).splits * d->Cout * d->Cin * d->KH * d->KW; }
+int w3_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st);   // conv3x3.hip (9 taps)
 
 int w4b_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st) {
   W4Plan p = w4_plan(d);
@@ -254,10 +259,16 @@ int w4b_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, h
   a.dy = dy; a.out = ws;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.gridM = p.gridM; a.gridC = p.gridC; a.tiles_per_split = p.tps;
   dim3 grid(p.gridM * p.gridC, p.splits);
+  const long long P = (long long)d->Cout * d->Cin;
+  if (d->KH == 3) {
+    if (p.wide) hipLaunchKernelGGL((wgrad4bf_kernel<2, 32, 3>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad4bf_kernel<4, 16, 3>), grid, dim3(256), 0, st, a);
+    AVSEP_LAUNCH_CHECK();
+    return w3_reduce(ws, dw, P, p.splits, st);
+  }
   if (p.wide) hipLaunchKernelGGL((wgrad4bf_kernel<2, 32>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wgrad4bf_kernel<4, 16>), grid, dim3(256), 0, st, a);
   AVSEP_LAUNCH_CHECK();
-  const long long P = (long long)d->Cout * d->Cin;
   hipLaunchKernelGGL(w4_reduce_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, ws, dw, P, p.splits);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
