@@ -244,7 +244,10 @@ static WBPlan wb_plan(const avsep_conv_desc* d) {
   WBPlan p;
   p.wide = d->W > 16;
   p.tilesX = cdiv(d->W, p.wide ? 32 : 16);
-  p.tilesY = cdiv(d->H, (p.wide && d->dil == 2) ? 2 : 4);    // the dilated 32-wide patch only fits with 2-row tiles
+  // 16-wide tiles are 8 rows tall: twice the MFMA work per staged tile (the loads of tile t+1 have one tile's MFMAs to
+  // arrive in, and a 4x16 tile's 36 MFMAs are shorter than an HBM round trip); the dilated 32-wide patch only fits
+  // with 2-row tiles
+  p.tilesY = cdiv(d->H, p.wide ? (d->dil == 2 ? 2 : 4) : 8);
   p.gridM = cdiv(d->Cout, WB_BM);
   p.gridC = cdiv(d->Cin, WB_BC);
   const long long tiles = (long long)p.tilesX * p.tilesY * d->N;
@@ -272,7 +275,7 @@ int wb_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   dim3 grid(p.gridM * p.gridC, p.splits);
   const bool a2 = (d->W & 3) != 0;
 #define WB_L(TW_, DIL_, A2_) \
-  hipLaunchKernelGGL((wgradbf_kernel<(TW_ == 32 && DIL_ == 2) ? 2 : 4, TW_, DIL_, A2_>), grid, dim3(256), 0, st, a)
+  hipLaunchKernelGGL((wgradbf_kernel<TW_ == 16 ? 8 : (DIL_ == 2 ? 2 : 4), TW_, DIL_, A2_>), grid, dim3(256), 0, st, a)
   if (d->dil == 1) {
     if (p.wide) { if (a2) WB_L(32, 1, true); else WB_L(32, 1, false); }
     else { if (a2) WB_L(16, 1, true); else WB_L(16, 1, false); }
