@@ -74,6 +74,7 @@ static int bf_class(const avsep_conv_desc* d) {
   if (d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->dil == 1) return 4;
   if (d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 && d->dil == 1) return 5;      // ResNet layer2.0 / layer3.0 conv1
   if (d->KH == 1 && d->KW == 1 && (d->stride == 1 || d->stride == 2) && d->pad == 0) return 1;  // ResNet downsample convs
+  if (d->KH == 4 && d->KW == 4 && d->stride == 1 && d->pad == 0 && d->dil == 1) return 6;      // stem after space-to-depth
   return 0;
 }
 // flat-pixel tiles: the small square maps of the visual trunk (14x14, 7x7) and of the deep U-Net levels (8x8, 4x4)
@@ -118,6 +119,7 @@ bool bf_applicable(const avsep_conv_desc* d, int mode) {
   const long long in_elems = mode == 0 ? (long long)d->N * d->Cin * d->H * d->W : (long long)d->N * d->Cout * d->Ho * d->Wo;
   if (in_elems >= (1LL << 30) || d->N > 65535) return false;
   if (cls == 3) return bf_flat(d) || (d->W >= 16 && d->H >= 4);
+  if (cls == 6) return mode == 0 && d->Wo >= 16 && d->Ho >= 4;
   if (cls == 1) return d->Wo >= 8 && d->Ho >= 4 && (d->stride == 1 || mode == 0 || ((d->H & 1) == 0 && (d->W & 1) == 0));
   if (mode == 0) return d->Wo >= 8 && d->Ho >= 4;               // 8-wide outputs (U-Net d5) use half of a 16-wide tile
   return d->Wo >= 8 && d->Ho >= 4 && (d->H & 1) == 0 && (d->W & 1) == 0;
@@ -237,6 +239,7 @@ int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
   switch (bf_class(d)) {
     case 4: return bf_launch_rect<4, 4, 2, 1>(a, st);
     case 5: return bf_launch_rect<3, 3, 2, 1>(a, st);
+    case 6: return bf_launch_rect<4, 4, 1, 1>(a, st);
     default: return d->stride == 1 ? bf_launch_rect<1, 1, 1, 1>(a, st) : bf_launch_rect<1, 1, 2, 1>(a, st);
   }
 }

@@ -15,13 +15,15 @@ static int cm_class(const avsep_conv_desc* d) {
   if (d->up2x || d->dil != 1) return 0;
   if (d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1) return 5;
   if (d->KH == 1 && d->KW == 1 && (d->stride == 1 || d->stride == 2) && d->pad == 0) return 1;
+  if (d->KH == 4 && d->KW == 4 && d->stride == 1 && d->pad == 0) return 6;      // the stem after space-to-depth (forward only)
   return 0;
 }
 bool cm_applicable(const avsep_conv_desc* d, int mode) {
   const int cls = cm_class(d);
   if (!cls || !cm_enabled() || d->N > 65535 || d->Wo < 12 || d->Ho < 4) return false;
+  if (cls == 6 && mode != 0) return false;
   if (mode == 0) {
-    if (cls == 5) return d->Cin % 2 == 0 && d->C0 % 2 == 0 && d->Cout >= 32;
+    if (cls == 5 || cls == 6) return d->Cin % 2 == 0 && d->C0 % 2 == 0 && d->Cout >= 32;
     return d->Cin % 16 == 0 && d->C0 % 16 == 0 && d->Cout >= 32;
   }
   if (d->Cin < 32) return false;
@@ -97,6 +99,7 @@ int cm_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
   a.wp = wp; a.wp_ld = roundup(d->Cout, 128); a.out = y; a.bias = bias; a.stats = stats;
   a.Ho = d->Ho; a.Wo = d->Wo; a.padh = a.padw = d->pad; a.os = 1; a.ooh = a.oow = 0; a.OHs = d->Ho; a.OWs = d->Wo;
   if (cm_class(d) == 5) return cm_launch<3, 3, 2, 2>(a, st);
+  if (cm_class(d) == 6) return cm_launch<4, 4, 1, 2>(a, st);
   return d->stride == 1 ? cm_launch<1, 1, 1, 16>(a, st) : cm_launch<1, 1, 2, 16>(a, st);
 }
 

@@ -972,6 +972,37 @@ extern "C" int avsep_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int32
   return AVSEP_OK;
 }
 
+// ---- stem as a stride-1 conv: space-to-depth of the frames ------------------------------------------------------------------
+// conv 7x7 / stride 2 / pad 3 over [N,3,H,W] (vision_net.py:111: resnet conv1)  ==  conv 4x4 / stride 1 / pad 0 over
+//   xs[n][(dy*2+dx)*C + c][i + 2][j + 2] = x[n][c][2i + dy][2j + dx]      ([N, Cp, H/2 + 3, W/2 + 3], zero elsewhere)
+// with w'[co][(dy*2+dx)*C + c][a][b] = w[co][c][2a + dy - 1][2b + dx - 1] (zero where kh, kw leave 0..6): every tap of
+// the 7x7 kernel appears exactly once.  Cp = 4*C rounded up to 16 gives the halo-patch kernels (f32 and bf16) a
+// 16-channel K-tile instead of the im2col gather over 3 channels (38 TFLOP/s).
+__global__ __launch_bounds__(256) void space_to_depth2_kernel(const float* __restrict__ x, int C, int Cp, int H, int W,
+                                                              long long total, float* __restrict__ xs) {
+  const int Hs = H / 2 + 3, Ws = W / 2 + 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int j = (int)(i % Ws), r = (int)((i / Ws) % Hs), q = (int)((i / ((long long)Ws * Hs)) % Cp);
+    const long long n = i / ((long long)Ws * Hs * Cp);
+    float v = 0.f;
+    const int ii = r - 2, jj = j - 2;
+    if (q < 4 * C && ii >= 0 && ii < H / 2 && jj >= 0 && jj < W / 2) {
+      const int c = q % C, dy = (q / C) >> 1, dx = (q / C) & 1;
+      v = x[((n * C + c) * H + 2 * ii + dy) * W + 2 * jj + dx];
+    }
+    xs[i] = v;
+  }
+}
+extern "C" int avsep_space_to_depth2(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp, float* xs,
+                                     avsep_stream_t stream) {
+  if (!x || !xs || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cp < 4 * C) return AVSEP_ERR_ARG;
+  const long long total = (long long)N * Cp * (H / 2 + 3) * (W / 2 + 3);
+  hipLaunchKernelGGL(space_to_depth2_kernel, dim3((int)min((total + 255) / 256, (long long)262144)), dim3(256), 0,
+                     (hipStream_t)stream, x, C, Cp, H, W, total, xs);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
 // ---- stem tail backward, fused: MaxPool(3,2,1) backward + ReLU mask + BatchNorm backward of the stem conv output -----
 // (vision_net.py:111-117 children 1-3 behind conv1).  g = dL/d(pooled) [N,C,Ho,Wo], idx = arg-max positions of the
 // forward, y = RAW conv output [N,C,H,W], pre = scale*y + shift.  dz[pos] = [pre > 0] * sum of g over the windows that

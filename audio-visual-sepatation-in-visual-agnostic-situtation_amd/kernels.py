@@ -330,6 +330,14 @@ def maxpool3x3s2_bwd(dy, idx, H, W):
     return dx
 
 
+def space_to_depth2(x, cp=16):
+    """[N,C,H,W] -> [N,cp,H/2+3,W/2+3]: the 2x2 phases of x as channels, zero border (2 before, 1 after): see avsep.h."""
+    N, Cc, H, W = x.shape
+    xs = _f32((N, cp, H // 2 + 3, W // 2 + 3), x)
+    call("avsep_space_to_depth2", ptr(x), N, Cc, H, W, cp, ptr(xs))
+    return xs
+
+
 def maxpool_bn_relu_bwd_stats(g, idx, y, bnrow, bstats):
     """BatchNorm-backward sums of the stem tail taken over the pooled grid (see avsep.h); bstats is accumulated into."""
     N, Cc, H, W = y.shape

@@ -49,6 +49,7 @@ SIGNATURES = {
     "avsep_conv2d_dgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
     "avsep_conv2d_head_applicable": (C.c_int32, [_CD]),
     "avsep_conv_kernel_name": (C.c_char_p, [_CD, _I, _I]),
+    "avsep_space_to_depth2": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "avsep_maxpool_bn_relu_bwd_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_maxpool_bn_relu_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_attmodel_infer_fwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

@@ -57,10 +57,47 @@ def param_list(net):
     return list(net.features.parameters()) + list(net.fc.parameters())
 
 
+_S2D_INDEX = {}
+
+
+def _stem_s2d_weight(w):
+    """w [Co,C,7,7] -> w' [Co,16,4,4] with w'[co][(dy*2+dx)*C + c][a][b] = w[co][c][2a+dy-1][2b+dx-1] (zero outside the 7x7
+    window, zero pad channels): the stride-1 form of the stem over kernels.space_to_depth2(x)."""
+    Co, Cc = w.shape[:2]
+    key = (Cc, w.device)
+    if key not in _S2D_INDEX:
+        idx = torch.zeros((16, 4, 4), dtype=torch.long)
+        ok = torch.zeros((16, 4, 4), dtype=torch.bool)
+        for q in range(4 * Cc):
+            c, dy, dx = q % Cc, (q // Cc) >> 1, (q // Cc) & 1
+            for a in range(4):
+                for b in range(4):
+                    kh, kw = 2 * a + dy - 1, 2 * b + dx - 1
+                    if 0 <= kh <= 6 and 0 <= kw <= 6:
+                        idx[q, a, b], ok[q, a, b] = (c * 7 + kh) * 7 + kw, True
+        _S2D_INDEX[key] = (idx.to(w.device).reshape(-1), ok.to(w.device).reshape(1, 16, 4, 4))
+    idx, ok = _S2D_INDEX[key]
+    return (w.reshape(Co, -1)[:, idx].reshape(Co, 16, 4, 4) * ok).contiguous()
+
+
+def _stem_is_s2d(conv, x):
+    return (conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1)
+            and conv.in_channels <= 4 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+
+
 def stem_forward(f, x, training):
-    """conv7x7/s2 (+BN statistics) -> max-pool 3x3/s2 over relu(bn(y0)) read on the fly."""
+    """conv7x7/s2 (+BN statistics) -> max-pool 3x3/s2 over relu(bn(y0)) read on the fly.  The forward conv runs in its
+    stride-1 form over the space-to-depth frames (16-channel K-tiles on the halo-patch kernels); the weight gradient
+    keeps the 7x7/s2 descriptor over the frames themselves."""
     S = {"x": x}
-    S["cv0"], S["y0"], S["bn0"] = _conv_bn(x, f[0], f[1], training)
+    if _stem_is_s2d(f[0], x):
+        S["cv0"] = _conv(x, f[0])                       # descriptor of the original conv: the weight gradient uses it
+        cs = K.Conv(K.space_to_depth2(x), f[0].out_channels, 4, 1, 0)
+        st = K.zeros_stats(f[0].out_channels, x) if training else None
+        S["y0"] = cs.fwd(cs.pack(_stem_s2d_weight(_w(f[0])), 0), None, st)
+        S["bn0"] = _bn_run(f[1], st, S["y0"].numel() // S["y0"].shape[1], training, x)
+    else:
+        S["cv0"], S["y0"], S["bn0"] = _conv_bn(x, f[0], f[1], training)
     z, S["idx"] = K.maxpool3x3s2(S["y0"], S["bn0"][0], S["bn0"][1], ACT_RELU)
     return S, z
 

@@ -312,6 +312,10 @@ int avsep_maxpool3x3s2_fwd(const float* x, const float* scale, const float* shif
                            int32_t NC, int32_t H, int32_t W, float* y, int32_t* idx, avsep_stream_t stream);
 int avsep_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int32_t NC, int32_t H, int32_t W,
                            float* dx, avsep_stream_t stream);
+/* Space-to-depth of the frames for the stem (vision_net.py:111, resnet conv1 7x7/s2/p3 == a 4x4/s1/p0 conv over it):
+ * xs [N, Cp, H/2+3, W/2+3], xs[n][(dy*2+dx)*C + c][i+2][j+2] = x[n][c][2i+dy][2j+dx], zero elsewhere; H, W even, Cp >= 4*C. */
+int avsep_space_to_depth2(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp, float* xs,
+                          avsep_stream_t stream);
 /* Stem tail backward, fused (vision_net.py:111-117: conv1 -> bn1 -> relu -> maxpool): from g = dL/d(pooled), the forward's
  * arg-max positions idx and the RAW conv output y with its BatchNorm rows (scale, shift, mean, invstd):
  *   _stats: bstats[2*C] (pre-zeroed) += (sum dz, sum dz*xhat), dz = relu'(scale*y+shift) * maxpool_backward(g);
