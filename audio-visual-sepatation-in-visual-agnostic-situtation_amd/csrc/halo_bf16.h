@@ -71,6 +71,7 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
   const int vr0 = FLAT ? (p0 / f_HW) * f_Hp + (p0 % f_HW) / FW : 0;
   const long long sHW = (long long)a.Hs * a.Ws;
   const bool has_aff = a.sc0 != nullptr;
+  const float slope = act_slope(a.act0);
 
   // ---- patch loader state: slot = (position, channel half g); 8 channels of one position per slot ----------------
   unsigned p_off[PE];                       // element offset of the slot's first channel inside x0 (< 2^30: checked on the host)
@@ -148,11 +149,12 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
       for (int j = 0; j < 8; ++j) {
         float x = praw[e][j];
         if (has_aff) x = fmaf(x, sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
-        x = act_apply(x, a.act0);
-        v[j] = ok ? x : 0.f;
+        v[j] = act_by_slope(x, slope);
       }
       if (PE * NTHR == NSLOT || tid + NTHR * e < NSLOT) {
-        u32x4 q = {bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
+        // zero padding AFTER the activation, on the packed words (the 8 channels of a slot share one position)
+        u32x4 q = {ok ? bf_pack2(v[0], v[1]) : 0u, ok ? bf_pack2(v[2], v[3]) : 0u, ok ? bf_pack2(v[4], v[5]) : 0u,
+                   ok ? bf_pack2(v[6], v[7]) : 0u};
         *reinterpret_cast<u32x4*>(Pb + buf * P_BYTES + p_lds[e]) = q;
       }
     }

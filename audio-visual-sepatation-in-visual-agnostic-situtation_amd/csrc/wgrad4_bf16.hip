@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void wgrad4bf_kernel(W4Args a) {
   const int t_begin = split * a.tiles_per_split, t_end = min(tiles_all, t_begin + a.tiles_per_split);
   const long long HW = (long long)a.H * a.W, HoWo = (long long)a.Ho * a.Wo;
   const bool has_aff = a.sc0 != nullptr;
+  const float slope = act_slope(a.act0);
 
   f32x16 acc[NTAP];
 #pragma unroll
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void wgrad4bf_kernel(W4Args a) {
         const bool ok = (bmask[e] >> p) & 1u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float x = act_apply(fmaf(breg[e][p][j], b_sc[e], b_sh[e]), a.act0);
+          float x = act_by_slope(fmaf(breg[e][p][j], b_sc[e], b_sh[e]), slope);
           x = ok ? x : 0.f;                                  // zero padding of the ACTIVATED tensor
           if (j & 1) od[2 * p + (j >> 1)] = x;
           else ev[2 * p + (j >> 1)] = x;

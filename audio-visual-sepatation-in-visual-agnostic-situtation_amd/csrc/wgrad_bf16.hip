@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
   const int t_begin = split * a.tiles_per_split, t_end = min(tiles_all, t_begin + a.tiles_per_split);
   const long long HW = (long long)a.H * a.W;
   const bool has_aff = a.sc0 != nullptr;
+  const float slope = act_slope(a.act0);
 
   f32x16 acc[9];
 #pragma unroll
@@ -161,12 +162,13 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float x = breg[e][j >> 2][j & 3];
-        x = act_apply(fmaf(x, b_sc[e], b_sh[e]), a.act0);
-        v[j] = ((bmask[e] >> j) & 1u) ? x : 0.f;          // zero padding of the ACTIVATED tensor
+        v[j] = act_by_slope(fmaf(breg[e][j >> 2][j & 3], b_sc[e], b_sh[e]), slope);
       }
       if (BE * NT == BU || tid + NT * e < BU) {
-        u32x4 o = {bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
+        // zero padding of the ACTIVATED tensor, on the packed pairs (W is even: a pair is all-in or all-out)
+        const unsigned m = bmask[e];
+        u32x4 o = {(m & 1u) ? bf_pack2(v[0], v[1]) : 0u, (m & 4u) ? bf_pack2(v[2], v[3]) : 0u,
+                   (m & 16u) ? bf_pack2(v[4], v[5]) : 0u, (m & 64u) ? bf_pack2(v[6], v[7]) : 0u};
         *reinterpret_cast<u32x4*>(Bb + (pk & 0x1ffffu)) = o;
       }
     }
