@@ -165,8 +165,12 @@ static int bf_launch_rect(C3Args& a, hipStream_t st) {
   a.tilesX = cdiv(a.Wo, wide ? 32 : 16);
   a.tilesY = cdiv(a.Ho, wide ? (big ? 8 : 4) : (big ? 16 : 8));
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
-#define BF_L(TH_, TW_, BM_, NWN_) \
-  hipLaunchKernelGGL((convbf_kernel<TH_, TW_, BM_, KH_, KW_, S_, DIL_, 0, NWN_>), grid, dim3(128 * NWN_), 0, st, a)
+  const bool raw = a.sc0 == nullptr && a.act0 == AVSEP_ACT_NONE;
+#define BF_L(TH_, TW_, BM_, NWN_)                                                                                               \
+  do {                                                                                                                          \
+    if (raw) hipLaunchKernelGGL((convbf_kernel<TH_, TW_, BM_, KH_, KW_, S_, DIL_, 0, NWN_, true>), grid, dim3(128 * NWN_), 0, st, a); \
+    else hipLaunchKernelGGL((convbf_kernel<TH_, TW_, BM_, KH_, KW_, S_, DIL_, 0, NWN_, false>), grid, dim3(128 * NWN_), 0, st, a); \
+  } while (0)
   if (m64) {
     if (big) { if (wide) BF_L(8, 32, 64, 4); else BF_L(16, 16, 64, 4); }
     else { if (wide) BF_L(4, 32, 64, 2); else BF_L(8, 16, 64, 2); }
@@ -188,8 +192,12 @@ static int bf_launch_flat(C3Args& a, int splits, hipStream_t st) {
   a.tilesX = cdiv(P, big ? 256 : 128);
   a.tilesY = 1;
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX), splits);
-#define BF_F(BM_, NWN_) \
-  hipLaunchKernelGGL((convbf_kernel<0, 0, BM_, 3, 3, 1, DIL_, FW_, NWN_>), grid, dim3(128 * NWN_), 0, st, a)
+  const bool raw = a.sc0 == nullptr && a.act0 == AVSEP_ACT_NONE;
+#define BF_F(BM_, NWN_)                                                                                                    \
+  do {                                                                                                                     \
+    if (raw) hipLaunchKernelGGL((convbf_kernel<0, 0, BM_, 3, 3, 1, DIL_, FW_, NWN_, true>), grid, dim3(128 * NWN_), 0, st, a); \
+    else hipLaunchKernelGGL((convbf_kernel<0, 0, BM_, 3, 3, 1, DIL_, FW_, NWN_, false>), grid, dim3(128 * NWN_), 0, st, a); \
+  } while (0)
   if (big) { if (m64) BF_F(64, 4); else BF_F(128, 4); }
   else { if (m64) BF_F(64, 2); else BF_F(128, 2); }
 #undef BF_F

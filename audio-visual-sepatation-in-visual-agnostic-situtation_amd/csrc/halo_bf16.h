@@ -34,7 +34,10 @@ __device__ __forceinline__ unsigned bf_pack2(float lo, float hi) {
 // width FW), BM output channels per workgroup, KH_ x KW_ taps, stride S, dilation DIL.  NWN = waves along the pixel
 // dimension (2 or 4): NPX = 64 * NWN pixels, 128 * NWN threads.  The 512-thread form (BM x 256 tile) halves the weight
 // traffic per flop and puts two waves on every SIMD, so one wave's staging overlaps the other's MFMAs.
-template <int TH, int TW, int BM, int KH_, int KW_, int S, int DIL, int FW = 0, int NWN = 2>
+// RAW: the staged tensor needs no affine and no activation (every data gradient; forward convs over a materialised
+// input such as the U-Net decoder's ReLU+upsample tensor): the kernels are VALU-bound in their staging loops (SQ counters:
+// 8-18 VALU per MFMA), so the two instructions per element are compiled out rather than multiplied by one.
+template <int TH, int TW, int BM, int KH_, int KW_, int S, int DIL, int FW = 0, int NWN = 2, bool RAW = false>
 __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
   constexpr int NTHR = 128 * NWN, NPX = 64 * NWN;
   static_assert(FW > 0 || TH * TW == NPX, "tile = NPX pixels");
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
   const int p0 = tx * NPX;
   const int vr0 = FLAT ? (p0 / f_HW) * f_Hp + (p0 % f_HW) / FW : 0;
   const long long sHW = (long long)a.Hs * a.Ws;
-  const bool has_aff = a.sc0 != nullptr;
+  const bool has_aff = !RAW && a.sc0 != nullptr;
   const float slope = act_slope(a.act0);
 
   // ---- patch loader state: slot = (position, channel half g); 8 channels of one position per slot ----------------
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
       for (int j = 0; j < 8; ++j) {
         float x = praw[e][j];
         if (has_aff) x = fmaf(x, sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
-        v[j] = act_by_slope(x, slope);
+        v[j] = RAW ? x : act_by_slope(x, slope);
       }
       if (PE * NTHR == NSLOT || tid + NTHR * e < NSLOT) {
         // zero padding AFTER the activation, on the packed words (the 8 channels of a slot share one position)

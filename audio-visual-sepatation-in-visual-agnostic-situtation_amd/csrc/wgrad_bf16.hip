@@ -33,7 +33,9 @@ struct WBArgs {
 
 constexpr int WB_BM = 128, WB_BC = 32;
 
-template <int TH, int TW, int DIL, bool A2>
+// RAW: the input needs no affine / activation (the U-Net decoder's materialised ReLU+upsample tensor): these kernels
+// are VALU-bound in their staging (SQ counters: 15-19 VALU per MFMA before this), so that work is compiled out.
+template <int TH, int TW, int DIL, bool A2, bool RAW = false>
 __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
   constexpr int NT = 256;
   constexpr int NPIX = TH * TW, PH = TH + 2 * DIL;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
   const int tiles_img = a.tilesX * a.tilesY, tiles_all = tiles_img * a.N;
   const int t_begin = split * a.tiles_per_split, t_end = min(tiles_all, t_begin + a.tiles_per_split);
   const long long HW = (long long)a.H * a.W;
-  const bool has_aff = a.sc0 != nullptr;
+  const bool has_aff = !RAW && a.sc0 != nullptr;
   const float slope = act_slope(a.act0);
 
   f32x16 acc[9];
@@ -123,14 +125,14 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
       const int pr = (int)((pk >> 17) & 15) - DIL, gc = (int)((pk >> 21) & 15) * 8 - 8;   // row / first column rel. to the tile
       const bool rok = (pk >> 31) && (unsigned)(h0 + pr) < (unsigned)a.H;
       const int col = w0 + gc;
-      unsigned m = 0;
+      unsigned m = 0;                       // one bit per PAIR (bits 0, 2, 4, 6): W and col are even, a pair is all-in or all-out
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m |= (unsigned)(rok && (unsigned)(col + j) < (unsigned)a.W) << j;
+      for (int p = 0; p < 4; ++p) m |= (unsigned)(rok && (unsigned)(col + 2 * p) < (unsigned)a.W) << (2 * p);
       bmask[e] = m;
       const float* src = xb + b_goff[e];
       if constexpr (!A2) {
-        breg[e][0] = *reinterpret_cast<const f32x4*>((m & 0x0fu) ? src : a.x0);           // quads are all-in or all-out (W % 4 == 0)
-        breg[e][1] = *reinterpret_cast<const f32x4*>((m & 0xf0u) ? src + 4 : a.x0);
+        breg[e][0] = *reinterpret_cast<const f32x4*>((m & 0x01u) ? src : a.x0);           // quads are all-in or all-out (W % 4 == 0)
+        breg[e][1] = *reinterpret_cast<const f32x4*>((m & 0x10u) ? src + 4 : a.x0);
       } else {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {        // pairs are all-in or all-out (W % 2 == 0)
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        v[j] = act_by_slope(fmaf(breg[e][j >> 2][j & 3], b_sc[e], b_sh[e]), slope);
+        v[j] = RAW ? breg[e][j >> 2][j & 3] : act_by_slope(fmaf(breg[e][j >> 2][j & 3], b_sc[e], b_sh[e]), slope);
       }
       if (BE * NT == BU || tid + NT * e < BU) {
         // zero padding of the ACTIVATED tensor, on the packed pairs (W is even: a pair is all-in or all-out)
@@ -276,8 +278,12 @@ int wb_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.gridM = p.gridM; a.gridC = p.gridC; a.tiles_per_split = p.tps;
   dim3 grid(p.gridM * p.gridC, p.splits);
   const bool a2 = (d->W & 3) != 0;
-#define WB_L(TW_, DIL_, A2_) \
-  hipLaunchKernelGGL((wgradbf_kernel<TW_ == 16 ? 8 : (DIL_ == 2 ? 2 : 4), TW_, DIL_, A2_>), grid, dim3(256), 0, st, a)
+  const bool raw = d->scale0 == nullptr && d->act0 == AVSEP_ACT_NONE;
+#define WB_L(TW_, DIL_, A2_)                                                                                                   \
+  do {                                                                                                                         \
+    if (raw) hipLaunchKernelGGL((wgradbf_kernel<TW_ == 16 ? 8 : (DIL_ == 2 ? 2 : 4), TW_, DIL_, A2_, true>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((wgradbf_kernel<TW_ == 16 ? 8 : (DIL_ == 2 ? 2 : 4), TW_, DIL_, A2_, false>), grid, dim3(256), 0, st, a); \
+  } while (0)
   if (d->dil == 1) {
     if (p.wide) { if (a2) WB_L(32, 1, true); else WB_L(32, 1, false); }
     else { if (a2) WB_L(16, 1, true); else WB_L(16, 1, false); }
