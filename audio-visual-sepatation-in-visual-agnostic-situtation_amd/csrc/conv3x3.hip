@@ -344,6 +344,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   const float* scs = first_src ? a.sc0 : a.sc1;
   const float* shs = first_src ? a.sh0 : a.sh1;
   const int act_s = first_src ? a.act0 : a.act1;
+  const float slope_s = act_slope(act_s);   // branch-free activation in the register-pipelined staging
   const long long sHW = (long long)a.Hs * a.Ws;
   // per staged element ONE packed word: LDS slot (bits 0-15) | tile row (16-19) | tile column (20-25) | valid (31).
   // (separate registers for these cost ~26 VGPRs and pushed the 128-row instantiations into scratch)
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
     }
 #pragma unroll
     for (int e = 0; e < PE; ++e) {
-      float v = act_apply(fmaf(praw[e], p_sc[e], p_sh[e]), act_s);
+      float v = act_by_slope(fmaf(praw[e], p_sc[e], p_sh[e]), slope_s);
       unsigned pk = p_pk[e];
       asm volatile("" : "+v"(pk));
       if (PE * NT == NP || tid + NT * e < NP) Ps[buf][pk & 0xffffu] = ((pmask >> e) & 1u) ? v : 0.f;

@@ -187,11 +187,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
   };
   // the affine/activation flags that belong to the tile held in registers (issue() may already have switched)
   bool fin_has = has0;
-  int fin_act = a.act0;
+  float fin_slope = act_slope(a.act0);      // branch-free activation max(v, slope * v): a run-time act switch costs two
+                                            // scalar branches per staged element, and the f32 MFMA shares the vector ALU
   auto finish = [&](int buf, int kt) __attribute__((always_inline)) {
     if (kt == kt_switch && a.C1 > 0) {
       fin_has = has1;
-      fin_act = a.act1;
+      fin_slope = act_slope(a.act1);
     }
     float* Ab = &As[buf][0][0];
 #pragma unroll
@@ -203,14 +204,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
       if constexpr (!UP2X) {
         v = praw[e][0];
         if (fin_has) v = fmaf(v, psc[e], psh[e]);
-        v = act_apply(v, fin_act);
+        v = act_by_slope(v, fin_slope);
       } else {
         float q[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float t = praw[e][k];
           if (fin_has) t = fmaf(t, psc[e], psh[e]);
-          q[k] = act_apply(t, fin_act);
+          q[k] = act_by_slope(t, fin_slope);
         }
         v = (1.f - plh[e]) * ((1.f - plw[e]) * q[0] + plw[e] * q[1]) + plh[e] * ((1.f - plw[e]) * q[2] + plw[e] * q[3]);
       }
