@@ -544,6 +544,12 @@ int head_dgrad(const avsep_conv_desc* d, const float* w, const float* dy, float*
                const float* invstd1, double* bstats1, int acc0, hipStream_t st);
 bool smallci_applicable(const avsep_conv_desc* d);
 int smallci_dgrad(const avsep_conv_desc* d, const float* w_oihw, const float* dy, float* dx, hipStream_t st);
+// conv_wino.hip: Winograd F(2x2, 3x3) form of the 3x3 / stride 1 / 'same' convs (forward and dgrad), fp32
+bool wn_applicable(const avsep_conv_desc* d, int mode);
+size_t wn_packed_floats(const avsep_conv_desc* d, int mode);
+int wn_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
+int wn_fwd(const avsep_conv_desc* d, const float* up, const float* bias, float* y, double* stats, hipStream_t st);
+int wn_dgrad(const avsep_conv_desc* d, const float* up, const float* dy, float* dx, hipStream_t st);
 // conv3x3.hip: LDS-halo-patch kernel for 3x3 / stride 1 / pad 1 (forward, and dgrad through flipped weights)
 bool c3_applicable(const avsep_conv_desc* d, int mode);
 size_t c3_packed_floats(const avsep_conv_desc* d, int mode);
@@ -621,6 +627,7 @@ extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
   if (!d || (mode != 0 && mode != 1)) return 0;
   if (mode == 1 && smallci_applicable(d)) return (size_t)d->Cout * d->Cin * d->KH * d->KW;   // OIHW as is
   if (bf_applicable(d, mode)) return bf_packed_floats(d, mode);
+  if (wn_applicable(d, mode)) return wn_packed_floats(d, mode);
   if (c3_applicable(d, mode)) return c3_packed_floats(d, mode);
   if (c4_applicable(d, mode)) return c4_packed_floats(d, mode);
   if (cm_applicable(d, mode)) return cm_packed_floats(d, mode);
@@ -637,6 +644,7 @@ extern "C" int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w,
     return AVSEP_OK;
   }
   if (bf_applicable(d, mode)) return bf_pack(d, w, packed, mode, (hipStream_t)stream);
+  if (wn_applicable(d, mode)) return wn_pack(d, w, packed, mode, (hipStream_t)stream);
   if (c3_applicable(d, mode)) return c3_pack(d, w, packed, mode, (hipStream_t)stream);
   if (c4_applicable(d, mode)) return c4_pack(d, w, packed, mode, (hipStream_t)stream);
   if (cm_applicable(d, mode)) return cm_pack(d, w, packed, mode, (hipStream_t)stream);
@@ -669,7 +677,7 @@ static SplitPlan splitk_plan(long long tiles, int K) {
   return p;
 }
 static bool fwd_uses_igemm(const avsep_conv_desc* d, const double* stats) {
-  return !((!stats && (smallco_applicable(d) || head_applicable(d))) || bf_applicable(d, 0) || c3_applicable(d, 0) ||
+  return !((!stats && (smallco_applicable(d) || head_applicable(d))) || bf_applicable(d, 0) || wn_applicable(d, 0) || c3_applicable(d, 0) ||
            c4_applicable(d, 0) || cm_applicable(d, 0));
 }
 static SplitPlan fwd_split(const avsep_conv_desc* d) {
@@ -711,7 +719,7 @@ extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
 }
 extern "C" size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (!check_desc(d) && !smallci_applicable(d) && bf_applicable(d, 1)) return bf_workspace_bytes(d, 1);
-  if (check_desc(d) || bf_applicable(d, 1) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1) ||
+  if (check_desc(d) || bf_applicable(d, 1) || wn_applicable(d, 1) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1) ||
       cm_applicable(d, 1))
     return 0;
   SplitPlan p = dgrad_split(d);
@@ -726,6 +734,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   if (!stats && smallco_applicable(d)) return smallco_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
   if (!stats && head_applicable(d)) return head_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
   if (bf_applicable(d, 0)) return bf_fwd(d, w_packed, bias, y, stats, workspace, workspace_bytes, (hipStream_t)stream);
+  if (wn_applicable(d, 0)) return wn_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (c3_applicable(d, 0)) return c3_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (c4_applicable(d, 0)) return c4_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (cm_applicable(d, 0)) return cm_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
@@ -770,6 +779,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
   if (smallci_applicable(d)) return smallci_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (bf_applicable(d, 1)) return bf_dgrad(d, w_packed_dgrad, dy, dx, workspace, workspace_bytes, (hipStream_t)stream);
+  if (wn_applicable(d, 1)) return wn_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c3_applicable(d, 1)) return c3_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c4_applicable(d, 1)) return c4_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (cm_applicable(d, 1)) return cm_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
@@ -899,6 +909,7 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
     if (!with_stats && smallco_applicable(d)) return "smallco_fwd";
     if (!with_stats && head_applicable(d)) return "head_fwd_kernel";
     if (bf_applicable(d, 0)) return "convbf_kernel";
+    if (wn_applicable(d, 0)) return "wino_kernel";
     if (c3_applicable(d, 0) || c4_applicable(d, 0) || cm_applicable(d, 0)) return "conv3x3_kernel";
     return "igemm_kernel<fwd>";
   }
@@ -906,6 +917,7 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
     if (head_applicable(d)) return "head_dgrad_kernel";
     if (smallci_applicable(d)) return "smallci_dgrad";
     if (bf_applicable(d, 1)) return "convbf_kernel";
+    if (wn_applicable(d, 1)) return "wino_kernel";
     if (c3_applicable(d, 1) || c4_applicable(d, 1) || cm_applicable(d, 1)) return "conv3x3_kernel";
     return "igemm_kernel<dgrad>";
   }

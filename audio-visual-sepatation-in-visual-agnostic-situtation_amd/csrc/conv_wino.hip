@@ -1,0 +1,432 @@
+// 3x3 / stride 1 / 'same' convolution (dilation 1 or 2) in the Winograd F(2x2, 3x3) form on the f32 MFMA:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A          per 2x2 output tile, 16 products instead of 36
+// i.e. 16 independent [Cout x Cin] x [Cin x tiles] GEMMs, one per transform position xi = (i, j), at 4/9 of the
+// direct form's MFMA work.  These are the U-Net decoder convs (audio_net.py:75-76,85-87,96-98,180-182) and the
+// BasicBlock / dilated layer3-4 convs of the visual trunk (vision_net.py:96-109), forward and data gradient (the data
+// gradient is the same conv over dY with flipped, transposed weights — only the weight transform differs).
+//
+// One workgroup (4 waves) owns 64 output channels x 64 tiles (256 output pixels) and loops over K-tiles of 8 input
+// channels; everything between HBM and the MFMA operands happens in LDS / registers:
+//   * the input halo patch of the tiles is staged ONCE per K-tile exactly as in halo_kernel.h (folded BatchNorm
+//     affine + ReLU/LeakyReLU + the two-source skip concat applied on the way in, zero padding written explicitly);
+//   * the transformed weights U[xi][ci][co] come from a pre-transformed image (wino_pack_kernel) by LDS-DMA — no
+//     registers, no VALU;
+//   * wave w owns transform ROW i = w: a lane reads the two patch rows that row i combines (B^T has two non-zeros per
+//     row) as four ds_read_b64, and 8 VALU adds give the B fragments of xi = (w, 0..3) for one (channel, tile):
+//     16 MFMAs (4 xi x 2 channel blocks x 2 tile blocks) per 16 VALU and 16 LDS reads;
+//   * the 4 x 2 x 2 accumulator tiles (256 registers) stay in the matrix domain until the end; the epilogue applies
+//     the column half of A^T . A in registers, exchanges the row half between the waves through LDS (64 KB, the dead
+//     operand buffers) and stores float2 pairs, with the BatchNorm sums of the fp32 result as in halo_kernel.h.
+// The 64 tiles of a workgroup are G groups of GH x GW tiles; a group is a rectangle of one image (or, for dilation 2,
+// of one of its four parity sub-images: a dilated 'same' conv is four independent undilated convs over the pixels of
+// equal row/column parity), so 56x56 / 28x28 / 14x14 / 7x7 maps are covered without the 23 % waste a 16x16-pixel
+// rectangle has on them.  Patch row / group strides are padded so that the 32 lanes of a ds_read_b64 hit 64 distinct
+// banks.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WN_CK = 8;            // input channels per K-tile (host-side packing constant)
+constexpr int WN_BM = 64;           // output channels per workgroup
+constexpr int WN_AFF_MAX = 2048;    // channels of the folded affine rows kept in LDS (host-checked)
+constexpr int WN_A_FLOATS = WN_CK * 16 * WN_BM;   // one K-tile of one M-tile of the transformed weights
+
+struct WArgs {
+  int N, C0, C1, Cin, H, W, Cout;   // full-image geometry; Cin = C0 + C1
+  int Hq, Wq;                       // the (sub-)image the tiles live in: H x W, or ceil(H/2) x ceil(W/2) per parity class
+  int gyn, gxn, ngroups;            // tile groups per (sub-)image along y / x, and in total
+  int gridM, act0, act1;
+  const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
+  const float* up;                  // [K-tile][M-tile][(channel pair, xi, parity) = 128 rows][64]
+  float* out;
+  const float* bias;
+  double* stats;
+};
+
+// rows r = (cpair*16 + xi)*2 + parity of K-tile kt: input channel kt*8 + 2*cpair + parity, xi = 4*i + j
+//   mode 0 (forward): g = w[co][ci][.][.]                         column co
+//   mode 1 (dgrad)  : g = w[ch][col][2-kh][2-kw] ("in" = co)      column ci
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int gridM, int nK,
+                                 int mode) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)nK * gridM * WN_A_FLOATS) return;
+  const int col = (int)(i % WN_BM), row = (int)((i / WN_BM) % (WN_CK * 16));
+  const int mt = (int)((i / WN_A_FLOATS) % gridM), kt = (int)(i / ((long long)WN_A_FLOATS * gridM));
+  const int parity = row & 1, xi = (row >> 1) & 15, cpl = row >> 5;
+  const int ch = kt * WN_CK + 2 * cpl + parity, co = mt * WN_BM + col;
+  float g[9];
+  const bool ok = mode == 0 ? (ch < Cin && co < Cout) : (ch < Cout && co < Cin);
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+    g[k] = !ok ? 0.f : (mode == 0 ? w[((long long)co * Cin + ch) * 9 + k] : w[((long long)ch * Cin + co) * 9 + (8 - k)]);
+  const float Gm[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  const int ti = xi >> 2, tj = xi & 3;
+  float u = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    float rsum = 0.f;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) rsum += Gm[tj][kw] * g[kh * 3 + kw];
+    u += Gm[ti][kh] * rsum;
+  }
+  out[i] = u;
+}
+
+// G groups of GH x GW tiles (G*GH*GW = 64); PWG = LDS row stride of a group's patch, GS = LDS stride between groups
+// (both padded for the bank map); SUB: the groups tile the four parity sub-images of a dilation-2 conv; RAW: no affine
+// and no activation on the staged tensor (every data gradient).
+template <int G, int GH, int GW, int PWG, int GS, bool SUB, bool RAW>
+__global__ __launch_bounds__(256) void wino_kernel(WArgs a) {
+  static_assert(G * GH * GW == 64, "64 tiles per workgroup");
+  constexpr int CK = WN_CK, BM = WN_BM;
+  constexpr int PHG = 2 * GH + 2, PCG = 2 * GW + 2, GE = PHG * PCG;   // patch of one group (valid elements)
+  static_assert(PWG >= PCG && PWG % 2 == 0 && GS >= PHG * PWG && GS % 2 == 0, "patch strides");
+  constexpr int PS = G * GS;                                          // floats per channel
+  constexpr int NPATCH = CK * G * GE, PE = (NPATCH + 255) / 256;
+  constexpr int A_FLOATS = WN_A_FLOATS, AE = A_FLOATS / 4 / 256;      // 16-byte LDS-DMA pieces per thread
+  constexpr int P_FLOATS = CK * PS;
+  static_assert(2 * A_FLOATS >= 4 * 2 * 2 * 16 * 64, "epilogue exchange fits the weight buffers");
+  static_assert(2 * P_FLOATS >= 8 * BM, "statistics partials fit the patch buffers");
+  __shared__ __attribute__((aligned(16))) float smem[2 * P_FLOATS + 2 * A_FLOATS + (RAW ? 0 : 2 * WN_AFF_MAX)];
+  float* const Pb = smem;                       // patch first: its immediate offsets stay small
+  float* const Ab = smem + 2 * P_FLOATS;
+  float* const aff_sc = Ab + 2 * A_FLOATS;
+  float* const aff_sh = aff_sc + WN_AFF_MAX;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = t % a.gridM, pt = t / a.gridM, m0 = mt * BM;
+  const int per = a.gyn * a.gxn;
+  const long long HW = (long long)a.H * a.W;
+
+  // ---- group table: image / origin of the G tile groups of this workgroup (one thread each), read back from LDS ----
+  __shared__ int gtab[G][4];                  // {first element of the (sub-)image's channel 0, y0, x0, valid}
+  if (tid < G) {
+    const int gid = pt * G + tid, gidc = min(gid, a.ngroups - 1);
+    const int img = gidc / per, gy = (gidc % per) / a.gxn, gx = gidc % a.gxn;
+    gtab[tid][0] = img;
+    gtab[tid][1] = gy * 2 * GH;
+    gtab[tid][2] = gx * 2 * GW;
+    gtab[tid][3] = gid < a.ngroups;
+  }
+  __syncthreads();
+
+  // ---- patch loader state: one 32-bit element offset + one packed (LDS slot | channel | valid) word per element ----
+  unsigned p_off[PE], p_pk[PE];
+#pragma unroll
+  for (int e = 0; e < PE; ++e) {
+    const int idx = min(tid + 256 * e, NPATCH - 1);
+    const int cc = idx / (G * GE), rem = idx % (G * GE), g = rem / GE, r = (rem % GE) / PCG, col = rem % PCG;
+    const int img = gtab[g][0], y = gtab[g][1] - 1 + r, x = gtab[g][2] - 1 + col;
+    const bool ok = (PE * 256 == NPATCH || tid + 256 * e < NPATCH) && gtab[g][3] && (unsigned)y < (unsigned)a.Hq &&
+                    (unsigned)x < (unsigned)a.Wq;
+    const int yc = min(max(y, 0), a.Hq - 1), xc = min(max(x, 0), a.Wq - 1);
+    int n = img, fy = yc, fx = xc;
+    if constexpr (SUB) {
+      n = img >> 2;
+      fy = 2 * yc + ((img >> 1) & 1);
+      fx = 2 * xc + (img & 1);
+    }
+    p_off[e] = (unsigned)(((long long)n * a.C0 + cc) * HW + (long long)fy * a.W + fx);   // C1 == C0 when there is a source 1
+    p_pk[e] = (unsigned)(cc * PS + g * GS + r * PWG + col) | ((unsigned)cc << 20) | ((unsigned)ok << 24);
+  }
+  if constexpr (!RAW) {                       // folded BatchNorm rows of both sources -> LDS once (identity where absent)
+    for (int c = tid; c < a.Cin; c += 256) {
+      const bool s0 = c < a.C0;
+      const float* sc = s0 ? a.sc0 : a.sc1;
+      const float* sh = s0 ? a.sh0 : a.sh1;
+      const int cs = s0 ? c : c - a.C0;
+      aff_sc[c] = sc ? sc[cs] : 1.f;
+      aff_sh[c] = sc ? sh[cs] : 0.f;
+    }
+    __syncthreads();
+  }
+  const int kt_switch = a.C1 > 0 ? a.C0 / CK : 0x7fffffff;      // first K-tile of source 1
+  const float slope0 = act_slope(a.act0), slope1 = act_slope(a.act1);
+  float praw[PE];
+
+  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    const float* src = a.up + ((long long)kt * a.gridM + mt) * A_FLOATS + tid * 4;
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      float* dst = Ab + buf * A_FLOATS + (e * 256 + wave * 64) * 4;       // wave-uniform base; hardware adds lane*16 B
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + e * 1024),
+                                       (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+    const float* xk = kt >= kt_switch ? a.x1 + (long long)(kt - kt_switch) * CK * HW : a.x0 + (long long)kt * CK * HW;
+#pragma unroll
+    for (int e = 0; e < PE; ++e) praw[e] = xk[p_off[e]];
+  };
+  auto finish = [&](int kt, int buf) __attribute__((always_inline)) {
+    const float slope = kt >= kt_switch ? slope1 : slope0;
+    float* const P = Pb + buf * P_FLOATS;
+#pragma unroll
+    for (int e = 0; e < PE; ++e) {
+      float v = praw[e];
+      if constexpr (!RAW) {
+        const int c = kt * CK + ((p_pk[e] >> 20) & 15);
+        v = act_by_slope(fmaf(v, aff_sc[c], aff_sh[c]), slope);
+      }
+      if (PE * 256 == NPATCH || tid + 256 * e < NPATCH) P[p_pk[e] & 0xfffffu] = ((p_pk[e] >> 24) & 1u) ? v : 0.f;
+    }
+  };
+
+  f32x16 acc[4][2][2];      // [xi column j][channel block][tile block]
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][cb][tb][r] = 0.f;
+
+  // transform row i = wave of B^T:  t = d[rA] + sgn * d[rB]   ((0,2,-) (1,2,+) (2,1,-) (1,3,-))
+  const int rA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), rB = wave == 2 ? 1 : (wave == 3 ? 3 : 2);
+  const float sgn = wave == 1 ? 1.f : -1.f;
+  int lbA[2], lbB[2];
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb) {
+    const int tile = tb * 32 + li, g = tile / (GH * GW), ty = (tile % (GH * GW)) / GW, tx = tile % GW;
+    const int lb = lk * PS + g * GS + 2 * ty * PWG + 2 * tx;
+    lbA[tb] = lb + rA * PWG;
+    lbB[tb] = lb + rB * PWG;
+  }
+  const int a_lane = wave * 512 + lk * 64 + li;     // A row ((kp*16 + 4*wave + q)*2 + lk), column cb*32 + li
+
+  const int nK = a.Cin / CK;
+  issue(0, 0);
+  finish(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nK; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nK) issue(kt + 1, buf ^ 1);
+    const float* Ak = Ab + buf * A_FLOATS + a_lane;
+    const float* Pk = Pb + buf * P_FLOATS;
+    float av[2][4][2];
+    f32x2 bA[2][2][2], bB[2][2][2];       // [slot][tile block][column pair]
+    auto read_ops = [&](int kp, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) av[slot][q][cb] = Ak[kp * 2048 + q * 128 + cb * 32];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        const float* pa = Pk + kp * 2 * PS + lbA[tb];
+        const float* pb = Pk + kp * 2 * PS + lbB[tb];
+        bA[slot][tb][0] = *reinterpret_cast<const f32x2*>(pa);
+        bA[slot][tb][1] = *reinterpret_cast<const f32x2*>(pa + 2);
+        bB[slot][tb][0] = *reinterpret_cast<const f32x2*>(pb);
+        bB[slot][tb][1] = *reinterpret_cast<const f32x2*>(pb + 2);
+      }
+    };
+    read_ops(0, 0);
+#pragma unroll
+    for (int kp = 0; kp < CK / 2; ++kp) {
+      const int cur = kp & 1;
+      if (kp + 1 < CK / 2) read_ops(kp + 1, cur ^ 1);
+      float v[2][4];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        const float t0 = fmaf(sgn, bB[cur][tb][0][0], bA[cur][tb][0][0]), t1 = fmaf(sgn, bB[cur][tb][0][1], bA[cur][tb][0][1]);
+        const float t2 = fmaf(sgn, bB[cur][tb][1][0], bA[cur][tb][1][0]), t3 = fmaf(sgn, bB[cur][tb][1][1], bA[cur][tb][1][1]);
+        v[tb][0] = t0 - t2;
+        v[tb][1] = t1 + t2;
+        v[tb][2] = t2 - t1;
+        v[tb][3] = t1 - t3;
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb)
+            acc[q][cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][q][cb], v[tb][q], acc[q][cb][tb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt + 1 < nK) finish(kt + 1, buf ^ 1);
+    __syncthreads();       // also drains the LDS-DMA of the next weight tile (vmcnt(0) before s_barrier)
+  }
+
+  // ---- epilogue: Y = A^T M A.  Columns (j) in registers, rows (i = wave) through LDS; wave (ea, etb) then owns output
+  //      row parity ea of tile block etb.  C/D map: tile = lane&31, channel row = (r&3) + 8*(r>>2) + 4*(lane>>5). ----
+  float* const Zs = Ab;                       // [wave i][b][tile block][r][lane]
+  float* const s_sum = Pb;                    // [wave][BM]
+  float* const s_sq = Pb + 4 * BM;
+  const int ea = wave & 1, etb = wave >> 1;
+  const int tile = etb * 32 + li, eg = tile / (GH * GW), ety = (tile % (GH * GW)) / GW, etx = tile % GW;
+  const int img = gtab[eg][0], oy = gtab[eg][1] + 2 * ety + ea, ox = gtab[eg][2] + 2 * etx;
+  const bool ok0 = gtab[eg][3] && oy < a.Hq && ox < a.Wq, ok1 = ok0 && ox + 1 < a.Wq;
+  long long obase;
+  if constexpr (SUB) obase = (long long)(img >> 2) * a.Cout * HW + (long long)(2 * oy + ((img >> 1) & 1)) * a.W + 2 * ox + (img & 1);
+  else obase = (long long)img * a.Cout * HW + (long long)oy * a.W + ox;
+  constexpr int XS = SUB ? 2 : 1;
+  const bool want_stats = a.stats != nullptr;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0_ = acc[0][cb][tb][r], m1 = acc[1][cb][tb][r], m2 = acc[2][cb][tb][r], m3 = acc[3][cb][tb][r];
+        Zs[(((wave * 2 + 0) * 2 + tb) * 16 + r) * 64 + lane] = m0_ + m1 + m2;
+        Zs[(((wave * 2 + 1) * 2 + tb) * 16 + r) * 64 + lane] = m1 - m2 - m3;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lrow = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, row = m0 + lrow;
+      const bool rok = row < a.Cout;
+      const float bias = (a.bias && rok) ? a.bias[row] : 0.f;
+      float y[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float* z = Zs + ((b * 2 + etb) * 16 + r) * 64 + lane;       // + i * (2*2*16*64)
+        const float z1 = z[1 * 4096], z2 = z[2 * 4096];
+        y[b] = (ea == 0 ? z[0] + z1 + z2 : z1 - z2 - z[3 * 4096]) + bias;
+      }
+      float* o = a.out + obase + (long long)row * HW;
+      float s = 0.f, q = 0.f;
+      if (rok && ok1) {
+        if constexpr (SUB) { o[0] = y[0]; o[XS] = y[1]; }
+        else *reinterpret_cast<f32x2*>(o) = f32x2{y[0], y[1]};
+        s = y[0] + y[1];
+        q = y[0] * y[0] + y[1] * y[1];
+      } else if (rok && ok0) {
+        o[0] = y[0];
+        s = y[0];
+        q = y[0] * y[0];
+      }
+      if (want_stats) {
+        s = half_sum(s);
+        q = half_sum(q);
+        if (li == 0) {
+          s_sum[wave * BM + lrow] = s;
+          s_sq[wave * BM + lrow] = q;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (want_stats) {
+    for (int rr = tid; rr < BM; rr += 256) {
+      const int row = m0 + rr;
+      if (row < a.Cout) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s += s_sum[w * BM + rr]; q += s_sq[w * BM + rr]; }
+        atomicAdd(&a.stats[row], (double)s);
+        atomicAdd(&a.stats[a.Cout + row], (double)q);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side (called from conv.hip)
+// ---------------------------------------------------------------------------
+struct WnCfg { int gh, gw, g; };     // pixels per group, groups per workgroup
+static const WnCfg WN_CFGS[4] = {{16, 16, 1}, {4, 32, 2}, {8, 8, 4}, {2, 16, 8}};
+
+// the group shape that wastes the fewest tiles on an Hq x Wq map (ties: the shape with the smaller halo overhead)
+static int wn_cfg(int Hq, int Wq) {
+  static const char* force = getenv("AVSEP_WINO_CFG");      // tuning / debugging: force one group shape (0..3)
+  if (force && force[0] >= '0' && force[0] <= '3') return force[0] - '0';
+  int best = 0;
+  double be = 0.0;
+  for (int c = 0; c < 4; ++c) {
+    const WnCfg& k = WN_CFGS[c];
+    const double e = (double)Hq * Wq / ((double)roundup(Hq, k.gh) * roundup(Wq, k.gw));
+    if (e > be + 0.03) { be = e; best = c; }
+  }
+  return best;
+}
+
+struct WnPlan { int Hq, Wq, cfg, gyn, gxn, ngroups, ptiles, gridM; };
+static WnPlan wn_plan(const avsep_conv_desc* d, int mode) {
+  WnPlan p{};
+  const bool sub = d->dil == 2;
+  p.Hq = sub ? (d->H + 1) / 2 : d->H;
+  p.Wq = sub ? (d->W + 1) / 2 : d->W;
+  p.cfg = wn_cfg(p.Hq, p.Wq);
+  const WnCfg& k = WN_CFGS[p.cfg];
+  p.gyn = cdiv(p.Hq, k.gh);
+  p.gxn = cdiv(p.Wq, k.gw);
+  p.ngroups = d->N * (sub ? 4 : 1) * p.gyn * p.gxn;
+  p.ptiles = cdiv(p.ngroups, k.g);
+  p.gridM = cdiv(mode == 0 ? d->Cout : d->Cin, WN_BM);
+  return p;
+}
+
+bool wn_applicable(const avsep_conv_desc* d, int mode) {
+  static const bool off = getenv("AVSEP_NO_WINOGRAD") != nullptr;
+  if (off || d->prec != AVSEP_PREC_F32) return false;
+  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil) || d->up2x) return false;
+  if ((d->H & 1) || (d->W & 1) || d->H < (d->dil == 1 ? 8 : 14) || d->W < (d->dil == 1 ? 8 : 14)) return false;   // float2 stores; tiny maps stay on split-K
+  const int cin = mode == 0 ? d->Cin : d->Cout, cout = mode == 0 ? d->Cout : d->Cin;
+  if (cin % WN_CK || cin < 32 || cin > WN_AFF_MAX || cout < 48) return false;
+  if (mode == 0) {
+    const int C1 = d->Cin - d->C0;
+    if (d->C0 % WN_CK || (C1 != 0 && C1 != d->C0)) return false;
+  }
+  if ((long long)d->N * (mode == 0 ? d->C0 : d->Cout) * d->H * d->W >= 0xffffffffLL) return false;   // 32-bit element offsets
+  const WnPlan p = wn_plan(d, mode);
+  return (long long)p.ptiles * p.gridM >= 256;      // one workgroup per CU at least
+}
+size_t wn_packed_floats(const avsep_conv_desc* d, int mode) {
+  const int cin = mode == 0 ? d->Cin : d->Cout, cout = mode == 0 ? d->Cout : d->Cin;
+  return (size_t)(cin / WN_CK) * cdiv(cout, WN_BM) * WN_A_FLOATS;
+}
+int wn_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st) {
+  const int cin = mode == 0 ? d->Cin : d->Cout, cout = mode == 0 ? d->Cout : d->Cin;
+  const int nK = cin / WN_CK, gridM = cdiv(cout, WN_BM);
+  const long long total = (long long)nK * gridM * WN_A_FLOATS;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, packed, d->Cout, d->Cin, gridM, nK, mode);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+template <bool SUB, bool RAW>
+static void wn_launch_cfg(const WArgs& a, int cfg, dim3 grid, hipStream_t st) {
+  // <G, GH, GW, PWG, GS>: strides chosen so that the 32 tiles of a tile block read 64 distinct banks (see header)
+  switch (cfg) {
+    case 0: hipLaunchKernelGGL((wino_kernel<1, 8, 8, 24, 18 * 24, SUB, RAW>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((wino_kernel<2, 2, 16, 48, 6 * 48, SUB, RAW>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((wino_kernel<4, 4, 4, 12, 160, SUB, RAW>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((wino_kernel<8, 1, 8, 18, 80, SUB, RAW>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
+static int wn_launch(WArgs& a, const avsep_conv_desc* d, int mode, bool raw, hipStream_t st) {
+  const WnPlan p = wn_plan(d, mode);
+  a.Hq = p.Hq; a.Wq = p.Wq; a.gyn = p.gyn; a.gxn = p.gxn; a.ngroups = p.ngroups; a.gridM = p.gridM;
+  dim3 grid((unsigned)((long long)p.ptiles * p.gridM));
+  const bool sub = d->dil == 2;
+  if (sub && raw) wn_launch_cfg<true, true>(a, p.cfg, grid, st);
+  else if (sub) wn_launch_cfg<true, false>(a, p.cfg, grid, st);
+  else if (raw) wn_launch_cfg<false, true>(a, p.cfg, grid, st);
+  else wn_launch_cfg<false, false>(a, p.cfg, grid, st);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+int wn_fwd(const avsep_conv_desc* d, const float* up, const float* bias, float* y, double* stats, hipStream_t st) {
+  WArgs a{};
+  a.N = d->N; a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.act0 = d->act0; a.act1 = d->act1;
+  a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
+  a.up = up; a.out = y; a.bias = bias; a.stats = stats;
+  const bool raw = !d->scale0 && !d->scale1 && d->act0 == AVSEP_ACT_NONE && (a.C1 == 0 || d->act1 == AVSEP_ACT_NONE);
+  return wn_launch(a, d, 0, raw, st);
+}
+
+// dX[N,Cin,H,W] = conv3x3(dY[N,Cout,H,W], flipped / transposed weights); the identity holds for any dilation with pad == dil
+int wn_dgrad(const avsep_conv_desc* d, const float* up, const float* dy, float* dx, hipStream_t st) {
+  WArgs a{};
+  a.N = d->N; a.C0 = d->Cout; a.C1 = 0; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
+  a.x0 = dy; a.up = up; a.out = dx;
+  return wn_launch(a, d, 1, true, st);
+}

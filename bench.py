@@ -66,12 +66,12 @@ class KernelTimer:
         for name in ("fwd", "bwd"):
             self._wrap_cat(name)
 
-    def _time(self, orig, args, kw, family, mode, flops, nbytes):
+    def _time(self, orig, args, kw, family, mode, flops, nbytes, layer=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = orig(*args, **kw)
         e1.record()
-        self.rec.append((mode, flops, e0, e1, family, nbytes))
+        self.rec.append((mode, flops, e0, e1, family, nbytes, layer))
         return out
 
     def _wrap_conv(self, name):
@@ -91,7 +91,8 @@ class KernelTimer:
                 nbytes = 4.0 * ((2 * lo if mode == "dgrad" else lo) + cv.N * cv.Cout * cv.Ho * cv.Wo + wts)
             else:   # each of the three operands (input, output / cotangent, weights) touched once
                 nbytes = 4.0 * (cv.N * cv.Cin * cv.H * cv.W + cv.N * cv.Cout * cv.Ho * cv.Wo + wts)
-            return timer._time(orig, (cv,) + a, kw, family, mode, flops, nbytes)
+            layer = (cv.N, cv.Cin, cv.H, cv.W, cv.Cout, cv.KH, cv.d.stride, cv.d.pad, cv.d.dil, cv.d.up2x)
+            return timer._time(orig, (cv,) + a, kw, family, mode, flops, nbytes, layer)
         setattr(self.K.Conv, name, wrapped)
 
     def _wrap_cat(self, name):
@@ -111,7 +112,11 @@ class KernelTimer:
 
     def summary(self, steps):
         fam = {}
-        for mode, fl, e0, e1, family, nbytes in self.rec:
+        self.layers = {}
+        for mode, fl, e0, e1, family, nbytes, layer in self.rec:
+            if layer is not None:
+                row = self.layers.setdefault((layer, mode, family), [0.0, 0.0, 0])
+                row[0] += e0.elapsed_time(e1) / steps; row[1] += fl / steps; row[2] += 1
             b = fam.setdefault(family, {"ms": 0.0, "flops": 0.0, "n": 0, "bytes": 0.0, "modes": set()})
             b["ms"] += e0.elapsed_time(e1); b["flops"] += fl; b["n"] += 1; b["bytes"] += nbytes; b["modes"].add(mode)
         self.rec = []
@@ -283,6 +288,7 @@ def main():
     ap.add_argument("--backend", default="hip", choices=["hip", "hybrid", "torch"], help="visual trunk of the headline run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--layers", default=None, help="write a per-convolution-call table of the headline step to this file")
     o = ap.parse_args()
 
     import avsep_amd as P
@@ -297,6 +303,13 @@ def main():
     timer = KernelTimer(P.kernels)
     head = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup, timer)
     kernels = timer.summary(o.steps)
+    if o.layers and rank == 0:
+        rows = sorted(timer.layers.items(), key=lambda kv: -kv[1][0])
+        with open(o.layers, "w") as f:
+            f.write("# %s step, batch %d: (N Cin H W Cout K stride pad dil up2x) mode family calls/step ms/step TFLOP/s\n" % (o.precision, B))
+            for (layer, mode, family), (ms, fl, n) in rows:
+                f.write("%-44s %-6s %-62s %5.1f %8.3f %7.1f\n" % (" ".join(map(str, layer)), mode, family[:62], n / o.steps, ms,
+                                                                   fl / (ms * 1e-3) / 1e12 if ms else 0.0))
     extras = {}
     if world == 1 and not o.no_extra:
         other = "bf16" if o.precision == "f32" else "f32"

@@ -62,6 +62,14 @@ CONV_CASES = [
     (3, 64, 14, 14, 144, 1, 1, 0, 1),      # 1x1 (layer4.0 downsample)
     (2, 32, 28, 28, 48, 1, 2, 0, 1),       # 1x1 / stride 2: dgrad zero-fills the skipped pixels
     (40, 128, 28, 28, 256, 1, 2, 0, 1),    # 1x1 / stride 2 at the layer3.0 downsample shape, 128-row tiles both ways
+    # conv_wino.hip: Winograd F(2x2, 3x3) forward + data gradient (needs >= 256 workgroups, hence the batch sizes)
+    (64, 48, 32, 32, 80, 3, 1, 1, 1),      # one 8x8-tile group per workgroup (U-Net decoder maps), ragged second M tile
+    (22, 64, 56, 56, 72, 3, 1, 1, 1),      # four 4x4-tile groups (56x56: 7x7 groups per image)
+    (80, 48, 28, 28, 72, 3, 1, 1, 1),      # two 2x16-tile groups (28x28)
+    (300, 48, 14, 14, 56, 3, 1, 1, 1),     # eight 1x8-tile groups (14x14), last workgroup partial
+    (260, 48, 14, 14, 56, 3, 1, 2, 2),     # dilation 2: the four 7x7 parity sub-images, odd sub-image size
+    (80, 48, 28, 28, 56, 3, 1, 2, 2),      # dilation 2 at 28x28: 14x14 sub-images on the 1x8-tile groups
+    (72, 48, 20, 36, 72, 3, 1, 1, 1),      # ragged group grid (H, W not multiples of the group)
 ]
 
 
@@ -179,6 +187,33 @@ def test_conv_bf16_operands(dev, case):
         (k in (3, 4) and s == 2 and Cin >= 32 and Cout >= 32 and W >= 32 and W % 8 == 0)
     assert (e_bf if has_bf16_wgrad else e_32) <= 2e-5, (has_bf16_wgrad, e_bf, e_32)
     assert_close(db, dy.sum((0, 2, 3)), 2e-5, "dbias")
+
+
+def test_conv_virtual_input_winograd(dev):
+    """the same folded two-source input (C0 == C1) through the Winograd kernel's staging (conv_wino.hip), with the
+    BatchNorm sums of the result."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(11)
+    N, C0, C1, Cout, H, W = 32, 24, 24, 72, 32, 32
+    x0, x1 = torch.randn(N, C0, H, W, generator=g), torch.randn(N, C1, H, W, generator=g)
+    sc0, sh0 = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g)
+    sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g)
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.05
+    a0 = F.leaky_relu(x0 * sc0.view(1, -1, 1, 1) + sh0.view(1, -1, 1, 1), 0.2)
+    a1 = F.relu(x1 * sc1.view(1, -1, 1, 1) + sh1.view(1, -1, 1, 1))
+    y_ref = F.conv2d(torch.cat([a0, a1], 1), w, None, 1, 1)
+    t = lambda z: z.to(dev)
+    cv = K.Conv(t(x0), Cout, 3, 1, 1, x1=t(x1), sc0=t(sc0), sh0=t(sh0), act0=2, sc1=t(sc1), sh1=t(sh1), act1=1)
+    assert cv.kernel_name("fwd", True) == "wino_kernel"
+    st = K.zeros_stats(Cout, cv.like)
+    assert_close(cv.fwd(cv.pack(t(w), 0), None, st), y_ref, 2e-5, "fwd")
+    st_ref = torch.cat([y_ref.double().sum((0, 2, 3)), (y_ref.double() ** 2).sum((0, 2, 3))])
+    assert_close(st, st_ref, 1e-5, "stats")
+    # one source, activation only (identity affine rows)
+    x01 = torch.cat([x0, x1], 1)
+    cv1 = K.Conv(t(x01), Cout, 3, 1, 1, act0=1)
+    assert cv1.kernel_name("fwd", False) == "wino_kernel"
+    assert_close(cv1.fwd(cv1.pack(t(w), 0)), F.conv2d(F.relu(x01), w, None, 1, 1), 2e-5, "fwd relu")
 
 
 @pytest.mark.parametrize("up2x,H,W", [(False, 9, 7), (True, 9, 7), (False, 10, 36), (True, 10, 18), (True, 6, 10)])
