@@ -9,8 +9,8 @@
 // channels; everything between HBM and the MFMA operands happens in LDS / registers:
 //   * the input halo patch of the tiles is staged ONCE per K-tile exactly as in halo_kernel.h (folded BatchNorm
 //     affine + ReLU/LeakyReLU + the two-source skip concat applied on the way in, zero padding written explicitly);
-//   * the transformed weights U[xi][ci][co] come from a pre-transformed image (wino_pack_kernel) by LDS-DMA — no
-//     registers, no VALU;
+//   * the transformed weights U[xi][ci][co] come from a pre-transformed image (wino_pack_kernel), one contiguous 32 KB
+//     block per (K-tile, M-tile): eight float4 loads and ds_write_b128 per thread, no address arithmetic;
 //   * wave w owns transform ROW i = w: a lane reads the two patch rows that row i combines (B^T has two non-zeros per
 //     row) as four ds_read_b64, and 8 VALU adds give the B fragments of xi = (w, 0..3) for one (channel, tile):
 //     16 MFMAs (4 xi x 2 channel blocks x 2 tile blocks) per 16 VALU and 16 LDS reads;
@@ -77,15 +77,22 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 // G groups of GH x GW tiles (G*GH*GW = 64); PWG = LDS row stride of a group's patch, GS = LDS stride between groups
 // (both padded for the bank map); SUB: the groups tile the four parity sub-images of a dilation-2 conv; RAW: no affine
 // and no activation on the staged tensor (every data gradient).
+//
+// 512 threads = 8 waves, TWO per SIMD: wave (i, tb) owns transform row i of tile block tb (32 tiles) for both channel
+// blocks — 4 x 2 accumulator tiles = 128 registers, so that two waves fit a SIMD.  That is what keeps the matrix pipe
+// fed: a wave issues in order and the f32 MFMA holds its issue slot, so with ONE wave per SIMD (the first version of
+// this kernel: 4 waves x 256 accumulator registers) every ds_read / VALU / ds_write between two MFMAs was dead time
+// for the pipe (measured 49-58 % MFMA busy against 84 % for halo_kernel.h, which runs two workgroups per CU).
+constexpr int WN_THREADS = 512;
 template <int G, int GH, int GW, int PWG, int GS, bool SUB, bool RAW>
-__global__ __launch_bounds__(256) void wino_kernel(WArgs a) {
+__global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
   static_assert(G * GH * GW == 64, "64 tiles per workgroup");
-  constexpr int CK = WN_CK, BM = WN_BM;
+  constexpr int CK = WN_CK, BM = WN_BM, NT = WN_THREADS;
   constexpr int PHG = 2 * GH + 2, PCG = 2 * GW + 2, GE = PHG * PCG;   // patch of one group (valid elements)
   static_assert(PWG >= PCG && PWG % 2 == 0 && GS >= PHG * PWG && GS % 2 == 0, "patch strides");
   constexpr int PS = G * GS;                                          // floats per channel
-  constexpr int NPATCH = CK * G * GE, PE = (NPATCH + 255) / 256;
-  constexpr int A_FLOATS = WN_A_FLOATS, AE = A_FLOATS / 4 / 256;      // 16-byte LDS-DMA pieces per thread
+  constexpr int NPATCH = CK * G * GE, PE = (NPATCH + NT - 1) / NT;
+  constexpr int A_FLOATS = WN_A_FLOATS, AE = A_FLOATS / 4 / NT;       // float4 pieces per thread
   constexpr int P_FLOATS = CK * PS;
   static_assert(2 * A_FLOATS >= 4 * 2 * 2 * 16 * 64, "epilogue exchange fits the weight buffers");
   static_assert(2 * P_FLOATS >= 8 * BM, "statistics partials fit the patch buffers");
@@ -96,13 +103,14 @@ __global__ __launch_bounds__(256) void wino_kernel(WArgs a) {
   float* const aff_sh = aff_sc + WN_AFF_MAX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+  const int wi = wave & 3, wtb = wave >> 2;     // transform row, tile block
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = t % a.gridM, pt = t / a.gridM, m0 = mt * BM;
   const int per = a.gyn * a.gxn;
   const long long HW = (long long)a.H * a.W;
 
   // ---- group table: image / origin of the G tile groups of this workgroup (one thread each), read back from LDS ----
-  __shared__ int gtab[G][4];                  // {first element of the (sub-)image's channel 0, y0, x0, valid}
+  __shared__ int gtab[G][4];                  // {(sub-)image, y0, x0, valid}
   if (tid < G) {
     const int gid = pt * G + tid, gidc = min(gid, a.ngroups - 1);
     const int img = gidc / per, gy = (gidc % per) / a.gxn, gx = gidc % a.gxn;
@@ -117,10 +125,10 @@ __global__ __launch_bounds__(256) void wino_kernel(WArgs a) {
   unsigned p_off[PE], p_pk[PE];
 #pragma unroll
   for (int e = 0; e < PE; ++e) {
-    const int idx = min(tid + 256 * e, NPATCH - 1);
+    const int idx = min(tid + NT * e, NPATCH - 1);
     const int cc = idx / (G * GE), rem = idx % (G * GE), g = rem / GE, r = (rem % GE) / PCG, col = rem % PCG;
     const int img = gtab[g][0], y = gtab[g][1] - 1 + r, x = gtab[g][2] - 1 + col;
-    const bool ok = (PE * 256 == NPATCH || tid + 256 * e < NPATCH) && gtab[g][3] && (unsigned)y < (unsigned)a.Hq &&
+    const bool ok = (PE * NT == NPATCH || tid + NT * e < NPATCH) && gtab[g][3] && (unsigned)y < (unsigned)a.Hq &&
                     (unsigned)x < (unsigned)a.Wq;
     const int yc = min(max(y, 0), a.Hq - 1), xc = min(max(x, 0), a.Wq - 1);
     int n = img, fy = yc, fx = xc;
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(256) void wino_kernel(WArgs a) {
     p_pk[e] = (unsigned)(cc * PS + g * GS + r * PWG + col) | ((unsigned)cc << 20) | ((unsigned)ok << 24);
   }
   if constexpr (!RAW) {                       // folded BatchNorm rows of both sources -> LDS once (identity where absent)
-    for (int c = tid; c < a.Cin; c += 256) {
+    for (int c = tid; c < a.Cin; c += NT) {
       const bool s0 = c < a.C0;
       const float* sc = s0 ? a.sc0 : a.sc1;
       const float* sh = s0 ? a.sh0 : a.sh1;
@@ -146,118 +154,137 @@ __global__ __launch_bounds__(256) void wino_kernel(WArgs a) {
   const int kt_switch = a.C1 > 0 ? a.C0 / CK : 0x7fffffff;      // first K-tile of source 1
   const float slope0 = act_slope(a.act0), slope1 = act_slope(a.act1);
   float praw[PE];
+  f32x4 areg[AE];
 
-  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-    const float* src = a.up + ((long long)kt * a.gridM + mt) * A_FLOATS + tid * 4;
-#pragma unroll
-    for (int e = 0; e < AE; ++e) {
-      float* dst = Ab + buf * A_FLOATS + (e * 256 + wave * 64) * 4;       // wave-uniform base; hardware adds lane*16 B
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + e * 1024),
-                                       (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+  // The staged tile of a K-tile moves in AE + PE independent pieces (one global load, later one LDS store, each) so that
+  // the MFMA loop can hang them behind individual MFMAs.  The weight tile is one contiguous 32 KB block per (K-tile,
+  // M-tile).  (An LDS-DMA for it would cost an s_waitcnt vmcnt(0) — a full memory round trip — in front of the first
+  // ds_read of every K-tile: the compiler orders every LDS read behind an outstanding LDS-DMA it cannot tell apart.)
+  constexpr int NPIECE = AE + PE;
+  auto issue_piece = [&](int kt, int pc) __attribute__((always_inline)) {
+    if (pc < AE) {
+      areg[pc] = *reinterpret_cast<const f32x4*>(a.up + ((long long)kt * a.gridM + mt) * A_FLOATS + tid * 4 + pc * (NT * 4));
+    } else if (pc < NPIECE) {
+      const float* xk = kt >= kt_switch ? a.x1 + (long long)(kt - kt_switch) * CK * HW : a.x0 + (long long)kt * CK * HW;
+      praw[pc - AE] = xk[p_off[pc - AE]];
     }
-    const float* xk = kt >= kt_switch ? a.x1 + (long long)(kt - kt_switch) * CK * HW : a.x0 + (long long)kt * CK * HW;
-#pragma unroll
-    for (int e = 0; e < PE; ++e) praw[e] = xk[p_off[e]];
   };
-  auto finish = [&](int kt, int buf) __attribute__((always_inline)) {
-    const float slope = kt >= kt_switch ? slope1 : slope0;
-    float* const P = Pb + buf * P_FLOATS;
-#pragma unroll
-    for (int e = 0; e < PE; ++e) {
+  auto finish_piece = [&](int kt, int buf, int pc) __attribute__((always_inline)) {
+    if (pc < AE) {
+      *reinterpret_cast<f32x4*>(Ab + buf * A_FLOATS + (pc * NT + tid) * 4) = areg[pc];
+    } else if (pc < NPIECE) {
+      const int e = pc - AE;
       float v = praw[e];
       if constexpr (!RAW) {
+        const float slope = kt >= kt_switch ? slope1 : slope0;
         const int c = kt * CK + ((p_pk[e] >> 20) & 15);
         v = act_by_slope(fmaf(v, aff_sc[c], aff_sh[c]), slope);
       }
-      if (PE * 256 == NPATCH || tid + 256 * e < NPATCH) P[p_pk[e] & 0xfffffu] = ((p_pk[e] >> 24) & 1u) ? v : 0.f;
+      if (PE * NT == NPATCH || tid + NT * e < NPATCH) (Pb + buf * P_FLOATS)[p_pk[e] & 0xfffffu] = ((p_pk[e] >> 24) & 1u) ? v : 0.f;
     }
   };
 
-  f32x16 acc[4][2][2];      // [xi column j][channel block][tile block]
+  f32x16 acc[4][2];         // [xi column j][channel block]
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][cb][tb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[q][cb][r] = 0.f;
 
-  // transform row i = wave of B^T:  t = d[rA] + sgn * d[rB]   ((0,2,-) (1,2,+) (2,1,-) (1,3,-))
-  const int rA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), rB = wave == 2 ? 1 : (wave == 3 ? 3 : 2);
-  const float sgn = wave == 1 ? 1.f : -1.f;
-  int lbA[2], lbB[2];
-#pragma unroll
-  for (int tb = 0; tb < 2; ++tb) {
-    const int tile = tb * 32 + li, g = tile / (GH * GW), ty = (tile % (GH * GW)) / GW, tx = tile % GW;
+  // transform row i of B^T:  t = d[rA] + sgn * d[rB]   ((0,2,-) (1,2,+) (2,1,-) (1,3,-))
+  const int rA = wi == 0 ? 0 : (wi == 2 ? 2 : 1), rB = wi == 2 ? 1 : (wi == 3 ? 3 : 2);
+  const float sgn = wi == 1 ? 1.f : -1.f;
+  int lbA, lbB;
+  {
+    const int tile = wtb * 32 + li, g = tile / (GH * GW), ty = (tile % (GH * GW)) / GW, tx = tile % GW;
     const int lb = lk * PS + g * GS + 2 * ty * PWG + 2 * tx;
-    lbA[tb] = lb + rA * PWG;
-    lbB[tb] = lb + rB * PWG;
+    lbA = lb + rA * PWG;
+    lbB = lb + rB * PWG;
   }
-  const int a_lane = wave * 512 + lk * 64 + li;     // A row ((kp*16 + 4*wave + q)*2 + lk), column cb*32 + li
+  const int a_lane = wi * 512 + lk * 64 + li;       // A row ((kp*16 + 4*i + q)*2 + lk), column cb*32 + li
 
+  // ---- main loop.  One BLOCK = the 8 MFMAs of one channel pair; every other instruction of the loop is hung behind
+  // one of those MFMAs (sched_barrier after each):
+  //   MFMA 0-1 : ds_read of the next block's two patch row pairs            MFMA 2-5 : its eight weight fragments
+  //   MFMA 4-7 : the 8 VALU of the next block's transform (two per MFMA)
+  //   block 2  : + the LDS stores of the NEXT K-tile (its global loads were issued three blocks earlier), then the
+  //              one barrier of the K-tile;   block 3 : + the global loads of the K-tile after that, and its operand
+  //              reads already come from the other buffer, so no latency is exposed behind the barrier.
+  // Staging is unconditional (tile indices clamped; the tail re-stages the last tile into a dead buffer): a branch
+  // around it would fork the accumulator state.
   const int nK = a.Cin / CK;
-  issue(0, 0);
-  finish(0, 0);
+  float av[2][4][2], v[2][4], tt[4];
+  f32x2 bA[2], bB[2];                       // column pairs of the two patch rows of the block being transformed
+  auto read_b = [&](int buf, int kp, int which) __attribute__((always_inline)) {
+    const float* pp = Pb + buf * P_FLOATS + kp * 2 * PS + (which ? lbB : lbA);
+    f32x2* dst = which ? bB : bA;
+    dst[0] = *reinterpret_cast<const f32x2*>(pp);
+    dst[1] = *reinterpret_cast<const f32x2*>(pp + 2);
+  };
+  auto read_a = [&](int buf, int kp, int slot, int q) __attribute__((always_inline)) {
+    const float* Ak = Ab + buf * A_FLOATS + a_lane + kp * 2048 + q * 128;
+    av[slot][q][0] = Ak[0];
+    av[slot][q][1] = Ak[32];
+  };
+  auto transform = [&](int slot, int st) __attribute__((always_inline)) {       // st = 0..3: two VALU each
+    if (st == 0) { tt[0] = fmaf(sgn, bB[0][0], bA[0][0]); tt[1] = fmaf(sgn, bB[0][1], bA[0][1]); }
+    if (st == 1) { tt[2] = fmaf(sgn, bB[1][0], bA[1][0]); tt[3] = fmaf(sgn, bB[1][1], bA[1][1]); }
+    if (st == 2) { v[slot][0] = tt[0] - tt[2]; v[slot][1] = tt[1] + tt[2]; }
+    if (st == 3) { v[slot][2] = tt[2] - tt[1]; v[slot][3] = tt[1] - tt[3]; }
+  };
+
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(0, pc);
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) finish_piece(0, 0, pc);
   __syncthreads();
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(min(1, nK - 1), pc);
+  read_b(0, 0, 0);
+  read_b(0, 0, 1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) read_a(0, 0, 0, q);
+#pragma unroll
+  for (int st = 0; st < 4; ++st) transform(0, st);
+
   for (int kt = 0; kt < nK; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nK) issue(kt + 1, buf ^ 1);
-    const float* Ak = Ab + buf * A_FLOATS + a_lane;
-    const float* Pk = Pb + buf * P_FLOATS;
-    float av[2][4][2];
-    f32x2 bA[2][2][2], bB[2][2][2];       // [slot][tile block][column pair]
-    auto read_ops = [&](int kp, int slot) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) av[slot][q][cb] = Ak[kp * 2048 + q * 128 + cb * 32];
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        const float* pa = Pk + kp * 2 * PS + lbA[tb];
-        const float* pb = Pk + kp * 2 * PS + lbB[tb];
-        bA[slot][tb][0] = *reinterpret_cast<const f32x2*>(pa);
-        bA[slot][tb][1] = *reinterpret_cast<const f32x2*>(pa + 2);
-        bB[slot][tb][0] = *reinterpret_cast<const f32x2*>(pb);
-        bB[slot][tb][1] = *reinterpret_cast<const f32x2*>(pb + 2);
-      }
-    };
-    read_ops(0, 0);
+    const int kt1 = min(kt + 1, nK - 1), kt2 = min(kt + 2, nK - 1);
 #pragma unroll
     for (int kp = 0; kp < CK / 2; ++kp) {
-      const int cur = kp & 1;
-      if (kp + 1 < CK / 2) read_ops(kp + 1, cur ^ 1);
-      float v[2][4];
+      const int cur = kp & 1, nxt = cur ^ 1;
+      const int nbuf = kp + 1 < CK / 2 ? buf : buf ^ 1, nkp = kp + 1 < CK / 2 ? kp + 1 : 0;
 #pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        const float t0 = fmaf(sgn, bB[cur][tb][0][0], bA[cur][tb][0][0]), t1 = fmaf(sgn, bB[cur][tb][0][1], bA[cur][tb][0][1]);
-        const float t2 = fmaf(sgn, bB[cur][tb][1][0], bA[cur][tb][1][0]), t3 = fmaf(sgn, bB[cur][tb][1][1], bA[cur][tb][1][1]);
-        v[tb][0] = t0 - t2;
-        v[tb][1] = t1 + t2;
-        v[tb][2] = t2 - t1;
-        v[tb][3] = t1 - t3;
+      for (int m = 0; m < 8; ++m) {
+        const int q = m >> 1, cb = m & 1;
+        acc[q][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][q][cb], v[cur][q], acc[q][cb], 0, 0, 0);
+        if (m < 2) read_b(nbuf, nkp, m);
+        if (m >= 2 && m < 6) read_a(nbuf, nkp, nxt, m - 2);
+        if (m >= 4) transform(nxt, m - 4);
+        if (kp == CK / 2 - 2) {
+#pragma unroll
+          for (int pc = m; pc < NPIECE; pc += 8) finish_piece(kt1, buf ^ 1, pc);
+        }
+        if (kp == CK / 2 - 1) {
+#pragma unroll
+          for (int pc = m; pc < NPIECE; pc += 8) issue_piece(kt2, pc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int tb = 0; tb < 2; ++tb)
-            acc[q][cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][q][cb], v[tb][q], acc[q][cb][tb], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      if (kp == CK / 2 - 2) __syncthreads();
     }
-    if (kt + 1 < nK) finish(kt + 1, buf ^ 1);
-    __syncthreads();       // also drains the LDS-DMA of the next weight tile (vmcnt(0) before s_barrier)
   }
+  __syncthreads();          // the last block's operand prefetch has read LDS: drain before the epilogue reuses it
 
-  // ---- epilogue: Y = A^T M A.  Columns (j) in registers, rows (i = wave) through LDS; wave (ea, etb) then owns output
-  //      row parity ea of tile block etb.  C/D map: tile = lane&31, channel row = (r&3) + 8*(r>>2) + 4*(lane>>5). ----
-  float* const Zs = Ab;                       // [wave i][b][tile block][r][lane]
-  float* const s_sum = Pb;                    // [wave][BM]
+  // ---- epilogue: Y = A^T M A.  Columns (j) in registers, rows (i) through LDS, one channel block at a time (64 KB, the
+  //      dead weight buffers); wave (i, tb) then owns output row parity i&1 of its tile block for the accumulator rows
+  //      r = 8*(i>>1) .. +7.  C/D map: tile = lane&31, channel row = (r&3) + 8*(r>>2) + 4*(lane>>5). ----
+  float* const Zs = Ab;                       // [i][b][tile block][r][lane]
+  float* const s_sum = Pb;                    // [slot = (i&1)*2 + tb][BM]
   float* const s_sq = Pb + 4 * BM;
-  const int ea = wave & 1, etb = wave >> 1;
-  const int tile = etb * 32 + li, eg = tile / (GH * GW), ety = (tile % (GH * GW)) / GW, etx = tile % GW;
+  const int ea = wi & 1, r0 = 8 * (wi >> 1), slot = ea * 2 + wtb;
+  const int tile = wtb * 32 + li, eg = tile / (GH * GW), ety = (tile % (GH * GW)) / GW, etx = tile % GW;
   const int img = gtab[eg][0], oy = gtab[eg][1] + 2 * ety + ea, ox = gtab[eg][2] + 2 * etx;
   const bool ok0 = gtab[eg][3] && oy < a.Hq && ox < a.Wq, ok1 = ok0 && ox + 1 < a.Wq;
   long long obase;
@@ -268,23 +295,22 @@ __global__ __launch_bounds__(256) void wino_kernel(WArgs a) {
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0_ = acc[0][cb][tb][r], m1 = acc[1][cb][tb][r], m2 = acc[2][cb][tb][r], m3 = acc[3][cb][tb][r];
-        Zs[(((wave * 2 + 0) * 2 + tb) * 16 + r) * 64 + lane] = m0_ + m1 + m2;
-        Zs[(((wave * 2 + 1) * 2 + tb) * 16 + r) * 64 + lane] = m1 - m2 - m3;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float m0_ = acc[0][cb][r], m1 = acc[1][cb][r], m2 = acc[2][cb][r], m3 = acc[3][cb][r];
+      Zs[(((wi * 2 + 0) * 2 + wtb) * 16 + r) * 64 + lane] = m0_ + m1 + m2;
+      Zs[(((wi * 2 + 1) * 2 + wtb) * 16 + r) * 64 + lane] = m1 - m2 - m3;
+    }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = r0 + rr;
       const int lrow = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, row = m0 + lrow;
       const bool rok = row < a.Cout;
       const float bias = (a.bias && rok) ? a.bias[row] : 0.f;
       float y[2];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const float* z = Zs + ((b * 2 + etb) * 16 + r) * 64 + lane;       // + i * (2*2*16*64)
+        const float* z = Zs + ((b * 2 + wtb) * 16 + r) * 64 + lane;       // + i * (2*2*16*64)
         const float z1 = z[1 * 4096], z2 = z[2 * 4096];
         y[b] = (ea == 0 ? z[0] + z1 + z2 : z1 - z2 - z[3 * 4096]) + bias;
       }
@@ -304,15 +330,15 @@ __global__ __launch_bounds__(256) void wino_kernel(WArgs a) {
         s = half_sum(s);
         q = half_sum(q);
         if (li == 0) {
-          s_sum[wave * BM + lrow] = s;
-          s_sq[wave * BM + lrow] = q;
+          s_sum[slot * BM + lrow] = s;
+          s_sq[slot * BM + lrow] = q;
         }
       }
     }
     __syncthreads();
   }
   if (want_stats) {
-    for (int rr = tid; rr < BM; rr += 256) {
+    for (int rr = tid; rr < BM; rr += NT) {
       const int row = m0 + rr;
       if (row < a.Cout) {
         float s = 0.f, q = 0.f;
@@ -393,10 +419,10 @@ template <bool SUB, bool RAW>
 static void wn_launch_cfg(const WArgs& a, int cfg, dim3 grid, hipStream_t st) {
   // <G, GH, GW, PWG, GS>: strides chosen so that the 32 tiles of a tile block read 64 distinct banks (see header)
   switch (cfg) {
-    case 0: hipLaunchKernelGGL((wino_kernel<1, 8, 8, 24, 18 * 24, SUB, RAW>), grid, dim3(256), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((wino_kernel<2, 2, 16, 48, 6 * 48, SUB, RAW>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((wino_kernel<4, 4, 4, 12, 160, SUB, RAW>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((wino_kernel<8, 1, 8, 18, 80, SUB, RAW>), grid, dim3(256), 0, st, a); break;
+    case 0: hipLaunchKernelGGL((wino_kernel<1, 8, 8, 24, 18 * 24, SUB, RAW>), grid, dim3(WN_THREADS), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((wino_kernel<2, 2, 16, 48, 6 * 48, SUB, RAW>), grid, dim3(WN_THREADS), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((wino_kernel<4, 4, 4, 12, 160, SUB, RAW>), grid, dim3(WN_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL((wino_kernel<8, 1, 8, 18, 80, SUB, RAW>), grid, dim3(WN_THREADS), 0, st, a); break;
   }
 }
 

@@ -1,0 +1,63 @@
+"""Times single convolution calls of the C ABI on cuda:0 (forward / data gradient / weight gradient) at the layer
+shapes of the bench step.  Usage: python tools/conv_bench.py [fwd|dgrad|wgrad] [--prec f32|bf16] [--reps 20]
+Prints ms and direct-form TFLOP/s (2*N*Ho*Wo*Cout*Cin*k*k / time) per shape and the kernel family that served it."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import avsep_amd as P  # noqa: E402
+
+SHAPES = [
+    # N, Cin, H, W, Cout, k, stride, pad, dil
+    (64, 1024, 32, 32, 256, 3, 1, 1, 1),
+    (64, 512, 64, 64, 128, 3, 1, 1, 1),
+    (64, 256, 128, 128, 64, 3, 1, 1, 1),
+    (64, 1024, 16, 16, 512, 3, 1, 1, 1),
+    (192, 64, 56, 56, 64, 3, 1, 1, 1),
+    (192, 128, 28, 28, 128, 3, 1, 1, 1),
+    (192, 256, 14, 14, 256, 3, 1, 1, 1),
+    (192, 512, 14, 14, 512, 3, 1, 2, 2),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("mode", nargs="?", default="fwd", choices=["fwd", "dgrad", "wgrad"])
+    ap.add_argument("--prec", default="f32")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--affine", action="store_true", help="forward over a folded BatchNorm + ReLU input, with statistics")
+    o = ap.parse_args()
+    K = P.kernels
+    K.set_precision(o.prec)
+    dev = torch.device("cuda:0")
+    for (N, Cin, H, W, Cout, k, s, p, d) in SHAPES:
+        x = torch.randn(N, Cin, H, W, device=dev)
+        w = torch.randn(Cout, Cin, k, k, device=dev) * 0.02
+        kw = {}
+        if o.affine:
+            kw = dict(sc0=torch.rand(Cin, device=dev) + 0.5, sh0=torch.randn(Cin, device=dev), act0=1)
+        cv = K.Conv(x, Cout, k, s, p, d, **kw)
+        st = K.zeros_stats(Cout, x) if o.affine else None
+        dy = torch.randn(N, Cout, cv.Ho, cv.Wo, device=dev)
+        wp = cv.pack(w, 1 if o.mode == "dgrad" else 0)
+        run = {"fwd": lambda: cv.fwd(wp, None, st), "dgrad": lambda: cv.dgrad(wp, dy), "wgrad": lambda: cv.wgrad(dy)}[o.mode]
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(o.reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / o.reps
+        fl = 2.0 * N * cv.Ho * cv.Wo * Cout * Cin * k * k
+        print("%-40s %-6s %-18s %8.3f ms %7.1f TFLOP/s" % ((N, Cin, H, W, Cout, k, s, p, d), o.mode, cv.kernel_name(o.mode, o.affine), ms,
+                                                           fl / ms / 1e9))
+
+
+if __name__ == "__main__":
+    main()
