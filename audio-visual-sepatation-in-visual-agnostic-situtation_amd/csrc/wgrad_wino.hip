@@ -1,0 +1,389 @@
+// Weight gradient of the 3x3 / stride 1 / 'same' convolutions (dilation 1 or 2) in the Winograd form, fp32:
+//     dW[kh][kw] = sum over 2x2 tiles of  G^T [ (A dY A^T) (.) (B^T d B) ] G        (the transpose of F(2x2, 3x3))
+// dY = the 2x2 cotangent tile, d = the 4x4 input tile around it, B^T as in conv_wino.hip,
+//     A = [[1,0],[1,1],[1,-1],[0,-1]],   G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]:
+// 16 products per tile and (co, ci) instead of the 36 of the direct form (conv3x3.hip's wgrad3x3_kernel: 48 ms of the
+// 153 ms fp32 step).  Per transform position xi = (i, j) this is a [Cout x tiles] x [tiles x Cin] GEMM whose K
+// dimension is the tile index, so one MFMA k-step consumes two tiles (lane half = tile parity) and BOTH operands are
+// transformed from LDS patches on their way into the MFMA:
+//   * a workgroup (8 waves, two per SIMD) owns 64 output x 64 input channels and sweeps the chunks (16 tiles each) of
+//     its K-split; wave (i, cib) owns transform row i for input-channel block cib and both output-channel blocks:
+//     4 x 2 accumulator tiles = 128 registers;
+//   * per k-step a lane reads the two dY rows of its tile (2 x ds_read_b64 per output-channel block) and the two input
+//     rows that B^T's row i combines (4 x ds_read_b64), 20 VALU make 8 + 4 fragments, 8 MFMAs consume them; lanes are
+//     CHANNELS here, so the per-channel LDS strides are 2 * odd words: 32 lanes x 8 bytes hit 64 distinct banks;
+//   * signs and the 1/2 factors of A and G are moved out of the loop (row 3 of A is used as (0, +1); the output
+//     transform applies s = (1, 1, 1, -1) and G^T once per workgroup);
+//   * staging follows conv_wino.hip: global loads of chunk c+2 and LDS stores of chunk c+1 hang behind individual MFMAs
+//     of chunk c, one barrier per chunk; the folded BatchNorm affine + activation of the input (and the two-source
+//     concat: a 64-channel block lies in one source) are applied on the way in;
+//   * the workgroup writes one tap-major partial slab [split][tap][Cout][Cin]; conv3x3.hip's w3_reduce_kernel sums the
+//     slabs (deterministic, no atomics).
+// Dilation 2: the four parity sub-images are independent undilated problems that add into the same dW.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WW_THREADS = 512, WW_B = 64;      // 64 x 64 channels per workgroup
+constexpr int WW_GT_MAX = 512;                  // group records of one K-split kept in LDS (host-checked)
+
+struct WwArgs {
+  int N, C0, C1, Cin, H, W, Cout;
+  int Hq, Wq, gyn, gxn, ngroups, nchunks, cps;  // (sub-)image geometry, tile groups, chunks in total / per split
+  int gridM, gridC, act0, act1;
+  const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
+  const float* dy;
+  float* out;                                   // slabs [split][tap][Cout][Cin]
+};
+
+// G groups of GH x GW tiles per chunk (G*GH*GW = 16 tiles = 8 k-steps); SUB: dilation 2 (parity sub-images); RAW: the
+// input needs no affine and no activation.
+template <int G, int GH, int GW, bool SUB, bool RAW>
+__global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
+  static_assert(G * GH * GW == 16 && (GW % 2) == 0, "16 tiles per chunk, tile pairs inside a tile row");
+  constexpr int NT = WW_THREADS, B = WW_B;
+  constexpr int PHG = 2 * GH + 2, PCG = 2 * GW + 2, GE = PHG * PCG, XCH = G * GE;
+  constexpr int PSX = ((XCH / 2) | 1) * 2;                   // per-channel stride of the input patch: 2 * odd words
+  constexpr int GD = 4 * GH * GW, PSD = 66;                  // dY: 64 pixels per channel per chunk, stride 2 * 33
+  constexpr int NX = B * XCH, PEX = (NX + NT - 1) / NT;      // input patch elements per thread
+  constexpr int PED = SUB ? 8 : 4;                           // dY pieces per thread: float2 (scalar when strided)
+  constexpr int NPIECE = PEX + PED;
+  static_assert(NPIECE <= 32, "valid bits of the pieces fit one register");
+  constexpr int X_FLOATS = B * PSX, D_FLOATS = B * PSD;
+  static_assert(2 * X_FLOATS >= 8 * 16 * 64, "epilogue exchange fits the input buffers");
+  __shared__ __attribute__((aligned(16))) float Xs[2][X_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Ds[2][D_FLOATS];
+  __shared__ __attribute__((aligned(16))) int gtab[WW_GT_MAX][4];     // {element offset of the group origin, y0-1, x0-1, valid}
+  __shared__ float aff_sc[B], aff_sh[B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+  const int wi = wave & 3, wcb = wave >> 2;
+  const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
+  const int m0 = mt * B, c0 = ct * B;
+  const long long HW = (long long)a.H * a.W;
+  const int iHW = a.H * a.W;
+  // the 64-channel input block lies in one source
+  const bool src1 = c0 >= a.C0;
+  const float* const xs = src1 ? a.x1 : a.x0;
+  const int Cs = src1 ? a.C1 : a.C0, cs0 = src1 ? c0 - a.C0 : c0;
+  const float slope = act_slope(src1 ? a.act1 : a.act0);
+  const int ch0 = split * a.cps, nc = min(a.cps, a.nchunks - ch0);     // chunks [ch0, ch0 + nc) of this split
+
+  // ---- group records of the whole split: origin offsets (input and dY), patch origin, validity ----
+  const int per = a.gyn * a.gxn;
+  for (int e = tid; e < nc * G; e += NT) {
+    const int gid = ch0 * G + e, gidc = min(gid, a.ngroups - 1);
+    const int img = gidc / per, gy = (gidc % per) / a.gxn, gx = gidc % a.gxn;
+    const int y0 = gy * 2 * GH, x0 = gx * 2 * GW;
+    const int n = SUB ? img >> 2 : img, ph = SUB ? (img >> 1) & 1 : 0, pw = SUB ? img & 1 : 0;
+    // element offset of sub-pixel (y0, x0) inside channel 0 of image n, WITHOUT the channel term (added per tensor)
+    const int pix = SUB ? (2 * y0 + ph) * a.W + 2 * x0 + pw : y0 * a.W + x0;
+    gtab[e][0] = n;
+    gtab[e][1] = pix;
+    gtab[e][2] = (y0 << 16) | x0;
+    gtab[e][3] = gid < a.ngroups;
+  }
+  if constexpr (!RAW) {
+    if (tid < B) {
+      const float* sc = src1 ? a.sc1 : a.sc0;
+      const float* sh = src1 ? a.sh1 : a.sh0;
+      aff_sc[tid] = sc ? sc[cs0 + tid] : 1.f;
+      aff_sh[tid] = sc ? sh[cs0 + tid] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- per-thread piece constants ----
+  // input patch element e: channel ci, group g, patch row r, column col.  xk = (LDS slot | r << 14 | col << 18 | g << 23 |
+  // ci << 24); xrel = element offset relative to the group origin (patch origin is one pixel up-left of it)
+  constexpr int PSTEP = SUB ? 2 : 1;
+  unsigned xk[PEX];
+#pragma unroll
+  for (int e = 0; e < PEX; ++e) {
+    const int idx = min(tid + NT * e, NX - 1);
+    const int ci = idx / XCH, rem = idx % XCH, g = rem / GE, r = (rem % GE) / PCG, col = rem % PCG;
+    xk[e] = (unsigned)(ci * PSX + rem) | ((unsigned)r << 14) | ((unsigned)col << 18) | ((unsigned)g << 23) | ((unsigned)ci << 24);
+  }
+  // dY piece e: channel co, group g, row, column (pairs when !SUB).  dk = (LDS slot | row << 14 | col << 18 | g << 23 | co << 24)
+  unsigned dk[PED];
+#pragma unroll
+  for (int e = 0; e < PED; ++e) {
+    const int idx = tid + NT * e;                           // B * 64 / (SUB ? 1 : 2) pieces: exact multiples of NT
+    const int co = SUB ? idx / 64 : idx / 32, rem = SUB ? idx % 64 : (idx % 32) * 2;      // pixel index inside the channel's 64
+    const int g = rem / GD, row = (rem % GD) / (2 * GW), col = rem % (2 * GW);
+    dk[e] = (unsigned)(co * PSD + rem) | ((unsigned)row << 14) | ((unsigned)col << 18) | ((unsigned)g << 23) | ((unsigned)co << 24);
+  }
+  float xraw[PEX];
+  f32x2 draw[SUB ? 1 : PED];
+  float draws[SUB ? PED : 1];
+  unsigned okbits = 0;
+
+  // piece pc of chunk c: global load into registers (address 0 of the tensor when masked; zeroed at the store)
+  auto issue_piece = [&](int c, int pc) __attribute__((always_inline)) {
+    if (pc < PEX) {
+      const int e = pc;
+      const int g = G > 1 ? (xk[e] >> 23) & 1 : 0;
+      const int4 gt = *reinterpret_cast<const int4*>(gtab[c * G + g]);
+      const int r = (xk[e] >> 14) & 15, col = (xk[e] >> 18) & 31;
+      const int y = (gt.z >> 16) - 1 + r, x = (gt.z & 0xffff) - 1 + col;
+      const bool ok = (PEX * NT == NX || tid + NT * e < NX) && gt.w && (unsigned)y < (unsigned)a.Hq && (unsigned)x < (unsigned)a.Wq;
+      // 24-bit multiplies (full rate): channel < 64, H * W < 2^24, rows / columns < 2^15 (host-checked)
+      const int rel = __mul24((int)(xk[e] >> 24), iHW) + __mul24(__mul24(r - 1, a.W) + (col - 1), PSTEP);
+      const unsigned off = (unsigned)((long long)(gt.x * Cs + cs0) * HW) + (unsigned)(gt.y + rel);
+      xraw[e] = xs[ok ? off : 0u];
+      okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
+    } else if (pc < NPIECE) {
+      const int e = pc - PEX;
+      const int g = G > 1 ? (dk[e] >> 23) & 1 : 0;
+      const int4 gt = *reinterpret_cast<const int4*>(gtab[c * G + g]);
+      const int row = (dk[e] >> 14) & 15, col = (dk[e] >> 18) & 31;
+      const int y = (gt.z >> 16) + row, x = (gt.z & 0xffff) + col;
+      const int co = (int)(dk[e] >> 24);
+      const bool ok = gt.w && y < a.Hq && x < a.Wq && m0 + co < a.Cout;      // W even, col even: a pair is in or out together
+      const int rel = __mul24(co, iHW) + __mul24(__mul24(row, a.W) + col, PSTEP);
+      const unsigned off = (unsigned)((long long)(gt.x * a.Cout + m0) * HW) + (unsigned)(gt.y + rel);
+      if constexpr (SUB) draws[e] = a.dy[ok ? off : 0u];
+      else draw[e] = *reinterpret_cast<const f32x2*>(a.dy + (ok ? off : 0u));
+      okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
+    }
+  };
+  auto finish_piece = [&](int buf, int pc) __attribute__((always_inline)) {
+    const bool ok = (okbits >> pc) & 1u;
+    if (pc < PEX) {
+      const int e = pc;
+      float v = xraw[e];
+      if constexpr (!RAW) {
+        const int ci = xk[e] >> 24;
+        v = act_by_slope(fmaf(v, aff_sc[ci], aff_sh[ci]), slope);
+      }
+      if (PEX * NT == NX || tid + NT * e < NX) Xs[buf][xk[e] & 0x3fffu] = ok ? v : 0.f;
+    } else if (pc < NPIECE) {
+      const int e = pc - PEX;
+      if constexpr (SUB) Ds[buf][dk[e] & 0x3fffu] = ok ? draws[e] : 0.f;
+      else *reinterpret_cast<f32x2*>(&Ds[buf][dk[e] & 0x3fffu]) = ok ? draw[e] : f32x2{0.f, 0.f};
+    }
+  };
+
+  f32x16 acc[4][2];         // [xi column j][output-channel block]
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][cb][r] = 0.f;
+
+  // row i of B^T on the input:  t = d[rA] + sgn * d[rB]   ((0,2,-) (1,2,+) (2,1,-) (1,3,-))
+  const int rA = wi == 0 ? 0 : (wi == 2 ? 2 : 1), rB = wi == 2 ? 1 : (wi == 3 ? 3 : 2);
+  const float sgn = wi == 1 ? 1.f : -1.f;
+  // row i of A on dY (row 3 taken as (0, +1): the sign moves to the output transform):  t = al * dY[0] + be * dY[1]
+  const float al = wi == 3 ? 0.f : 1.f, be = wi == 0 ? 0.f : (wi == 2 ? -1.f : 1.f);
+  const int lbx = (wcb * 32 + li) * PSX + 2 * lk;            // + rA/rB * PCG + tile(ks)
+  const int lbd = li * PSD + 2 * lk;                         // + cob * 32 * PSD + tile(ks)
+
+  float u[2][2][4], v[2][4];           // [slot][output-channel block][j], [slot][j]
+  f32x2 d0[2], d1[2], xa[2], xb[2];    // dY rows 0 / 1 per output-channel block; input rows A / B as two column pairs
+  float ta[2][2], tb[4];
+  auto tile_x = [&](int ks) { const int t = 2 * ks, g = t / (GH * GW), ty = (t % (GH * GW)) / GW, tx = t % GW; return g * GE + 2 * ty * PCG + 2 * tx; };
+  auto tile_d = [&](int ks) { const int t = 2 * ks, g = t / (GH * GW), ty = (t % (GH * GW)) / GW, tx = t % GW; return g * GD + 2 * ty * 2 * GW + 2 * tx; };
+  auto read_d = [&](int buf, int ks, int cob) __attribute__((always_inline)) {
+    const float* p = &Ds[buf][lbd + cob * 32 * PSD + tile_d(ks)];
+    d0[cob] = *reinterpret_cast<const f32x2*>(p);
+    d1[cob] = *reinterpret_cast<const f32x2*>(p + 2 * GW);
+  };
+  auto read_x = [&](int buf, int ks, int which) __attribute__((always_inline)) {
+    const float* p = &Xs[buf][lbx + (which ? rB : rA) * PCG + tile_x(ks)];
+    f32x2* dst = which ? xb : xa;
+    dst[0] = *reinterpret_cast<const f32x2*>(p);
+    dst[1] = *reinterpret_cast<const f32x2*>(p + 2);
+  };
+  auto xform_d = [&](int slot, int cob, int st) __attribute__((always_inline)) {
+    if (st == 0) { ta[cob][0] = fmaf(be, d1[cob][0], al * d0[cob][0]); ta[cob][1] = fmaf(be, d1[cob][1], al * d0[cob][1]); }
+    if (st == 1) {
+      u[slot][cob][0] = ta[cob][0];
+      u[slot][cob][1] = ta[cob][0] + ta[cob][1];
+      u[slot][cob][2] = ta[cob][0] - ta[cob][1];
+      u[slot][cob][3] = ta[cob][1];
+    }
+  };
+  auto xform_x = [&](int slot, int st) __attribute__((always_inline)) {
+    if (st == 0) {
+      tb[0] = fmaf(sgn, xb[0][0], xa[0][0]); tb[1] = fmaf(sgn, xb[0][1], xa[0][1]);
+      tb[2] = fmaf(sgn, xb[1][0], xa[1][0]); tb[3] = fmaf(sgn, xb[1][1], xa[1][1]);
+    }
+    if (st == 1) { v[slot][0] = tb[0] - tb[2]; v[slot][1] = tb[1] + tb[2]; v[slot][2] = tb[2] - tb[1]; v[slot][3] = tb[1] - tb[3]; }
+  };
+
+  // ---- prologue: chunk 0 -> buffer 0, loads of chunk 1 in flight, operands of k-step 0 ----
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(0, pc);
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) finish_piece(0, pc);
+  __syncthreads();
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(min(1, nc - 1), pc);
+  read_d(0, 0, 0); read_d(0, 0, 1); read_x(0, 0, 0); read_x(0, 0, 1);
+#pragma unroll
+  for (int cob = 0; cob < 2; ++cob) { xform_d(0, cob, 0); xform_d(0, cob, 1); }
+  xform_x(0, 0); xform_x(0, 1);
+
+  // ---- main loop: 8 k-steps (blocks of 8 MFMAs) per chunk; everything else rides behind individual MFMAs:
+  //   MFMA 0-3 : the next block's four operand read pairs          MFMA 3-7 : its transforms (20 VALU)
+  //   blocks 4-5 : LDS stores of chunk c+1 (loaded six blocks earlier); barrier after block 6 (the last block that
+  //   reads this chunk's buffers); block 7 prefetches from the other buffer; blocks 6-7 : global loads of chunk c+2.
+  // Staging is unconditional (chunk indices clamped): a branch around it would fork the accumulator state.
+  for (int c = 0; c < nc; ++c) {
+    const int buf = c & 1;
+    const int c2 = min(c + 2, nc - 1);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      const int nbuf = ks < 7 ? buf : buf ^ 1, nks = ks < 7 ? ks + 1 : 0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int q = m >> 1, cb = m & 1;
+        acc[q][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[cur][cb][q], v[cur][q], acc[q][cb], 0, 0, 0);
+        if (m == 0) read_d(nbuf, nks, 0);
+        if (m == 1) read_d(nbuf, nks, 1);
+        if (m == 2) read_x(nbuf, nks, 0);
+        if (m == 3) { read_x(nbuf, nks, 1); xform_d(nxt, 0, 0); }
+        if (m == 4) { xform_d(nxt, 0, 1); xform_d(nxt, 1, 0); }
+        if (m == 5) xform_d(nxt, 1, 1);
+        if (m == 6) xform_x(nxt, 0);
+        if (m == 7) xform_x(nxt, 1);
+        if (ks == 4 || ks == 5) {
+#pragma unroll
+          for (int pc = (ks - 4) * 8 + m; pc < NPIECE; pc += 16) finish_piece(buf ^ 1, pc);
+        }
+        if (ks == 6 || ks == 7) {
+#pragma unroll
+          for (int pc = (ks - 6) * 8 + m; pc < NPIECE; pc += 16) issue_piece(c2, pc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ks == 6) __syncthreads();
+    }
+  }
+  __syncthreads();          // the last block's operand prefetch has read LDS: drain before the epilogue reuses it
+
+  // ---- epilogue: dW = G^T (s s^T . M) G.  Columns (j -> kw) in registers; rows (i -> kh) through LDS, one (output-channel
+  //      block, kw) plane set at a time: 8 waves x 16 x 64 floats = 32 KB.  Wave (i < 3, cib) then owns tap row kh = i.
+  //      C/D map: ci = lane & 31, co row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5). ----
+  float* const Zs = &Xs[0][0];                // [wave][r][lane]
+  const int ci = c0 + wcb * 32 + li;
+#pragma unroll
+  for (int cob = 0; cob < 2; ++cob) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0_ = acc[0][cob][r], m1 = acc[1][cob][r], m2 = acc[2][cob][r], m3 = acc[3][cob][r];
+        const float z = kw == 0 ? m0_ + 0.5f * (m1 + m2) : (kw == 1 ? 0.5f * (m1 - m2) : 0.5f * (m1 + m2) - m3);
+        Zs[(wave * 16 + r) * 64 + lane] = z;
+      }
+      __syncthreads();
+      if (wi < 3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* z = Zs + ((wcb * 4) * 16 + r) * 64 + lane;      // + i * 1024
+          const float z1 = z[1024], z2 = z[2048];
+          const float w_ = wi == 0 ? z[0] + 0.5f * (z1 + z2) : (wi == 1 ? 0.5f * (z1 - z2) : 0.5f * (z1 + z2) - z[3072]);
+          const int co = m0 + cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (co < a.Cout && ci < a.Cin) a.out[(((long long)split * 9 + wi * 3 + kw) * a.Cout + co) * a.Cin + ci] = w_;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side (called from conv.hip)
+// ---------------------------------------------------------------------------
+int w3_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st);      // conv3x3.hip
+
+struct WwCfg { int gh, gw, g; };     // pixels per group, groups per chunk
+static const WwCfg WW_CFGS[3] = {{4, 16, 1}, {8, 8, 1}, {2, 16, 2}};
+static int ww_cfg(int Hq, int Wq) {
+  static const char* force = getenv("AVSEP_WINOW_CFG");
+  if (force && force[0] >= '0' && force[0] <= '2') return force[0] - '0';
+  int best = 0;
+  double be = 0.0;
+  for (int c = 0; c < 3; ++c) {
+    const WwCfg& k = WW_CFGS[c];
+    const double e = (double)Hq * Wq / ((double)roundup(Hq, k.gh) * roundup(Wq, k.gw));
+    if (e > be + 0.03) { be = e; best = c; }
+  }
+  return best;
+}
+struct WwPlan { int Hq, Wq, cfg, gyn, gxn, ngroups, nchunks, gridM, gridC, splits, cps; };
+static WwPlan ww_plan(const avsep_conv_desc* d) {
+  WwPlan p{};
+  const bool sub = d->dil == 2;
+  p.Hq = sub ? (d->H + 1) / 2 : d->H;
+  p.Wq = sub ? (d->W + 1) / 2 : d->W;
+  p.cfg = ww_cfg(p.Hq, p.Wq);
+  const WwCfg& k = WW_CFGS[p.cfg];
+  p.gyn = cdiv(p.Hq, k.gh);
+  p.gxn = cdiv(p.Wq, k.gw);
+  p.ngroups = d->N * (sub ? 4 : 1) * p.gyn * p.gxn;
+  p.nchunks = cdiv(p.ngroups, k.g);
+  p.gridM = cdiv(d->Cout, WW_B);
+  p.gridC = cdiv(d->Cin, WW_B);
+  // one workgroup per CU (512 threads x ~230 registers): aim at ~3 rounds of 256, at least 8 chunks per split, and no
+  // more group records per split than the LDS table holds
+  int want = cdiv(768, p.gridM * p.gridC);
+  const int maxs = p.nchunks / 8 > 0 ? p.nchunks / 8 : 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  p.cps = cdiv(p.nchunks, want);
+  if (p.cps * k.g > WW_GT_MAX) p.cps = WW_GT_MAX / k.g;
+  p.splits = cdiv(p.nchunks, p.cps);
+  return p;
+}
+
+bool ww_applicable(const avsep_conv_desc* d) {
+  static const bool off = getenv("AVSEP_NO_WINOGRAD") != nullptr || getenv("AVSEP_NO_WINOGRAD_WGRAD") != nullptr;
+  if (off || d->prec != AVSEP_PREC_F32) return false;
+  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil) || d->up2x) return false;
+  if ((d->H & 1) || (d->W & 1) || d->H < (d->dil == 1 ? 8 : 14) || d->W < (d->dil == 1 ? 8 : 14)) return false;
+  const int C1 = d->Cin - d->C0;
+  if (d->Cin % WW_B || d->C0 % WW_B || d->Cout < 48 || (C1 != 0 && C1 != d->C0)) return false;
+  if (d->H >= 32768 || d->W >= 32768 || (long long)d->H * d->W >= (1 << 24)) return false;   // 24-bit offset arithmetic
+  if ((long long)d->N * (d->C0 > d->Cout ? d->C0 : d->Cout) * d->H * d->W >= 0x7fffffffLL) return false;   // 32-bit element offsets
+  const WwPlan p = ww_plan(d);
+  return (long long)p.gridM * p.gridC * p.splits >= 192 && p.nchunks >= 8;
+}
+size_t ww_workspace_floats(const avsep_conv_desc* d) {
+  const WwPlan p = ww_plan(d);
+  return (size_t)p.splits * 9 * d->Cout * d->Cin;
+}
+
+template <bool SUB, bool RAW>
+static void ww_launch_cfg(const WwArgs& a, int cfg, dim3 grid, hipStream_t st) {
+  switch (cfg) {
+    case 0: hipLaunchKernelGGL((winow_kernel<1, 2, 8, SUB, RAW>), grid, dim3(WW_THREADS), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((winow_kernel<1, 4, 4, SUB, RAW>), grid, dim3(WW_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL((winow_kernel<2, 1, 8, SUB, RAW>), grid, dim3(WW_THREADS), 0, st, a); break;
+  }
+}
+
+int ww_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st) {
+  const WwPlan p = ww_plan(d);
+  WwArgs a{};
+  a.N = d->N; a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.Hq = p.Hq; a.Wq = p.Wq; a.gyn = p.gyn; a.gxn = p.gxn; a.ngroups = p.ngroups; a.nchunks = p.nchunks; a.cps = p.cps;
+  a.gridM = p.gridM; a.gridC = p.gridC; a.act0 = d->act0; a.act1 = d->act1;
+  a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
+  a.dy = dy; a.out = ws;
+  const bool raw = !d->scale0 && !d->scale1 && d->act0 == AVSEP_ACT_NONE && (a.C1 == 0 || d->act1 == AVSEP_ACT_NONE);
+  dim3 grid((unsigned)(p.gridM * p.gridC), (unsigned)p.splits);
+  const bool sub = d->dil == 2;
+  if (sub && raw) ww_launch_cfg<true, true>(a, p.cfg, grid, st);
+  else if (sub) ww_launch_cfg<true, false>(a, p.cfg, grid, st);
+  else if (raw) ww_launch_cfg<false, true>(a, p.cfg, grid, st);
+  else ww_launch_cfg<false, false>(a, p.cfg, grid, st);
+  AVSEP_LAUNCH_CHECK();
+  return w3_reduce(ws, dw, (long long)d->Cout * d->Cin, p.splits, st);
+}

@@ -70,6 +70,11 @@ CONV_CASES = [
     (260, 48, 14, 14, 56, 3, 1, 2, 2),     # dilation 2: the four 7x7 parity sub-images, odd sub-image size
     (80, 48, 28, 28, 56, 3, 1, 2, 2),      # dilation 2 at 28x28: 14x14 sub-images on the 1x8-tile groups
     (72, 48, 20, 36, 72, 3, 1, 1, 1),      # ragged group grid (H, W not multiples of the group)
+    # wgrad_wino.hip: Winograd weight gradient (Cin % 64 == 0, >= 192 workgroups); forward / dgrad as above
+    (64, 64, 32, 32, 80, 3, 1, 1, 1),      # 4x16-pixel chunks, ragged second output-channel tile
+    (300, 128, 14, 14, 56, 3, 1, 1, 1),    # two 2x16-pixel groups per chunk (14x14), two input-channel tiles
+    (260, 128, 14, 14, 56, 3, 1, 2, 2),    # dilation 2: 7x7 parity sub-images on 8x8-pixel chunks, strided dY loads
+    (40, 64, 20, 36, 72, 3, 1, 1, 1),      # ragged group grid
 ]
 
 
@@ -194,17 +199,22 @@ def test_conv_virtual_input_winograd(dev):
     BatchNorm sums of the result."""
     K = _pkg().kernels
     g = torch.Generator().manual_seed(11)
-    N, C0, C1, Cout, H, W = 32, 24, 24, 72, 32, 32
+    N, C0, C1, Cout, H, W = 32, 64, 64, 72, 32, 32
     x0, x1 = torch.randn(N, C0, H, W, generator=g), torch.randn(N, C1, H, W, generator=g)
     sc0, sh0 = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g)
     sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g)
     w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.05
     a0 = F.leaky_relu(x0 * sc0.view(1, -1, 1, 1) + sh0.view(1, -1, 1, 1), 0.2)
     a1 = F.relu(x1 * sc1.view(1, -1, 1, 1) + sh1.view(1, -1, 1, 1))
-    y_ref = F.conv2d(torch.cat([a0, a1], 1), w, None, 1, 1)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(torch.cat([a0, a1], 1), wr, None, 1, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    y_ref = y_ref.detach()
     t = lambda z: z.to(dev)
     cv = K.Conv(t(x0), Cout, 3, 1, 1, x1=t(x1), sc0=t(sc0), sh0=t(sh0), act0=2, sc1=t(sc1), sh1=t(sh1), act1=1)
-    assert cv.kernel_name("fwd", True) == "wino_kernel"
+    assert cv.kernel_name("fwd", True) == "wino_kernel" and cv.kernel_name("wgrad") == "winow_kernel"
+    assert_close(cv.wgrad(t(dy))[0], wr.grad, 2e-5, "wgrad")
     st = K.zeros_stats(Cout, cv.like)
     assert_close(cv.fwd(cv.pack(t(w), 0), None, st), y_ref, 2e-5, "fwd")
     st_ref = torch.cat([y_ref.double().sum((0, 2, 3)), (y_ref.double() ** 2).sum((0, 2, 3))])
