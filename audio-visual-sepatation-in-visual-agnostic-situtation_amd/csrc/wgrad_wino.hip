@@ -44,19 +44,26 @@ template <int G, int GH, int GW, bool SUB, bool RAW>
 __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
   static_assert(G * GH * GW == 16 && (GW % 2) == 0, "16 tiles per chunk, tile pairs inside a tile row");
   constexpr int NT = WW_THREADS, B = WW_B;
-  constexpr int PHG = 2 * GH + 2, PCG = 2 * GW + 2, GE = PHG * PCG, XCH = G * GE;
+  // The input patch of a group is staged in even-aligned COLUMN PAIRS starting two pixels left of the group (pair k =
+  // pixels x0-2+2k, +1): one 8-byte global load, one mask and one offset per pair (W and x0 are even, so a pair is
+  // inside or outside the image together); in LDS pair k sits at columns 2k+1, 2k+2 of a (2*GW+6)-wide row so that the
+  // columns a tile reads (x0+2tx-1 .. +2) start at the even column 2tx+2.
+  constexpr int PHG = 2 * GH + 2, KP = GW + 2, PCG = 2 * GW + 6, GE = PHG * PCG, XCH = G * GE;
   constexpr int PSX = ((XCH / 2) | 1) * 2;                   // per-channel stride of the input patch: 2 * odd words
   constexpr int GD = 4 * GH * GW, PSD = 66;                  // dY: 64 pixels per channel per chunk, stride 2 * 33
-  constexpr int NX = B * XCH, PEX = (NX + NT - 1) / NT;      // input patch elements per thread
-  constexpr int PED = SUB ? 8 : 4;                           // dY pieces per thread: float2 (scalar when strided)
+  constexpr int PP = PHG * KP, NXG = B * PP;                 // column pairs per channel / per group
+  constexpr int PEG = (NXG + NT - 1) / NT, PEX = G * PEG;    // input pieces per thread: group-major, so the group of a piece is static
+  constexpr int PDG = (SUB ? B * GD : B * GD / 2) / NT;      // dY pieces per thread per group: float2 (scalar when strided)
+  constexpr int PED = G * PDG;
+  static_assert((SUB ? B * GD : B * GD / 2) % NT == 0, "whole dY pieces");
   constexpr int NPIECE = PEX + PED;
   static_assert(NPIECE <= 32, "valid bits of the pieces fit one register");
   constexpr int X_FLOATS = B * PSX, D_FLOATS = B * PSD;
-  static_assert(2 * X_FLOATS >= 8 * 16 * 64, "epilogue exchange fits the input buffers");
+  static_assert(X_FLOATS < (1 << 14) && 2 * X_FLOATS >= 8 * 16 * 64, "epilogue exchange fits the input buffers");
   __shared__ __attribute__((aligned(16))) float Xs[2][X_FLOATS];
   __shared__ __attribute__((aligned(16))) float Ds[2][D_FLOATS];
   __shared__ __attribute__((aligned(16))) int gtab[WW_GT_MAX][4];     // {element offset of the group origin, y0-1, x0-1, valid}
-  __shared__ float aff_sc[B], aff_sh[B];
+  __shared__ f32x2 aff[B];                     // (scale, shift) of the 64 input channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
   const int wi = wave & 3, wcb = wave >> 2;
@@ -89,80 +96,109 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
     if (tid < B) {
       const float* sc = src1 ? a.sc1 : a.sc0;
       const float* sh = src1 ? a.sh1 : a.sh0;
-      aff_sc[tid] = sc ? sc[cs0 + tid] : 1.f;
-      aff_sh[tid] = sc ? sh[cs0 + tid] : 0.f;
+      aff[tid] = f32x2{sc ? sc[cs0 + tid] : 1.f, sc ? sh[cs0 + tid] : 0.f};
     }
   }
   __syncthreads();
 
-  // ---- per-thread piece constants ----
-  // input patch element e: channel ci, group g, patch row r, column col.  xk = (LDS slot | r << 14 | col << 18 | g << 23 |
-  // ci << 24); xrel = element offset relative to the group origin (patch origin is one pixel up-left of it)
+  // ---- per-thread piece constants (the same for every chunk; only the group origins change) ----
+  // input piece (g, e): channel ci, patch row r, column pair k.  xk = LDS slot of the pair's first column | r << 14 | k << 18 |
+  // ci << 24; xrel = element offset from the patch origin (y0-1, x0-2).
   constexpr int PSTEP = SUB ? 2 : 1;
   unsigned xk[PEX];
+  int xrel[PEX];
 #pragma unroll
-  for (int e = 0; e < PEX; ++e) {
-    const int idx = min(tid + NT * e, NX - 1);
-    const int ci = idx / XCH, rem = idx % XCH, g = rem / GE, r = (rem % GE) / PCG, col = rem % PCG;
-    xk[e] = (unsigned)(ci * PSX + rem) | ((unsigned)r << 14) | ((unsigned)col << 18) | ((unsigned)g << 23) | ((unsigned)ci << 24);
+  for (int p = 0; p < PEX; ++p) {
+    const int g = p / PEG, e = p % PEG;
+    const int idx = min(tid + NT * e, NXG - 1);
+    const int ci = idx / PP, rem = idx % PP, r = rem / KP, k = rem % KP;
+    xk[p] = (unsigned)(ci * PSX + g * GE + r * PCG + 2 * k + 1) | ((unsigned)r << 14) | ((unsigned)k << 18) | ((unsigned)ci << 24);
+    xrel[p] = ci * iHW + (r * a.W + 2 * k) * PSTEP;
   }
-  // dY piece e: channel co, group g, row, column (pairs when !SUB).  dk = (LDS slot | row << 14 | col << 18 | g << 23 | co << 24)
+  // dY piece (g, e): channel co, row, column (pairs when !SUB) of the group.  dk = LDS slot | row << 14 | col << 18 | co << 24;
+  // drel = element offset from the group origin (y0, x0)
   unsigned dk[PED];
+  int drel[PED];
 #pragma unroll
-  for (int e = 0; e < PED; ++e) {
-    const int idx = tid + NT * e;                           // B * 64 / (SUB ? 1 : 2) pieces: exact multiples of NT
-    const int co = SUB ? idx / 64 : idx / 32, rem = SUB ? idx % 64 : (idx % 32) * 2;      // pixel index inside the channel's 64
-    const int g = rem / GD, row = (rem % GD) / (2 * GW), col = rem % (2 * GW);
-    dk[e] = (unsigned)(co * PSD + rem) | ((unsigned)row << 14) | ((unsigned)col << 18) | ((unsigned)g << 23) | ((unsigned)co << 24);
+  for (int p = 0; p < PED; ++p) {
+    const int g = p / PDG, e = p % PDG;
+    const int idx = tid + NT * e;
+    const int co = SUB ? idx / GD : idx / (GD / 2), rem = SUB ? idx % GD : (idx % (GD / 2)) * 2;    // pixel index inside the group
+    const int row = rem / (2 * GW), col = rem % (2 * GW);
+    dk[p] = (unsigned)(co * PSD + g * GD + rem) | ((unsigned)row << 14) | ((unsigned)col << 18) | ((unsigned)co << 24);
+    drel[p] = co * iHW + (row * a.W + col) * PSTEP;
   }
-  float xraw[PEX];
+  f32x2 xraw[PEX];
   f32x2 draw[SUB ? 1 : PED];
   float draws[SUB ? PED : 1];
-  unsigned okbits = 0;
+  unsigned okbits = 0, okhi = 0;     // piece valid; SUB: second pixel of an input pair valid (odd sub-image widths)
 
-  // piece pc of chunk c: global load into registers (address 0 of the tensor when masked; zeroed at the store)
-  auto issue_piece = [&](int c, int pc) __attribute__((always_inline)) {
-    if (pc < PEX) {
-      const int e = pc;
-      const int g = G > 1 ? (xk[e] >> 23) & 1 : 0;
+  // group records of the chunk being loaded, wave-uniform (scalar registers)
+  int g_n[G], g_pix[G], g_y0[G], g_x0[G], g_ok[G];
+  auto load_groups = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
       const int4 gt = *reinterpret_cast<const int4*>(gtab[c * G + g]);
-      const int r = (xk[e] >> 14) & 15, col = (xk[e] >> 18) & 31;
-      const int y = (gt.z >> 16) - 1 + r, x = (gt.z & 0xffff) - 1 + col;
-      const bool ok = (PEX * NT == NX || tid + NT * e < NX) && gt.w && (unsigned)y < (unsigned)a.Hq && (unsigned)x < (unsigned)a.Wq;
-      // 24-bit multiplies (full rate): channel < 64, H * W < 2^24, rows / columns < 2^15 (host-checked)
-      const int rel = __mul24((int)(xk[e] >> 24), iHW) + __mul24(__mul24(r - 1, a.W) + (col - 1), PSTEP);
-      const unsigned off = (unsigned)((long long)(gt.x * Cs + cs0) * HW) + (unsigned)(gt.y + rel);
-      xraw[e] = xs[ok ? off : 0u];
+      g_n[g] = __builtin_amdgcn_readfirstlane(gt.x);
+      g_pix[g] = __builtin_amdgcn_readfirstlane(gt.y);
+      g_y0[g] = __builtin_amdgcn_readfirstlane(gt.z >> 16);
+      g_x0[g] = __builtin_amdgcn_readfirstlane(gt.z & 0xffff);
+      g_ok[g] = __builtin_amdgcn_readfirstlane(gt.w);
+    }
+  };
+  // piece pc of the chunk whose groups are loaded: global load into registers (a safe in-image address when masked;
+  // zeroed at the store)
+  auto issue_piece = [&](int pc) __attribute__((always_inline)) {
+    if (pc < PEX) {
+      const int g = pc / PEG, e = pc % PEG;
+      const int r = (xk[pc] >> 14) & 15, k = (xk[pc] >> 18) & 31;
+      const int y = g_y0[g] - 1 + r, x = g_x0[g] - 2 + 2 * k;
+      const bool ok = (PEG * NT == NXG || tid + NT * e < NXG) && g_ok[g] && (unsigned)y < (unsigned)a.Hq && (unsigned)x < (unsigned)a.Wq;
+      // patch origin (y0-1, x0-2) of the group inside channel cs0 of image n (may lie before the tensor: never dereferenced
+      // unmasked); masked pieces read the group's own origin pixel
+      const float* pb = xs + ((long long)(g_n[g] * Cs + cs0) * HW + g_pix[g] - (a.W + 2) * PSTEP);
+      const unsigned off = ok ? (unsigned)xrel[pc] : (unsigned)((a.W + 2) * PSTEP);
+      if constexpr (SUB) {
+        const bool ok1 = ok && x + 1 < a.Wq;
+        xraw[pc][0] = pb[off];
+        xraw[pc][1] = pb[ok1 ? off + 2 : off];
+        okhi = (okhi & ~(1u << pc)) | ((unsigned)ok1 << pc);
+      } else {
+        xraw[pc] = *reinterpret_cast<const f32x2*>(pb + off);
+      }
       okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
     } else if (pc < NPIECE) {
-      const int e = pc - PEX;
-      const int g = G > 1 ? (dk[e] >> 23) & 1 : 0;
-      const int4 gt = *reinterpret_cast<const int4*>(gtab[c * G + g]);
-      const int row = (dk[e] >> 14) & 15, col = (dk[e] >> 18) & 31;
-      const int y = (gt.z >> 16) + row, x = (gt.z & 0xffff) + col;
-      const int co = (int)(dk[e] >> 24);
-      const bool ok = gt.w && y < a.Hq && x < a.Wq && m0 + co < a.Cout;      // W even, col even: a pair is in or out together
-      const int rel = __mul24(co, iHW) + __mul24(__mul24(row, a.W) + col, PSTEP);
-      const unsigned off = (unsigned)((long long)(gt.x * a.Cout + m0) * HW) + (unsigned)(gt.y + rel);
-      if constexpr (SUB) draws[e] = a.dy[ok ? off : 0u];
-      else draw[e] = *reinterpret_cast<const f32x2*>(a.dy + (ok ? off : 0u));
+      const int p = pc - PEX, g = p / PDG;
+      const int row = (dk[p] >> 14) & 15, col = (dk[p] >> 18) & 31, co = (int)(dk[p] >> 24);
+      const bool ok = g_ok[g] && g_y0[g] + row < a.Hq && g_x0[g] + col < a.Wq && m0 + co < a.Cout;   // W, col even: a pair is in or out together
+      const float* pb = a.dy + ((long long)(g_n[g] * a.Cout + m0) * HW + g_pix[g]);
+      const unsigned off = ok ? (unsigned)drel[p] : 0u;
+      if constexpr (SUB) draws[p] = pb[off];
+      else draw[p] = *reinterpret_cast<const f32x2*>(pb + off);
       okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
     }
   };
   auto finish_piece = [&](int buf, int pc) __attribute__((always_inline)) {
     const bool ok = (okbits >> pc) & 1u;
     if (pc < PEX) {
-      const int e = pc;
-      float v = xraw[e];
+      f32x2 v = xraw[pc];
       if constexpr (!RAW) {
-        const int ci = xk[e] >> 24;
-        v = act_by_slope(fmaf(v, aff_sc[ci], aff_sh[ci]), slope);
+        const int ci = xk[pc] >> 24;
+        const f32x2 ss = aff[ci];
+        v = __builtin_elementwise_fma(v, f32x2{ss[0], ss[0]}, f32x2{ss[1], ss[1]});       // v_pk_fma_f32 / v_pk_mul_f32
+        const f32x2 w2 = v * f32x2{slope, slope};
+        v = f32x2{fmaxf(v[0], w2[0]), fmaxf(v[1], w2[1])};
       }
-      if (PEX * NT == NX || tid + NT * e < NX) Xs[buf][xk[e] & 0x3fffu] = ok ? v : 0.f;
+      const bool ok1 = SUB ? (okhi >> pc) & 1u : ok;
+      if (PEG * NT == NXG || tid + NT * (pc % PEG) < NXG) {
+        float* q = &Xs[buf][xk[pc] & 0x3fffu];
+        q[0] = ok ? v[0] : 0.f;
+        q[1] = ok1 ? v[1] : 0.f;
+      }
     } else if (pc < NPIECE) {
-      const int e = pc - PEX;
-      if constexpr (SUB) Ds[buf][dk[e] & 0x3fffu] = ok ? draws[e] : 0.f;
-      else *reinterpret_cast<f32x2*>(&Ds[buf][dk[e] & 0x3fffu]) = ok ? draw[e] : f32x2{0.f, 0.f};
+      const int p = pc - PEX;
+      if constexpr (SUB) Ds[buf][dk[p] & 0x3fffu] = ok ? draws[p] : 0.f;
+      else *reinterpret_cast<f32x2*>(&Ds[buf][dk[p] & 0x3fffu]) = ok ? draw[p] : f32x2{0.f, 0.f};
     }
   };
 
@@ -185,7 +221,7 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
   float u[2][2][4], v[2][4];           // [slot][output-channel block][j], [slot][j]
   f32x2 d0[2], d1[2], xa[2], xb[2];    // dY rows 0 / 1 per output-channel block; input rows A / B as two column pairs
   float ta[2][2], tb[4];
-  auto tile_x = [&](int ks) { const int t = 2 * ks, g = t / (GH * GW), ty = (t % (GH * GW)) / GW, tx = t % GW; return g * GE + 2 * ty * PCG + 2 * tx; };
+  auto tile_x = [&](int ks) { const int t = 2 * ks, g = t / (GH * GW), ty = (t % (GH * GW)) / GW, tx = t % GW; return g * GE + 2 * ty * PCG + 2 * tx + 2; };
   auto tile_d = [&](int ks) { const int t = 2 * ks, g = t / (GH * GW), ty = (t % (GH * GW)) / GW, tx = t % GW; return g * GD + 2 * ty * 2 * GW + 2 * tx; };
   auto read_d = [&](int buf, int ks, int cob) __attribute__((always_inline)) {
     const float* p = &Ds[buf][lbd + cob * 32 * PSD + tile_d(ks)];
@@ -216,13 +252,15 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
   };
 
   // ---- prologue: chunk 0 -> buffer 0, loads of chunk 1 in flight, operands of k-step 0 ----
+  load_groups(0);
 #pragma unroll
-  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(0, pc);
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(pc);
 #pragma unroll
   for (int pc = 0; pc < NPIECE; ++pc) finish_piece(0, pc);
   __syncthreads();
+  load_groups(min(1, nc - 1));
 #pragma unroll
-  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(min(1, nc - 1), pc);
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(pc);
   read_d(0, 0, 0); read_d(0, 0, 1); read_x(0, 0, 0); read_x(0, 0, 1);
 #pragma unroll
   for (int cob = 0; cob < 2; ++cob) { xform_d(0, cob, 0); xform_d(0, cob, 1); }
@@ -257,8 +295,9 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
           for (int pc = (ks - 4) * 8 + m; pc < NPIECE; pc += 16) finish_piece(buf ^ 1, pc);
         }
         if (ks == 6 || ks == 7) {
+          if (ks == 6 && m == 0) load_groups(c2);
 #pragma unroll
-          for (int pc = (ks - 6) * 8 + m; pc < NPIECE; pc += 16) issue_piece(c2, pc);
+          for (int pc = (ks - 6) * 8 + m; pc < NPIECE; pc += 16) issue_piece(pc);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
