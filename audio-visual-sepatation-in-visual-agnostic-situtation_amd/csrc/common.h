@@ -53,6 +53,21 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
+// Same sum on the DPP path of the vector ALU (no LDS traffic, no ds_bpermute latency): four row rotations leave every lane
+// of a 16-lane row with the row's total, a row broadcast then adds row 0 into row 1 (and row 2 into row 3).  The result
+// is valid in lanes 16-31 and 48-63 ONLY: the caller lets lane (lane & 31) == 31 write it.
+__device__ __forceinline__ float half_sum_hi(float v) {
+#define AVSEP_DPP_ADD(ctrl, rmask)                                                                                     \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  AVSEP_DPP_ADD(0x128, 0xf);   // row_ror:8
+  AVSEP_DPP_ADD(0x124, 0xf);   // row_ror:4
+  AVSEP_DPP_ADD(0x122, 0xf);   // row_ror:2
+  AVSEP_DPP_ADD(0x121, 0xf);   // row_ror:1
+  AVSEP_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3 (rows 0 and 2 add the zero of `old`)
+#undef AVSEP_DPP_ADD
+  return v;
+}
+
 // Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (id % 8 equal under
 // round-robin dispatch) receive CONSECUTIVE logical ids, so tiles that re-read the same
 // operand sit behind one L2.  Speed only, never correctness.

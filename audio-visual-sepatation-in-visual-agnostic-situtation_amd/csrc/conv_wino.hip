@@ -327,9 +327,9 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
         q = y[0] * y[0];
       }
       if (want_stats) {
-        s = half_sum(s);
-        q = half_sum(q);
-        if (li == 0) {
+        s = half_sum_hi(s);
+        q = half_sum_hi(q);
+        if (li == 31) {
           s_sum[slot * BM + lrow] = s;
           s_sq[slot * BM + lrow] = q;
         }
@@ -400,7 +400,7 @@ bool wn_applicable(const avsep_conv_desc* d, int mode) {
   }
   if ((long long)d->N * (mode == 0 ? d->C0 : d->Cout) * d->H * d->W >= 0xffffffffLL) return false;   // 32-bit element offsets
   const WnPlan p = wn_plan(d, mode);
-  return (long long)p.ptiles * p.gridM >= 256;      // one workgroup per CU at least
+  return (long long)p.ptiles * p.gridM >= 128;      // at least half of the CUs busy (below that the split-K im2col path wins)
 }
 size_t wn_packed_floats(const avsep_conv_desc* d, int mode) {
   const int cin = mode == 0 ? d->Cin : d->Cout, cout = mode == 0 ? d->Cout : d->Cin;

@@ -317,9 +317,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(C3Args a) {
         }
       }
       if (want_stats) {
-        s = half_sum(s);
-        q = half_sum(q);
-        if (li == 0) {
+        s = half_sum_hi(s);
+        q = half_sum_hi(q);
+        if (li == 31) {
           s_sum[wn * BM + lrow] = s;
           s_sq[wn * BM + lrow] = q;
         }
