@@ -50,28 +50,37 @@ struct WArgs {
 //   mode 1 (dgrad)  : g = w[ch][col][2-kh][2-kw] ("in" = co)      column ci
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int gridM, int nK,
                                  int mode) {
+  // one thread per (input channel, output channel): 9 contiguous taps in, U = G g G^T (16 values) out; consecutive
+  // threads are consecutive output channels, so every one of the 16 stores is coalesced
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)nK * gridM * WN_A_FLOATS) return;
-  const int col = (int)(i % WN_BM), row = (int)((i / WN_BM) % (WN_CK * 16));
-  const int mt = (int)((i / WN_A_FLOATS) % gridM), kt = (int)(i / ((long long)WN_A_FLOATS * gridM));
-  const int parity = row & 1, xi = (row >> 1) & 15, cpl = row >> 5;
+  if (i >= (long long)nK * gridM * (WN_CK * WN_BM)) return;
+  const int col = (int)(i % WN_BM), parity = (int)((i / WN_BM) & 1), cpl = (int)((i / (2 * WN_BM)) % (WN_CK / 2));
+  const int mt = (int)((i / (WN_CK * WN_BM)) % gridM), kt = (int)(i / ((long long)WN_CK * WN_BM * gridM));
   const int ch = kt * WN_CK + 2 * cpl + parity, co = mt * WN_BM + col;
   float g[9];
   const bool ok = mode == 0 ? (ch < Cin && co < Cout) : (ch < Cout && co < Cin);
 #pragma unroll
   for (int k = 0; k < 9; ++k)
     g[k] = !ok ? 0.f : (mode == 0 ? w[((long long)co * Cin + ch) * 9 + k] : w[((long long)ch * Cin + co) * 9 + (8 - k)]);
-  const float Gm[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-  const int ti = xi >> 2, tj = xi & 3;
-  float u = 0.f;
+  // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: rows of G g (4 x 3), then columns
+  float t[4][3];
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {
-    float rsum = 0.f;
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) rsum += Gm[tj][kw] * g[kh * 3 + kw];
-    u += Gm[ti][kh] * rsum;
+  for (int c = 0; c < 3; ++c) {
+    const float s02 = 0.5f * (g[c] + g[6 + c]), h1 = 0.5f * g[3 + c];
+    t[0][c] = g[c];
+    t[1][c] = s02 + h1;
+    t[2][c] = s02 - h1;
+    t[3][c] = g[6 + c];
   }
-  out[i] = u;
+  float* o = out + ((long long)kt * gridM + mt) * WN_A_FLOATS + (cpl * 32 + parity) * WN_BM + col;
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const float s02 = 0.5f * (t[ti][0] + t[ti][2]), h1 = 0.5f * t[ti][1];
+    o[(ti * 4 + 0) * 2 * WN_BM] = t[ti][0];
+    o[(ti * 4 + 1) * 2 * WN_BM] = s02 + h1;
+    o[(ti * 4 + 2) * 2 * WN_BM] = s02 - h1;
+    o[(ti * 4 + 3) * 2 * WN_BM] = t[ti][2];
+  }
 }
 
 // G groups of GH x GW tiles (G*GH*GW = 64); PWG = LDS row stride of a group's patch, GS = LDS stride between groups
@@ -409,7 +418,7 @@ size_t wn_packed_floats(const avsep_conv_desc* d, int mode) {
 int wn_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st) {
   const int cin = mode == 0 ? d->Cin : d->Cout, cout = mode == 0 ? d->Cout : d->Cin;
   const int nK = cin / WN_CK, gridM = cdiv(cout, WN_BM);
-  const long long total = (long long)nK * gridM * WN_A_FLOATS;
+  const long long total = (long long)nK * gridM * (WN_CK * WN_BM);
   hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, packed, d->Cout, d->Cin, gridM, nK, mode);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;

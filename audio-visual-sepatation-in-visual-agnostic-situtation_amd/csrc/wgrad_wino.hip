@@ -370,10 +370,20 @@ static WwPlan ww_plan(const avsep_conv_desc* d) {
   p.nchunks = cdiv(p.ngroups, k.g);
   p.gridM = cdiv(d->Cout, WW_B);
   p.gridC = cdiv(d->Cin, WW_B);
-  // one workgroup per CU (512 threads x ~230 registers): aim at ~3 rounds of 256, at least 8 chunks per split, and no
-  // more group records per split than the LDS table holds
-  int want = cdiv(768, p.gridM * p.gridC);
-  const int maxs = p.nchunks / 8 > 0 ? p.nchunks / 8 : 1;
+  // one workgroup per CU (512 threads x ~230 registers) and no overlap between consecutive workgroups of a CU: ONE round
+  // of workgroups is the fastest plan at every layer shape of the step (measured 256 / 384 / 512 / 768 / 1024 / 1536
+  // workgroups: 186 / 144 / 186 / 182 / 180 / 173 TFLOP/s at 1024 -> 256 @ 32x32, 121 / 91 / 101 / 83 / 71 / 63 at
+  // 64 -> 64 @ 56x56) — fewer epilogues and slabs, no partial last round
+  static const char* tw = getenv("AVSEP_WINOW_WGS");      // tuning: target workgroup count
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  int want = (tw ? atoi(tw) : cus) / (p.gridM * p.gridC);
+  const int maxs = p.nchunks / 8 > 0 ? p.nchunks / 8 : 1;    // at least 8 chunks per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   p.cps = cdiv(p.nchunks, want);
@@ -392,7 +402,7 @@ bool ww_applicable(const avsep_conv_desc* d) {
   if (d->H >= 32768 || d->W >= 32768 || (long long)d->H * d->W >= (1 << 24)) return false;   // 24-bit offset arithmetic
   if ((long long)d->N * (d->C0 > d->Cout ? d->C0 : d->Cout) * d->H * d->W >= 0x7fffffffLL) return false;   // 32-bit element offsets
   const WwPlan p = ww_plan(d);
-  return (long long)p.gridM * p.gridC * p.splits >= 192 && p.nchunks >= 8;
+  return (long long)p.gridM * p.gridC * p.splits >= 128 && p.nchunks >= 8;
 }
 size_t ww_workspace_floats(const avsep_conv_desc* d) {
   const WwPlan p = ww_plan(d);
