@@ -19,7 +19,9 @@
 //     concat: a 64-channel block lies in one source) are applied on the way in;
 //   * the workgroup writes one tap-major partial slab [split][tap][Cout][Cin]; conv3x3.hip's w3_reduce_kernel sums the
 //     slabs (deterministic, no atomics).
-// Dilation 2: the four parity sub-images are independent undilated problems that add into the same dW.
+// Dilation 2: the four parity sub-images are independent undilated problems that add into the same dW; a chunk takes
+// the same 4x8 sub-pixel region of BOTH column parities of one row-parity class, so its loads stay 8-byte pairs of
+// adjacent full-resolution pixels.
 #include <stdlib.h>
 
 #include "common.h"
@@ -52,9 +54,13 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
   constexpr int PSX = ((XCH / 2) | 1) * 2;                   // per-channel stride of the input patch: 2 * odd words
   constexpr int GD = 4 * GH * GW, PSD = 66;                  // dY: 64 pixels per channel per chunk, stride 2 * 33
   constexpr int PP = PHG * KP, NXG = B * PP;                 // column pairs per channel / per group
-  constexpr int PEG = (NXG + NT - 1) / NT, PEX = G * PEG;    // input pieces per thread: group-major, so the group of a piece is static
-  constexpr int PDG = (SUB ? B * GD : B * GD / 2) / NT;      // dY pieces per thread per group: float2 (scalar when strided)
-  constexpr int PED = G * PDG;
+  // Dilation 2 (SUB): the G = 2 groups of a chunk are the two COLUMN parities of one region of one row-parity class, so an
+  // 8-byte load of two adjacent full-resolution pixels feeds one element of each group (stride-2 scalar loads otherwise).
+  static_assert(!SUB || G == 2, "dilation 2: the two groups of a chunk are the column parities");
+  constexpr int SG = SUB ? 1 : G;                            // groups as the STAGING code sees them
+  constexpr int PEG = (NXG + NT - 1) / NT, PEX = SG * PEG;   // input pieces per thread: group-major, so the group of a piece is static
+  constexpr int PDG = (SUB ? B * GD : B * GD / 2) / NT;      // dY pieces per thread per group: one float2 each
+  constexpr int PED = SG * PDG;
   static_assert((SUB ? B * GD : B * GD / 2) % NT == 0, "whole dY pieces");
   constexpr int NPIECE = PEX + PED;
   static_assert(NPIECE <= 32, "valid bits of the pieces fit one register");
@@ -80,13 +86,13 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
 
   // ---- group records of the whole split: origin offsets (input and dY), patch origin, validity ----
   const int per = a.gyn * a.gxn;
-  for (int e = tid; e < nc * G; e += NT) {
-    const int gid = ch0 * G + e, gidc = min(gid, a.ngroups - 1);
-    const int img = gidc / per, gy = (gidc % per) / a.gxn, gx = gidc % a.gxn;
+  for (int e = tid; e < nc * SG; e += NT) {
+    const int gid = ch0 * SG + e, gidc = min(gid, a.ngroups - 1);
+    const int img = gidc / per, gy = (gidc % per) / a.gxn, gx = gidc % a.gxn;     // SUB: img = 2 * n + row parity
     const int y0 = gy * 2 * GH, x0 = gx * 2 * GW;
-    const int n = SUB ? img >> 2 : img, ph = SUB ? (img >> 1) & 1 : 0, pw = SUB ? img & 1 : 0;
-    // element offset of sub-pixel (y0, x0) inside channel 0 of image n, WITHOUT the channel term (added per tensor)
-    const int pix = SUB ? (2 * y0 + ph) * a.W + 2 * x0 + pw : y0 * a.W + x0;
+    const int n = SUB ? img >> 1 : img, ph = SUB ? img & 1 : 0;
+    // element offset of (sub-)pixel (y0, x0) [column parity 0] inside channel 0 of image n, WITHOUT the channel term
+    const int pix = SUB ? (2 * y0 + ph) * a.W + 2 * x0 : y0 * a.W + x0;
     gtab[e][0] = n;
     gtab[e][1] = pix;
     gtab[e][2] = (y0 << 16) | x0;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
     const int idx = min(tid + NT * e, NXG - 1);
     const int ci = idx / PP, rem = idx % PP, r = rem / KP, k = rem % KP;
     xk[p] = (unsigned)(ci * PSX + g * GE + r * PCG + 2 * k + 1) | ((unsigned)r << 14) | ((unsigned)k << 18) | ((unsigned)ci << 24);
-    xrel[p] = ci * iHW + (r * a.W + 2 * k) * PSTEP;
+    xrel[p] = ci * iHW + (r * a.W + 2 * k) * PSTEP;          // SUB: full-resolution row 2r, column 4k from the patch origin
   }
   // dY piece (g, e): channel co, row, column (pairs when !SUB) of the group.  dk = LDS slot | row << 14 | col << 18 | co << 24;
   // drel = element offset from the group origin (y0, x0)
@@ -123,22 +129,21 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
   for (int p = 0; p < PED; ++p) {
     const int g = p / PDG, e = p % PDG;
     const int idx = tid + NT * e;
-    const int co = SUB ? idx / GD : idx / (GD / 2), rem = SUB ? idx % GD : (idx % (GD / 2)) * 2;    // pixel index inside the group
+    const int co = SUB ? idx / GD : idx / (GD / 2), rem = SUB ? idx % GD : (idx % (GD / 2)) * 2;    // (sub-)pixel index inside the group
     const int row = rem / (2 * GW), col = rem % (2 * GW);
     dk[p] = (unsigned)(co * PSD + g * GD + rem) | ((unsigned)row << 14) | ((unsigned)col << 18) | ((unsigned)co << 24);
     drel[p] = co * iHW + (row * a.W + col) * PSTEP;
   }
-  f32x2 xraw[PEX];
-  f32x2 draw[SUB ? 1 : PED];
-  float draws[SUB ? PED : 1];
+  f32x2 xraw[PEX], xraw2[SUB ? PEX : 1];   // SUB: (column parity 0, 1) at sub-column x, and at x + 1
+  f32x2 draw[PED];                          // SUB: (column parity 0, 1) of one sub-pixel
   unsigned okbits = 0, okhi = 0;     // piece valid; SUB: second pixel of an input pair valid (odd sub-image widths)
 
   // group records of the chunk being loaded, wave-uniform (scalar registers)
-  int g_n[G], g_pix[G], g_y0[G], g_x0[G], g_ok[G];
+  int g_n[SG], g_pix[SG], g_y0[SG], g_x0[SG], g_ok[SG];
   auto load_groups = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int4 gt = *reinterpret_cast<const int4*>(gtab[c * G + g]);
+    for (int g = 0; g < SG; ++g) {
+      const int4 gt = *reinterpret_cast<const int4*>(gtab[c * SG + g]);
       g_n[g] = __builtin_amdgcn_readfirstlane(gt.x);
       g_pix[g] = __builtin_amdgcn_readfirstlane(gt.y);
       g_y0[g] = __builtin_amdgcn_readfirstlane(gt.z >> 16);
@@ -160,8 +165,8 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
       const unsigned off = ok ? (unsigned)xrel[pc] : (unsigned)((a.W + 2) * PSTEP);
       if constexpr (SUB) {
         const bool ok1 = ok && x + 1 < a.Wq;
-        xraw[pc][0] = pb[off];
-        xraw[pc][1] = pb[ok1 ? off + 2 : off];
+        xraw[pc] = *reinterpret_cast<const f32x2*>(pb + off);
+        xraw2[pc] = *reinterpret_cast<const f32x2*>(pb + (ok1 ? off + 2 : off));
         okhi = (okhi & ~(1u << pc)) | ((unsigned)ok1 << pc);
       } else {
         xraw[pc] = *reinterpret_cast<const f32x2*>(pb + off);
@@ -173,32 +178,44 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
       const bool ok = g_ok[g] && g_y0[g] + row < a.Hq && g_x0[g] + col < a.Wq && m0 + co < a.Cout;   // W, col even: a pair is in or out together
       const float* pb = a.dy + ((long long)(g_n[g] * a.Cout + m0) * HW + g_pix[g]);
       const unsigned off = ok ? (unsigned)drel[p] : 0u;
-      if constexpr (SUB) draws[p] = pb[off];
-      else draw[p] = *reinterpret_cast<const f32x2*>(pb + off);
+      draw[p] = *reinterpret_cast<const f32x2*>(pb + off);
       okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
     }
+  };
+  auto affine_act2 = [&](f32x2 v, int ci) __attribute__((always_inline)) {
+    const f32x2 ss = aff[ci];
+    v = __builtin_elementwise_fma(v, f32x2{ss[0], ss[0]}, f32x2{ss[1], ss[1]});       // v_pk_fma_f32 / v_pk_mul_f32
+    const f32x2 w2 = v * f32x2{slope, slope};
+    return f32x2{fmaxf(v[0], w2[0]), fmaxf(v[1], w2[1])};
   };
   auto finish_piece = [&](int buf, int pc) __attribute__((always_inline)) {
     const bool ok = (okbits >> pc) & 1u;
     if (pc < PEX) {
       f32x2 v = xraw[pc];
-      if constexpr (!RAW) {
-        const int ci = xk[pc] >> 24;
-        const f32x2 ss = aff[ci];
-        v = __builtin_elementwise_fma(v, f32x2{ss[0], ss[0]}, f32x2{ss[1], ss[1]});       // v_pk_fma_f32 / v_pk_mul_f32
-        const f32x2 w2 = v * f32x2{slope, slope};
-        v = f32x2{fmaxf(v[0], w2[0]), fmaxf(v[1], w2[1])};
-      }
+      if constexpr (!RAW) v = affine_act2(v, xk[pc] >> 24);
       const bool ok1 = SUB ? (okhi >> pc) & 1u : ok;
       if (PEG * NT == NXG || tid + NT * (pc % PEG) < NXG) {
         float* q = &Xs[buf][xk[pc] & 0x3fffu];
-        q[0] = ok ? v[0] : 0.f;
-        q[1] = ok1 ? v[1] : 0.f;
+        if constexpr (SUB) {                  // v = both column parities at sub-column x, v2 at x + 1: one element of each group each
+          f32x2 v2 = xraw2[pc];
+          if constexpr (!RAW) v2 = affine_act2(v2, xk[pc] >> 24);
+          q[0] = ok ? v[0] : 0.f;
+          q[1] = ok1 ? v2[0] : 0.f;
+          q[GE] = ok ? v[1] : 0.f;
+          q[GE + 1] = ok1 ? v2[1] : 0.f;
+        } else {
+          q[0] = ok ? v[0] : 0.f;
+          q[1] = ok1 ? v[1] : 0.f;
+        }
       }
     } else if (pc < NPIECE) {
       const int p = pc - PEX;
-      if constexpr (SUB) Ds[buf][dk[p] & 0x3fffu] = ok ? draws[p] : 0.f;
-      else *reinterpret_cast<f32x2*>(&Ds[buf][dk[p] & 0x3fffu]) = ok ? draw[p] : f32x2{0.f, 0.f};
+      if constexpr (SUB) {
+        Ds[buf][dk[p] & 0x3fffu] = ok ? draw[p][0] : 0.f;
+        Ds[buf][(dk[p] & 0x3fffu) + GD] = ok ? draw[p][1] : 0.f;
+      } else {
+        *reinterpret_cast<f32x2*>(&Ds[buf][dk[p] & 0x3fffu]) = ok ? draw[p] : f32x2{0.f, 0.f};
+      }
     }
   };
 
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
 int w3_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st);      // conv3x3.hip
 
 struct WwCfg { int gh, gw, g; };     // pixels per group, groups per chunk
-static const WwCfg WW_CFGS[3] = {{4, 16, 1}, {8, 8, 1}, {2, 16, 2}};
+static const WwCfg WW_CFGS[4] = {{4, 16, 1}, {8, 8, 1}, {2, 16, 2}, {4, 8, 1}};     // [3]: dilation 2 (4x8 sub-pixels x both column parities)
 static int ww_cfg(int Hq, int Wq) {
   static const char* force = getenv("AVSEP_WINOW_CFG");
   if (force && force[0] >= '0' && force[0] <= '2') return force[0] - '0';
@@ -362,11 +379,11 @@ static WwPlan ww_plan(const avsep_conv_desc* d) {
   const bool sub = d->dil == 2;
   p.Hq = sub ? (d->H + 1) / 2 : d->H;
   p.Wq = sub ? (d->W + 1) / 2 : d->W;
-  p.cfg = ww_cfg(p.Hq, p.Wq);
+  p.cfg = sub ? 3 : ww_cfg(p.Hq, p.Wq);
   const WwCfg& k = WW_CFGS[p.cfg];
   p.gyn = cdiv(p.Hq, k.gh);
   p.gxn = cdiv(p.Wq, k.gw);
-  p.ngroups = d->N * (sub ? 4 : 1) * p.gyn * p.gxn;
+  p.ngroups = d->N * (sub ? 2 : 1) * p.gyn * p.gxn;      // dilation 2: one staging group = a region of a ROW-parity class, both column parities
   p.nchunks = cdiv(p.ngroups, k.g);
   p.gridM = cdiv(d->Cout, WW_B);
   p.gridC = cdiv(d->Cin, WW_B);
@@ -411,10 +428,14 @@ size_t ww_workspace_floats(const avsep_conv_desc* d) {
 
 template <bool SUB, bool RAW>
 static void ww_launch_cfg(const WwArgs& a, int cfg, dim3 grid, hipStream_t st) {
+  if constexpr (SUB) {
+    hipLaunchKernelGGL((winow_kernel<2, 2, 4, true, RAW>), grid, dim3(WW_THREADS), 0, st, a);
+    return;
+  }
   switch (cfg) {
-    case 0: hipLaunchKernelGGL((winow_kernel<1, 2, 8, SUB, RAW>), grid, dim3(WW_THREADS), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((winow_kernel<1, 4, 4, SUB, RAW>), grid, dim3(WW_THREADS), 0, st, a); break;
-    default: hipLaunchKernelGGL((winow_kernel<2, 1, 8, SUB, RAW>), grid, dim3(WW_THREADS), 0, st, a); break;
+    case 0: hipLaunchKernelGGL((winow_kernel<1, 2, 8, false, RAW>), grid, dim3(WW_THREADS), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((winow_kernel<1, 4, 4, false, RAW>), grid, dim3(WW_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL((winow_kernel<2, 1, 8, false, RAW>), grid, dim3(WW_THREADS), 0, st, a); break;
   }
 }
 
