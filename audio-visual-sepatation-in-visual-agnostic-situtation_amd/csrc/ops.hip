@@ -1040,11 +1040,47 @@ __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_stats_kernel(const fl
   }
 }
 // pass 2: dy[i] = p * ([pre > 0] * sum_{windows that chose i} g) + q * y[i] + r
+// One (n, c) plane per blockIdx.y (per-channel constants in scalar registers, 32-bit indexing); a thread owns the pixel
+// pair (h, 2j), (h, 2j+1): the even pixel lies in window column j only, the odd one in j and j+1, an even row in window row
+// h/2 only, an odd one in (h-1)/2 and (h+1)/2 — at most four (index, gradient) pairs per thread, 8-byte loads and stores.
 __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_apply_kernel(const float* __restrict__ g, const int* __restrict__ idx,
                                                                         const float* __restrict__ y, const float* __restrict__ scale,
                                                                         const float* __restrict__ shift, const float* __restrict__ pqr,
-                                                                        int C, int NC, int H, int W, int Ho, int Wo,
-                                                                        float* __restrict__ dy) {
+                                                                        int C, int H, int W, int Ho, int Wo, float* __restrict__ dy) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int nc = blockIdx.y, c = nc % C, Wh = W >> 1;
+  const float sc = scale[c], sh = shift[c], cp = pqr[c], cq = pqr[C + c], cr = pqr[2 * C + c];
+  const float* yp = y + (long long)nc * H * W;
+  float* dp = dy + (long long)nc * H * W;
+  const float* gp = g + (long long)nc * Ho * Wo;
+  const int* ip = idx + (long long)nc * Ho * Wo;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * Wh; i += gridDim.x * 256) {
+    const int h = i / Wh, j = i - h * Wh, w = 2 * j, self = h * W + w;
+    const f32x2 yv = *reinterpret_cast<const f32x2*>(yp + self);
+    float s0 = 0.f, s1 = 0.f;
+    const int ho0 = h >> 1, nho = (h & 1) && ho0 + 1 < Ho ? 2 : 1;
+    const bool right = j + 1 < Wo;
+    for (int a = 0; a < nho; ++a) {
+      const int o = (ho0 + a) * Wo + j;
+      const int i0 = ip[o];
+      const float g0 = gp[o];
+      if (i0 == self) s0 += g0;
+      if (i0 == self + 1) s1 += g0;
+      if (right) {
+        if (ip[o + 1] == self + 1) s1 += gp[o + 1];
+      }
+    }
+    if (!(fmaf(yv[0], sc, sh) > 0.f)) s0 = 0.f;
+    if (!(fmaf(yv[1], sc, sh) > 0.f)) s1 = 0.f;
+    *reinterpret_cast<f32x2*>(dp + self) = f32x2{fmaf(cp, s0, fmaf(cq, yv[0], cr)), fmaf(cp, s1, fmaf(cq, yv[1], cr))};
+  }
+}
+// odd widths: one pixel per thread
+__global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_apply1_kernel(const float* __restrict__ g, const int* __restrict__ idx,
+                                                                         const float* __restrict__ y, const float* __restrict__ scale,
+                                                                         const float* __restrict__ shift, const float* __restrict__ pqr,
+                                                                         int C, int NC, int H, int W, int Ho, int Wo,
+                                                                         float* __restrict__ dy) {
   const long long total = (long long)NC * H * W;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int w = (int)(i % W), h = (int)((i / W) % H);
@@ -1079,8 +1115,14 @@ extern "C" int avsep_maxpool_bn_relu_bwd_apply(const float* g, const int32_t* id
   if (!g || !idx || !y || !scale || !shift || !pqr || !dy || N <= 0 || C <= 0 || H <= 0 || W <= 0) return AVSEP_ERR_ARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * C * H * W;
-  hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply_kernel, dim3((int)min((total + 255) / 256, (long long)262144)), dim3(256), 0,
-                     (hipStream_t)stream, g, idx, y, scale, shift, pqr, C, N * C, H, W, Ho, Wo, dy);
+  if ((W & 1) == 0 && (long long)N * C <= 65535 && (long long)H * W < 0x7fffffffLL) {
+    const int per = H * (W / 2), gx = (per + 255) / 256 < 64 ? (per + 255) / 256 : 64;
+    hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply_kernel, dim3(gx, N * C), dim3(256), 0, (hipStream_t)stream, g, idx, y, scale,
+                       shift, pqr, C, H, W, Ho, Wo, dy);
+  } else {
+    hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply1_kernel, dim3((int)min((total + 255) / 256, (long long)262144)), dim3(256), 0,
+                       (hipStream_t)stream, g, idx, y, scale, shift, pqr, C, N * C, H, W, Ho, Wo, dy);
+  }
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
