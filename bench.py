@@ -143,7 +143,7 @@ def pmc_traffic(family, prec="f32"):
     if row is None:
         return None
     return {"traffic_bytes_per_step": row.get("traffic_bytes_per_step"), "batch": table.get("batch"),
-            "source": "profiles/pmc_traffic.json: " + table.get("command", "")}
+            "source": "profiles/%s: %s" % (os.path.basename(path), table.get("command", ""))}
 
 
 def physical_cores():
