@@ -561,6 +561,9 @@ bool w3_applicable(const avsep_conv_desc* d);
 bool ww_applicable(const avsep_conv_desc* d);
 size_t ww_workspace_floats(const avsep_conv_desc* d);
 int ww_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
+bool w4d_applicable(const avsep_conv_desc* d);      // 4x4 / stride 2 on the same skeleton (direct form)
+size_t w4d_workspace_floats(const avsep_conv_desc* d);
+int w4d_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 bool c4_applicable(const avsep_conv_desc* d, int mode);
 size_t c4_packed_floats(const avsep_conv_desc* d, int mode);
 int c4_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
@@ -850,6 +853,7 @@ extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (wb_applicable(d)) return wb_workspace_floats(d) * sizeof(float);
   if (w4b_applicable(d)) return w4b_workspace_floats(d) * sizeof(float);
   if (ww_applicable(d)) return ww_workspace_floats(d) * sizeof(float);
+  if (w4d_applicable(d)) return w4d_workspace_floats(d) * sizeof(float);
   if (w3_applicable(d)) return w3_workspace_floats(d) * sizeof(float);
   WgradPlan p = wgrad_plan(d);
   if (p.splits <= 1) return 0;
@@ -866,10 +870,11 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   if (need > workspace_bytes || (need && !workspace)) return AVSEP_ERR_WORKSPACE;
   if (smallco_applicable(d)) return smallco_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
   if (head_applicable(d)) return head_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
-  if (wb_applicable(d) || w4b_applicable(d) || ww_applicable(d) || w3_applicable(d)) {
+  if (wb_applicable(d) || w4b_applicable(d) || ww_applicable(d) || w4d_applicable(d) || w3_applicable(d)) {
     int rc3 = wb_applicable(d) ? wb_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : w4b_applicable(d) ? w4b_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : ww_applicable(d) ? ww_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
+              : w4d_applicable(d) ? w4d_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
                                   : w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
     if (rc3) return rc3;
     if (dbias) {
@@ -932,6 +937,7 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
   if (wb_applicable(d)) return "wgradbf_kernel";
   if (w4b_applicable(d)) return "wgrad4bf_kernel";
   if (ww_applicable(d)) return "winow_kernel";
+  if (w4d_applicable(d)) return "wgrad4d_kernel";
   if (w3_applicable(d)) return "wgrad3x3_kernel";
   return "igemm_kernel<wgrad>";
 }

@@ -223,6 +223,12 @@ __global__ void w4_reduce_kernel(const float* __restrict__ ws, float* __restrict
     reinterpret_cast<float4*>(out + cc * 16)[t] = float4{s[4 * t], s[4 * t + 1], s[4 * t + 2], s[4 * t + 3]};
 }
 
+int w4_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st) {
+  hipLaunchKernelGGL(w4_reduce_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, ws, dw, P, splits);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
 static inline bool w4_enabled() { return getenv("AVSEP_NO_BF16_KERNELS") == nullptr && getenv("AVSEP_NO_BF16_WGRAD") == nullptr; }
 
 bool w4b_applicable(const avsep_conv_desc* d) {

@@ -354,6 +354,215 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
   }
 }
 
+// ===========================================================================
+// 4x4 / stride 2 / pad 1 weight gradient (the U-Net encoder's down convs, audio_net.py:57-58,170-171) on the same skeleton.
+// An output pixel (oy, ox) reads the input window rows 2oy-1 .. 2oy+2, columns 2ox-1 .. 2ox+2 — exactly the 4x4 input tile
+// of Winograd tile (oy, ox) — and dW[kh][kw] accumulates dY[oy][ox] * d[kh][kw]: the 16 taps ARE the 16 accumulator
+// positions, with identity transforms.  Same staging of the input patch, same wave layout (wave (kh, ci block) owns the
+// four taps of row kh for both output-channel blocks), no VALU in the operand path (one ds_read_b32 per dY fragment, two
+// ds_read_b64 per input row), no exchange in the epilogue.  K-step = two output pixels, a chunk = 16 of them.
+// ===========================================================================
+struct W4dArgs {
+  int N, Cin, H, W, Cout, Ho, Wo;
+  int gyn, gxn, ngroups, nchunks, cps;
+  int gridM, gridC, act0;
+  const float *x0, *sc0, *sh0;
+  const float* dy;
+  float* out;                                   // slabs [split][16 taps][Cout][Cin]
+};
+
+template <int G, int GH, int GW, bool RAW>
+__global__ __launch_bounds__(WW_THREADS) void wgrad4d_kernel(W4dArgs a) {
+  static_assert(G * GH * GW == 16 && (GW % 2) == 0, "16 output pixels per chunk, pixel pairs inside a row");
+  constexpr int NT = WW_THREADS, B = WW_B;
+  constexpr int PHG = 2 * GH + 2, KP = GW + 2, PCG = 2 * GW + 6, GE = PHG * PCG, XCH = G * GE;
+  constexpr int PSX = ((XCH / 2) | 1) * 2;
+  constexpr int GD = GH * GW, PSD = 17;                      // dY: 16 output pixels per channel per chunk, odd stride (32 banks)
+  constexpr int PP = PHG * KP, NXG = B * PP;
+  constexpr int PEG = (NXG + NT - 1) / NT, PEX = G * PEG;
+  static_assert(B * GD / 2 * G == NT, "one dY pair per thread and chunk");
+  constexpr int NPIECE = PEX + 1;
+  static_assert(NPIECE <= 32, "valid bits of the pieces fit one register");
+  constexpr int X_FLOATS = B * PSX, D_FLOATS = B * PSD;
+  static_assert(X_FLOATS < (1 << 14), "LDS slot field");
+  __shared__ __attribute__((aligned(16))) float Xs[2][X_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Ds[2][D_FLOATS];
+  __shared__ __attribute__((aligned(16))) int gtab[WW_GT_MAX][4];
+  __shared__ f32x2 aff[B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+  const int wi = wave & 3, wcb = wave >> 2;
+  const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
+  const int m0 = mt * B, c0 = ct * B;
+  const long long HW = (long long)a.H * a.W, HWo = (long long)a.Ho * a.Wo;
+  const int iHW = a.H * a.W, iHWo = a.Ho * a.Wo;
+  const float slope = act_slope(a.act0);
+  const int ch0 = split * a.cps, nc = min(a.cps, a.nchunks - ch0);
+
+  const int per = a.gyn * a.gxn;
+  for (int e = tid; e < nc * G; e += NT) {
+    const int gid = ch0 * G + e, gidc = min(gid, a.ngroups - 1);
+    const int img = gidc / per, gy = (gidc % per) / a.gxn, gx = gidc % a.gxn;
+    const int y0 = gy * 2 * GH, x0 = gx * 2 * GW;             // input-pixel origin of the group (= 2 * output origin)
+    gtab[e][0] = img;
+    gtab[e][1] = y0 * a.W + x0;
+    gtab[e][2] = (y0 << 16) | x0;
+    gtab[e][3] = gid < a.ngroups;
+  }
+  if constexpr (!RAW) {
+    if (tid < B) aff[tid] = f32x2{a.sc0 ? a.sc0[c0 + tid] : 1.f, a.sc0 ? a.sh0[c0 + tid] : 0.f};
+  }
+  __syncthreads();
+
+  unsigned xk[PEX];
+  int xrel[PEX];
+#pragma unroll
+  for (int p = 0; p < PEX; ++p) {
+    const int g = p / PEG, e = p % PEG;
+    const int idx = min(tid + NT * e, NXG - 1);
+    const int ci = idx / PP, rem = idx % PP, r = rem / KP, k = rem % KP;
+    xk[p] = (unsigned)(ci * PSX + g * GE + r * PCG + 2 * k + 1) | ((unsigned)r << 14) | ((unsigned)k << 18) | ((unsigned)ci << 24);
+    xrel[p] = ci * iHW + r * a.W + 2 * k;
+  }
+  // the thread's dY pair: group dg, channel dco, output row drow, output column pair dcol of the group
+  constexpr int DPG = B * GD / 2;                             // pairs per group
+  const int dg = tid / DPG, dco = (tid % DPG) / (GD / 2), drem = (tid % (GD / 2)) * 2, drow = drem / GW, dcol = drem % GW;
+  const int dslot = dco * PSD + dg * GD + drem, drel = dco * iHWo + drow * a.Wo + dcol;
+  f32x2 xraw[PEX], draw;
+  unsigned okbits = 0;
+
+  int g_n[G], g_pix[G], g_y0[G], g_x0[G], g_ok[G];
+  auto load_groups = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int4 gt = *reinterpret_cast<const int4*>(gtab[c * G + g]);
+      g_n[g] = __builtin_amdgcn_readfirstlane(gt.x);
+      g_pix[g] = __builtin_amdgcn_readfirstlane(gt.y);
+      g_y0[g] = __builtin_amdgcn_readfirstlane(gt.z >> 16);
+      g_x0[g] = __builtin_amdgcn_readfirstlane(gt.z & 0xffff);
+      g_ok[g] = __builtin_amdgcn_readfirstlane(gt.w);
+    }
+  };
+  auto issue_piece = [&](int pc) __attribute__((always_inline)) {
+    if (pc < PEX) {
+      const int g = pc / PEG, e = pc % PEG;
+      const int r = (xk[pc] >> 14) & 15, k = (xk[pc] >> 18) & 31;
+      const int y = g_y0[g] - 1 + r, x = g_x0[g] - 2 + 2 * k;
+      const bool ok = (PEG * NT == NXG || tid + NT * e < NXG) && g_ok[g] && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+      const float* pb = a.x0 + ((long long)(g_n[g] * a.Cin + c0) * HW + g_pix[g] - (a.W + 2));
+      xraw[pc] = *reinterpret_cast<const f32x2*>(pb + (ok ? (unsigned)xrel[pc] : (unsigned)(a.W + 2)));
+      okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
+    } else if (pc < NPIECE) {
+      // the group index of the thread's dY pair is a lane value when G > 1: select among the scalar records
+      int n = g_n[0], y0 = g_y0[0], x0 = g_x0[0], gok = g_ok[0];
+#pragma unroll
+      for (int g = 1; g < G; ++g)
+        if (dg == g) { n = g_n[g]; y0 = g_y0[g]; x0 = g_x0[g]; gok = g_ok[g]; }
+      const int oy = (y0 >> 1) + drow, ox = (x0 >> 1) + dcol;
+      const bool ok = gok && oy < a.Ho && ox < a.Wo && m0 + dco < a.Cout;       // Wo, dcol even: a pair is in or out together
+      const unsigned off = (unsigned)((long long)(n * a.Cout + m0) * HWo) + (unsigned)(__mul24(y0 >> 1, a.Wo) + (x0 >> 1) + drel);
+      draw = *reinterpret_cast<const f32x2*>(a.dy + (ok ? off : 0u));
+      okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
+    }
+  };
+  auto finish_piece = [&](int buf, int pc) __attribute__((always_inline)) {
+    const bool ok = (okbits >> pc) & 1u;
+    if (pc < PEX) {
+      f32x2 v = xraw[pc];
+      if constexpr (!RAW) {
+        const f32x2 ss = aff[xk[pc] >> 24];
+        v = __builtin_elementwise_fma(v, f32x2{ss[0], ss[0]}, f32x2{ss[1], ss[1]});
+        const f32x2 w2 = v * f32x2{slope, slope};
+        v = f32x2{fmaxf(v[0], w2[0]), fmaxf(v[1], w2[1])};
+      }
+      if (PEG * NT == NXG || tid + NT * (pc % PEG) < NXG) {
+        float* q = &Xs[buf][xk[pc] & 0x3fffu];
+        q[0] = ok ? v[0] : 0.f;
+        q[1] = ok ? v[1] : 0.f;
+      }
+    } else if (pc < NPIECE) {
+      Ds[buf][dslot] = ok ? draw[0] : 0.f;
+      Ds[buf][dslot + 1] = ok ? draw[1] : 0.f;
+    }
+  };
+
+  f32x16 acc[4][2];         // [kw][output-channel block]
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][cb][r] = 0.f;
+
+  const int lbx = (wcb * 32 + li) * PSX + 2 * lk + wi * PCG;   // input row kh = wave row of the pixel's window
+  const int lbd = li * PSD + lk;
+  float u[2][2];
+  f32x2 v[2][2];
+  auto tile_x = [&](int ks) { const int t = 2 * ks, g = t / (GH * GW), ty = (t % (GH * GW)) / GW, tx = t % GW; return g * GE + 2 * ty * PCG + 2 * tx + 2; };
+  auto read_ops = [&](int buf, int ks, int slot, int part) __attribute__((always_inline)) {
+    if (part == 0) {
+      u[slot][0] = Ds[buf][lbd + 2 * ks];
+      u[slot][1] = Ds[buf][lbd + 32 * PSD + 2 * ks];
+    } else {
+      const float* p = &Xs[buf][lbx + tile_x(ks)];
+      v[slot][0] = *reinterpret_cast<const f32x2*>(p);
+      v[slot][1] = *reinterpret_cast<const f32x2*>(p + 2);
+    }
+  };
+
+  load_groups(0);
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(pc);
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) finish_piece(0, pc);
+  __syncthreads();
+  load_groups(min(1, nc - 1));
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) issue_piece(pc);
+  read_ops(0, 0, 0, 0);
+  read_ops(0, 0, 0, 1);
+
+  for (int c = 0; c < nc; ++c) {
+    const int buf = c & 1;
+    const int c2 = min(c + 2, nc - 1);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      const int nbuf = ks < 7 ? buf : buf ^ 1, nks = ks < 7 ? ks + 1 : 0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int q = m >> 1, cb = m & 1;
+        acc[q][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[cur][cb], v[cur][q >> 1][q & 1], acc[q][cb], 0, 0, 0);
+        if (m == 0) read_ops(nbuf, nks, nxt, 0);
+        if (m == 1) read_ops(nbuf, nks, nxt, 1);
+        if (ks == 4 || ks == 5) {
+#pragma unroll
+          for (int pc = (ks - 4) * 8 + m; pc < NPIECE; pc += 16) finish_piece(buf ^ 1, pc);
+        }
+        if (ks == 6 || ks == 7) {
+          if (ks == 6 && m == 0) load_groups(c2);
+#pragma unroll
+          for (int pc = (ks - 6) * 8 + m; pc < NPIECE; pc += 16) issue_piece(pc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ks == 6) __syncthreads();
+    }
+  }
+
+  // epilogue: tap (kh = wave row, kw = q) straight to the slab; ci = lane & 31, co row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int ci = c0 + wcb * 32 + li;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int cob = 0; cob < 2; ++cob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (co < a.Cout && ci < a.Cin) a.out[(((long long)split * 16 + wi * 4 + q) * a.Cout + co) * a.Cin + ci] = acc[q][cob][r];
+      }
+}
+
 // ---------------------------------------------------------------------------
 // host side (called from conv.hip)
 // ---------------------------------------------------------------------------
@@ -456,4 +665,48 @@ int ww_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   else ww_launch_cfg<false, false>(a, p.cfg, grid, st);
   AVSEP_LAUNCH_CHECK();
   return w3_reduce(ws, dw, (long long)d->Cout * d->Cin, p.splits, st);
+}
+
+// ---- 4x4 / stride 2 ----
+int w4_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st);      // wgrad4_bf16.hip
+
+static WwPlan w4d_plan(const avsep_conv_desc* d) {
+  avsep_conv_desc e = *d;                       // the chunk geometry of the 3x3 plan on the INPUT grid (tile = output pixel)
+  e.dil = 1;
+  return ww_plan(&e);
+}
+bool w4d_applicable(const avsep_conv_desc* d) {
+  static const bool off = getenv("AVSEP_NO_WINOGRAD") != nullptr || getenv("AVSEP_NO_WINOGRAD_WGRAD") != nullptr;
+  if (off || d->prec != AVSEP_PREC_F32) return false;
+  if (!(d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->dil == 1) || d->up2x || d->C0 != d->Cin) return false;
+  if ((d->H & 3) || (d->W & 3) || d->H < 8 || d->W < 8 || d->Ho * 2 != d->H || d->Wo * 2 != d->W) return false;
+  if (d->Cin % WW_B || d->Cout < 48 || d->H >= 32768 || d->W >= 32768 || (long long)d->H * d->W >= (1 << 24)) return false;
+  if ((long long)d->N * (d->Cin > d->Cout ? d->Cin : d->Cout) * d->H * d->W >= 0x7fffffffLL) return false;
+  const WwPlan p = w4d_plan(d);
+  return p.cfg < 2 && (long long)p.gridM * p.gridC * p.splits >= 128 && p.nchunks >= 8;
+}
+size_t w4d_workspace_floats(const avsep_conv_desc* d) {
+  const WwPlan p = w4d_plan(d);
+  return (size_t)p.splits * 16 * d->Cout * d->Cin;
+}
+int w4d_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st) {
+  const WwPlan p = w4d_plan(d);
+  W4dArgs a{};
+  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.gyn = p.gyn; a.gxn = p.gxn; a.ngroups = p.ngroups; a.nchunks = p.nchunks; a.cps = p.cps;
+  a.gridM = p.gridM; a.gridC = p.gridC; a.act0 = d->act0;
+  a.x0 = d->x0; a.sc0 = d->scale0; a.sh0 = d->shift0; a.dy = dy; a.out = ws;
+  const bool raw = !d->scale0 && d->act0 == AVSEP_ACT_NONE;
+  dim3 grid((unsigned)(p.gridM * p.gridC), (unsigned)p.splits);
+#define W4D_LAUNCH(G_, GH_, GW_)                                                                               \
+  do {                                                                                                       \
+    if (raw) hipLaunchKernelGGL((wgrad4d_kernel<G_, GH_, GW_, true>), grid, dim3(WW_THREADS), 0, st, a);      \
+    else hipLaunchKernelGGL((wgrad4d_kernel<G_, GH_, GW_, false>), grid, dim3(WW_THREADS), 0, st, a);        \
+  } while (0)
+  if (p.cfg == 0) W4D_LAUNCH(1, 2, 8);
+  else if (p.cfg == 1) W4D_LAUNCH(1, 4, 4);
+  else return AVSEP_ERR_ARG;          // 2x16-pixel groups only win on heights that are not multiples of 4 (excluded above)
+#undef W4D_LAUNCH
+  AVSEP_LAUNCH_CHECK();
+  return w4_reduce(ws, dw, (long long)d->Cout * d->Cin, p.splits, st);
 }

@@ -75,6 +75,10 @@ CONV_CASES = [
     (300, 128, 14, 14, 56, 3, 1, 1, 1),    # two 2x16-pixel groups per chunk (14x14), two input-channel tiles
     (260, 128, 14, 14, 56, 3, 1, 2, 2),    # dilation 2: 7x7 parity sub-images on 8x8-pixel chunks, strided dY loads
     (40, 64, 20, 36, 72, 3, 1, 1, 1),      # ragged group grid
+    # wgrad4d_kernel (wgrad_wino.hip): 4x4 / stride 2 weight gradient on the same skeleton (Cin % 64 == 0, >= 128 workgroups)
+    (64, 64, 32, 32, 80, 4, 2, 1, 1),      # 4x16-pixel chunks, ragged second output-channel tile
+    (64, 64, 24, 24, 72, 4, 2, 1, 1),      # 8x8-pixel chunks
+    (72, 64, 20, 36, 72, 4, 2, 1, 1),      # ragged group grid
 ]
 
 
@@ -221,6 +225,15 @@ def test_conv_virtual_input_winograd(dev):
     assert_close(st, st_ref, 1e-5, "stats")
     # one source, activation only (identity affine rows)
     x01 = torch.cat([x0, x1], 1)
+    # 4x4 / stride 2 over a folded BatchNorm + LeakyReLU input: weight gradient on wgrad4d_kernel
+    sc, sh = torch.cat([sc0, sc1]), torch.cat([sh0, sh1])
+    w4 = (torch.randn(Cout, C0 + C1, 4, 4, generator=g) * 0.05).requires_grad_(True)
+    y4 = F.conv2d(F.leaky_relu(x01 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2), w4, None, 2, 1)
+    dy4 = torch.randn(y4.shape, generator=g)
+    y4.backward(dy4)
+    cv4 = K.Conv(t(x01), Cout, 4, 2, 1, sc0=t(sc), sh0=t(sh), act0=2)
+    assert cv4.kernel_name("wgrad") == "wgrad4d_kernel"
+    assert_close(cv4.wgrad(t(dy4))[0], w4.grad, 2e-5, "wgrad 4x4/s2")
     cv1 = K.Conv(t(x01), Cout, 3, 1, 1, act0=1)
     assert cv1.kernel_name("fwd", False) == "wino_kernel"
     assert_close(cv1.fwd(cv1.pack(t(w), 0)), F.conv2d(F.relu(x01), w, None, 1, 1), 2e-5, "fwd relu")
