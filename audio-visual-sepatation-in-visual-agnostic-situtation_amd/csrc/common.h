@@ -15,6 +15,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
+// compute units of the current device (256 on MI355X; 256 when no device is visible, e.g. the CPU-only build check)
+static inline int cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == AVSEP_ACT_RELU) return fmaxf(v, 0.f);

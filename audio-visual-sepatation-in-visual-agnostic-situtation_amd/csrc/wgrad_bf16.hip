@@ -255,7 +255,11 @@ static WBPlan wb_plan(const avsep_conv_desc* d) {
   p.gridM = cdiv(d->Cout, WB_BM);
   p.gridC = cdiv(d->Cin, WB_BC);
   const long long tiles = (long long)p.tilesX * p.tilesY * d->N;
-  const int want = cdiv(768, p.gridM * p.gridC);           // one workgroup per CU (107 KB of LDS): ~3 rounds of workgroups
+  // one workgroup per CU (107 KB of LDS) and nothing overlaps a workgroup's prologue / epilogue: ONE round of workgroups
+  // (measured 256 / 512 / 768 / 1024: 231 / 201 / 175 / 154 TFLOP/s at 64 -> 64 @ 56x56, 573 / 543 / 506 / 494 at 1024 -> 512 @ 16x16)
+  static const char* tw = getenv("AVSEP_WB_WGS");
+  int want = (tw ? atoi(tw) : cu_count()) / (p.gridM * p.gridC);
+  if (want < 1) want = 1;
   const long long maxs = tiles / 4 > 0 ? tiles / 4 : 1;     // at least 4 pixel tiles per slab
   int splits = (int)(want < maxs ? want : maxs);
   if (splits < 1) splits = 1;

@@ -601,14 +601,7 @@ static WwPlan ww_plan(const avsep_conv_desc* d) {
   // workgroups: 186 / 144 / 186 / 182 / 180 / 173 TFLOP/s at 1024 -> 256 @ 32x32, 121 / 91 / 101 / 83 / 71 / 63 at
   // 64 -> 64 @ 56x56) — fewer epilogues and slabs, no partial last round
   static const char* tw = getenv("AVSEP_WINOW_WGS");      // tuning: target workgroup count
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-              ? prop.multiProcessorCount : 256;
-  }
-  int want = (tw ? atoi(tw) : cus) / (p.gridM * p.gridC);
+  int want = (tw ? atoi(tw) : cu_count()) / (p.gridM * p.gridC);
   const int maxs = p.nchunks / 8 > 0 ? p.nchunks / 8 : 1;    // at least 8 chunks per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
