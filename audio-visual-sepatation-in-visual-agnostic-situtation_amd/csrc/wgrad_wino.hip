@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
   static_assert(X_FLOATS < (1 << 14) && 2 * X_FLOATS >= 8 * 16 * 64, "epilogue exchange fits the input buffers");
   __shared__ __attribute__((aligned(16))) float Xs[2][X_FLOATS];
   __shared__ __attribute__((aligned(16))) float Ds[2][D_FLOATS];
-  __shared__ __attribute__((aligned(16))) int gtab[WW_GT_MAX][4];     // {element offset of the group origin, y0-1, x0-1, valid}
+  __shared__ __attribute__((aligned(16))) int gtab[WW_GT_MAX][4];     // {image, pixel offset of the group origin, y0 << 16 | x0, valid}
   __shared__ f32x2 aff[B];                     // (scale, shift) of the 64 input channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
