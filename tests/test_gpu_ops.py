@@ -239,6 +239,30 @@ def test_conv_virtual_input_winograd(dev):
     assert_close(cv1.fwd(cv1.pack(t(w), 0)), F.conv2d(F.relu(x01), w, None, 1, 1), 2e-5, "fwd relu")
 
 
+def test_conv_dilated_folded_input_winograd(dev):
+    """dilation 2 over a folded BatchNorm + ReLU input (the ResNet layer3/4 form): the parity-sub-image instantiations of the
+    Winograd forward, data-gradient and weight-gradient kernels with the affine staging path, and the BatchNorm sums."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(12)
+    N, Cin, Cout, H, W = 260, 128, 72, 14, 14
+    x = torch.randn(N, Cin, H, W, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    v = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    y_ref = F.conv2d(v, w, None, 1, 2, 2)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    t = lambda z: z.to(dev)
+    cv = K.Conv(t(x), Cout, 3, 1, 2, 2, sc0=t(sc), sh0=t(sh), act0=1)
+    assert (cv.kernel_name("fwd", True), cv.kernel_name("dgrad"), cv.kernel_name("wgrad")) == ("wino_kernel", "wino_kernel", "winow_kernel")
+    st = K.zeros_stats(Cout, cv.like)
+    yd = y_ref.detach()
+    assert_close(cv.fwd(cv.pack(t(w.detach()), 0), None, st), yd, 2e-5, "fwd")
+    assert_close(st, torch.cat([yd.double().sum((0, 2, 3)), (yd.double() ** 2).sum((0, 2, 3))]), 1e-5, "stats")
+    assert_close(cv.dgrad(cv.pack(t(w.detach()), 1), t(dy)), v.grad, 2e-5, "dgrad")
+    assert_close(cv.wgrad(t(dy))[0], w.grad, 2e-5, "wgrad")
+
+
 @pytest.mark.parametrize("up2x,H,W", [(False, 9, 7), (True, 9, 7), (False, 10, 36), (True, 10, 18), (True, 6, 10)])
 def test_conv_virtual_input(dev, up2x, H, W):
     """two-source concat + per-channel affine + LeakyReLU/ReLU (+ bilinear x2) folded into the gather;
