@@ -6,6 +6,11 @@
 pair when ``-history['val_ao']['si_sdr'][-1]`` improves on ``args.best_err``.  The reference forgets the optimizer
 and the iteration counter, so a resumed run restarts the momentum; ``optimizer`` (a FlatSGD) adds
 ``optim_latest.pth`` for that — an extra file the reference ignores.
+
+The SoP++ three-stage form (``nets`` = (sound, frame, synthesizer, attention module), SoP++/main.py:599-631) also writes
+``synthesizer_{latest,best}.pth`` and ``net_pit_latest.pth`` like the reference, plus ``net_pit_best.pth`` (the reference
+writes ``net_pit_latest.pth`` twice at :630-631 and never reloads the module, :913-921; here ``--load_ckpt`` and eval
+mode restore it, so that a resumed or evaluated run has the attention module it was saved with).
 """
 import os
 
@@ -25,12 +30,17 @@ def _cpu_state(net):
 
 def checkpoint(nets, history, itera, args, optimizer=None):
     print("Saving checkpoints at {} iterations.".format(itera))
-    net_sound, net_frame = nets
+    if len(nets) not in (2, 4):
+        raise ValueError("checkpoint() takes (sound, frame) or (sound, frame, synthesizer, attention module)")
+    net_sound, net_frame = nets[:2]
+    extra = list(zip(("synthesizer", "net_pit"), nets[2:]))
     os.makedirs(args.ckpt, exist_ok=True)
     path = lambda what, suffix: os.path.join(args.ckpt, "{}_{}".format(what, suffix))   # noqa: E731
     _save(history, path("history", "latest.pth"))
     _save(_cpu_state(net_sound), path("sound", "latest.pth"))
     _save(_cpu_state(net_frame), path("frame", "latest.pth"))
+    for what, net in extra:
+        _save(_cpu_state(net), path(what, "latest.pth"))
     if optimizer is not None:
         _save({"itera": itera, "state": optimizer.state_dict()}, path("optim", "latest.pth"))
     cur_err = -history["val_ao"]["si_sdr"][-1]
@@ -38,12 +48,16 @@ def checkpoint(nets, history, itera, args, optimizer=None):
         args.best_err = cur_err
         _save(_cpu_state(net_sound), path("sound", "best.pth"))
         _save(_cpu_state(net_frame), path("frame", "best.pth"))
+        for what, net in extra:
+            _save(_cpu_state(net), path(what, "best.pth"))
 
 
-def resume_paths(args, best=False):
-    """The weight paths the reference derives for --resume ('latest') and for eval mode ('best'), main.py:780-791."""
+def resume_paths(args, best=False, three_stage=False):
+    """The weight paths the reference derives for --resume ('latest') and for eval mode ('best'), main.py:780-791;
+    `three_stage` adds the synthesizer's (SoP++/main.py:913-921) and the attention module's."""
     suffix = "best.pth" if best else "latest.pth"
-    return os.path.join(args.ckpt, "sound_" + suffix), os.path.join(args.ckpt, "frame_" + suffix)
+    names = ("sound_", "frame_") + (("synthesizer_", "net_pit_") if three_stage else ())
+    return tuple(os.path.join(args.ckpt, n + suffix) for n in names)
 
 
 def load_optimizer(optimizer, args):

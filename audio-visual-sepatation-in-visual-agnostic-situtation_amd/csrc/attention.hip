@@ -214,6 +214,9 @@ extern "C" int avsep_attmodel_infer_fwd(const float* a, const float* mix, int32_
   if (!maps_raw || !ctx || !match) return AVSEP_ERR_ARG;
   AttArgs p{a, mix, B, S, K, HW, att};
   const size_t lds = (size_t)(S * K + S * HW + ATT_MAXS + 4) * sizeof(float);
+  if (lds > 160 * 1024) return AVSEP_ERR_ARG;
+  if (lds > 64 * 1024)      // the limit shapes att_check admits (HW = 4096, S = 4) need ~67 KB: opt in above the 64 KB default
+    (void)hipFuncSetAttribute((const void*)att_infer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(att_infer_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, p, maps_raw, ctx, match);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
@@ -227,6 +230,9 @@ extern "C" int avsep_attmodel_infer_bwd(const float* a, const float* mix, const 
   if (!maps_raw || !dctx || !da || !dmix) return AVSEP_ERR_ARG;
   AttArgs p{a, mix, B, S, K, HW, att};
   const size_t lds = (size_t)(2 * S * K + 2 * S * HW + HW + 2 * ATT_MAXS + 4) * sizeof(float);
+  if (lds > 160 * 1024) return AVSEP_ERR_ARG;
+  if (lds > 64 * 1024)      // HW = 4096, S = 4: ~151 KB
+    (void)hipFuncSetAttribute((const void*)att_infer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(att_infer_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, p, maps_raw, dctx, dmaps, dmatch,
                      da, dmix);
   AVSEP_LAUNCH_CHECK();

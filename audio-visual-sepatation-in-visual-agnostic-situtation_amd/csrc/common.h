@@ -15,6 +15,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
+// The descriptor with the batch its launch heuristics are planned for (avsep_conv_desc.plan_n, 0 = N): kernel-family,
+// tile-size and split-K DECISIONS are taken on this copy, grids and workspace sizes on the real batch.
+static inline avsep_conv_desc plan_desc(const avsep_conv_desc* d) {
+  avsep_conv_desc e = *d;
+  if (d->plan_n > 0) e.N = d->plan_n;
+  return e;
+}
+static inline int plan_batch(const avsep_conv_desc* d) { return d->plan_n > 0 ? d->plan_n : d->N; }
 // compute units of the current device (256 on MI355X; 256 when no device is visible, e.g. the CPU-only build check)
 static inline int cu_count() {
   static int cus = 0;

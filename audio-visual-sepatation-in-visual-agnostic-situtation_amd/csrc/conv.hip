@@ -11,6 +11,8 @@
 // Both operands are staged global -> registers -> LDS (K-major, double buffered, one barrier
 // per K-tile); each wave owns a (BM/WM)x(BN/WN) block of 32x32 MFMA tiles.
 #include "common.h"
+#include <stdio.h>
+#include <string.h>
 
 enum { M_FWD = 0, M_DGRAD = 1, M_WGRAD = 2 };
 
@@ -687,15 +689,21 @@ static bool fwd_uses_igemm(const avsep_conv_desc* d, const double* stats) {
   return !((!stats && (smallco_applicable(d) || head_applicable(d))) || bf_applicable(d, 0) || wn_applicable(d, 0) || c3_applicable(d, 0) ||
            c4_applicable(d, 0) || cm_applicable(d, 0));
 }
+// the im2col kernel's tile size and split-K are decided on the planned batch (plan_desc), like every launch heuristic
+static bool fwd_big(const avsep_conv_desc* d) { return use_big(d->Cout, (long long)plan_batch(d) * d->Ho * d->Wo); }
+static bool dgrad_big(const avsep_conv_desc* d) {
+  const int s = d->stride;
+  return use_big(d->Cin, (long long)plan_batch(d) * cdiv(d->H, s) * cdiv(d->W, s) * s * s);
+}
 static SplitPlan fwd_split(const avsep_conv_desc* d) {
-  long long ncols = (long long)d->N * d->Ho * d->Wo;
+  long long ncols = (long long)plan_batch(d) * d->Ho * d->Wo;
   bool big = use_big(d->Cout, ncols);
   long long tiles = big ? (long long)cdiv(d->Cout, 128) * cdiv(ncols, 128) : (long long)cdiv(d->Cout, 64) * cdiv(ncols, 64);
   return splitk_plan(tiles, d->Cin * d->KH * d->KW);
 }
 static SplitPlan dgrad_split(const avsep_conv_desc* d) {
   const int s = d->stride;
-  long long ncols = (long long)d->N * cdiv(d->H, s) * cdiv(d->W, s);
+  long long ncols = (long long)plan_batch(d) * cdiv(d->H, s) * cdiv(d->W, s);
   bool big = use_big(d->Cin, ncols * s * s);
   long long tiles = (big ? (long long)cdiv(d->Cin, 128) * cdiv(ncols, 128) : (long long)cdiv(d->Cin, 64) * cdiv(ncols, 64)) * s * s;
   int taps = cdiv(d->KH, s) * cdiv(d->KW, s);               // taps of the fullest parity class
@@ -759,7 +767,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
     a.slab = (long long)d->N * d->Cout * d->Ho * d->Wo;
     a.out = (float*)workspace;
   }
-  if (use_big(a.M, ncols)) {
+  if (fwd_big(d)) {
     a.gridM = cdiv(a.M, 128);
     hipLaunchKernelGGL((igemm_kernel<M_FWD, 128, 128, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 128), sp.splits), dim3(256), 0,
                        st, a);
@@ -806,7 +814,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
     a.slab = (long long)d->N * d->Cin * d->H * d->W;
     a.out = (float*)workspace;
   }
-  if (use_big(a.M, ncols * s * s)) {
+  if (dgrad_big(d)) {
     a.gridM = cdiv(a.M, 128);
     hipLaunchKernelGGL((igemm_kernel<M_DGRAD, 128, 128, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 128), s * s, sp.splits),
                        dim3(256), 0, st, a);
@@ -940,6 +948,29 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
   if (w4d_applicable(d)) return "wgrad4d_kernel";
   if (w3_applicable(d)) return "wgrad3x3_kernel";
   return "igemm_kernel<wgrad>";
+}
+
+void bf_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap);      // conv_bf16.hip
+void c3_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap);      // conv3x3.hip
+void c4_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap);
+void cm_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap);      // conv_misc.hip
+
+extern "C" int avsep_conv_kernel_variant(const avsep_conv_desc* d, int32_t mode, int32_t with_stats, char* buf, size_t cap) {
+  if (!buf || cap < 8) return AVSEP_ERR_ARG;
+  const char* fam = avsep_conv_kernel_name(d, mode, with_stats);
+  char tail[64] = "";
+  if (!strcmp(fam, "convbf_kernel")) bf_variant(d, mode, tail, sizeof(tail));
+  else if (!strcmp(fam, "conv3x3_kernel")) {
+    if (c3_applicable(d, mode)) c3_variant(d, mode, tail, sizeof(tail));
+    else if (c4_applicable(d, mode)) c4_variant(d, mode, tail, sizeof(tail));
+    else cm_variant(d, mode, tail, sizeof(tail));
+  } else if (!strcmp(fam, "igemm_kernel<fwd>")) {
+    snprintf(tail, sizeof(tail), "BM%d,split%d", fwd_big(d) ? 128 : 64, fwd_split(d).splits);
+  } else if (!strcmp(fam, "igemm_kernel<dgrad>")) {
+    snprintf(tail, sizeof(tail), "BM%d,split%d", dgrad_big(d) ? 128 : 64, dgrad_split(d).splits);
+  }
+  snprintf(buf, cap, tail[0] ? "%s:%s" : "%s", fam, tail);
+  return AVSEP_OK;
 }
 
 // ---------------------------------------------------------------------------

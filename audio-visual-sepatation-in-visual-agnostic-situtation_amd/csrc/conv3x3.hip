@@ -39,9 +39,13 @@ __global__ void c3_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // conv_flat.hip: flat-pixel tiles for the small square maps of the visual trunk
 int c3_flat_width(int H, int W, int dil);
 int c3_flat_launch(C3Args& a, int dil, hipStream_t st);
+static bool c3_flat_enabled() {
+  static const bool on = getenv("AVSEP_NO_FLAT") == nullptr;      // read once per process, like every AVSEP_* switch
+  return on;
+}
 static bool c3_flat(const avsep_conv_desc* d) {
   return !d->up2x && d->C0 == d->Cin && c3_flat_width(d->H, d->W, d->dil) > 0 && (long long)d->N * d->H * d->W < 0x7fffffffLL &&
-         getenv("AVSEP_NO_FLAT") == nullptr;
+         c3_flat_enabled();
 }
 
 bool c3_applicable(const avsep_conv_desc* d, int mode) {
@@ -65,7 +69,7 @@ int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
 
 static int c3_launch(C3Args& a, hipStream_t st, int dil = 1) {
   a.Ho = a.H; a.Wo = a.W; a.padh = a.padw = dil; a.os = 1; a.ooh = a.oow = 0; a.OHs = a.H; a.OWs = a.W;
-  if (!a.up2x && a.C1 == 0 && c3_flat_width(a.H, a.W, dil) > 0 && getenv("AVSEP_NO_FLAT") == nullptr)
+  if (!a.up2x && a.C1 == 0 && c3_flat_width(a.H, a.W, dil) > 0 && c3_flat_enabled())
     return c3_flat_launch(a, dil, st);
   const bool wide = a.W >= 32;
   a.tilesX = cdiv(a.W, wide ? 32 : 16);
@@ -73,8 +77,8 @@ static int c3_launch(C3Args& a, hipStream_t st, int dil = 1) {
   // 64-row tiles when the GEMM M dimension is small, when 128-row tiles would leave most CUs with one workgroup, or when
   // their count quantises badly over the 256 CUs (384 workgroups = 1.5 per CU runs at 75 %: the ResNet 256-channel
   // 14x14 layers)
-  const long long wg128 = (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * a.N;
-  const bool narrow = a.Cout <= 64 || wg128 < 384 || (wg128 < 1024 && wg128 * 5 < ((wg128 + 255) / 256) * 256 * 4);
+  const long long wg128 = (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * c3_plan_n(a);
+  const bool narrow = c3_narrow_rule(a.Cout, wg128, true);
   a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
 #define C3_LAUNCH(TH_, TW_, BM_)                                                                               \
@@ -92,9 +96,29 @@ static int c3_launch(C3Args& a, hipStream_t st, int dil = 1) {
   return AVSEP_OK;
 }
 
+// tile decision of the halo-patch launches above as text (avsep_conv_kernel_variant); M = GEMM rows, Ho x Wo = tile space
+void c3_variant_text(int M, int Ho, int Wo, long long planN, bool flat, bool quantise, char* buf, size_t cap) {
+  if (flat) {
+    const long long wg128 = (long long)cdiv(M, 128) * cdiv(planN * Ho * Wo, 128);
+    snprintf(buf, cap, "flat%d,BM%d", Wo, c3_narrow_rule(M, wg128, true) ? 64 : 128);
+    return;
+  }
+  const bool wide = Wo >= 32;
+  const long long wg128 = (long long)cdiv(M, 128) * cdiv(Wo, wide ? 32 : 16) * cdiv(Ho, wide ? 4 : 8) * planN;
+  snprintf(buf, cap, "%s,BM%d", wide ? "4x32" : "8x16", c3_narrow_rule(M, wg128, quantise) ? 64 : 128);
+}
+void c3_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
+  const bool flat = !d->up2x && d->C0 == d->Cin && c3_flat_width(d->H, d->W, d->dil) > 0 && c3_flat_enabled();
+  c3_variant_text(mode == 0 ? d->Cout : d->Cin, d->H, d->W, plan_batch(d), flat, true, buf, cap);
+}
+void c4_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
+  if (mode == 0) c3_variant_text(d->Cout, d->Ho, d->Wo, plan_batch(d), false, false, buf, cap);
+  else c3_variant_text(d->Cin, d->H / 2, d->W / 2, plan_batch(d), false, false, buf, cap);     // each of the 4 parity classes
+}
+
 int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st) {
   C3Args a{};
-  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = d->up2x;
   a.Hs = d->up2x ? d->H / 2 : d->H; a.Ws = d->up2x ? d->W / 2 : d->W;
   a.rh = (d->up2x && d->H > 1) ? (float)(a.Hs - 1) / (float)(d->H - 1) : 0.f;
@@ -107,7 +131,7 @@ int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
 // dX[N,Cin,H,W] = conv3x3(dY[N,Cout,H,W], flipped/transposed weights)
 int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st) {
   C3Args a{};
-  a.N = d->N; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
+  a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
   a.C0 = d->Cout; a.C1 = 0; a.Hs = d->H; a.Ws = d->W;
   a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
   return c3_launch(a, st, d->dil);      // the flipped-weight identity holds for any dilation with pad == dil
@@ -169,7 +193,7 @@ static int c4_launch(C3Args& a, hipStream_t st) {
   const bool wide = a.Wo >= 32;
   a.tilesX = cdiv(a.Wo, wide ? 32 : 16);
   a.tilesY = cdiv(a.Ho, wide ? 4 : 8);
-  const bool narrow = a.Cout <= 64 || (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * a.N < 384;
+  const bool narrow = c3_narrow_rule(a.Cout, (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * c3_plan_n(a), false);
   a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
   if (wide && !narrow) hipLaunchKernelGGL((conv3x3_kernel<4, 32, 128, false, KS_, S_, 1, CK_>), grid, dim3(256), 0, st, a);
@@ -182,7 +206,7 @@ static int c4_launch(C3Args& a, hipStream_t st) {
 
 int c4_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st) {
   C3Args a{};
-  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = 0;
   a.Hs = d->H; a.Ws = d->W;
   a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
@@ -197,7 +221,7 @@ int c4_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
   for (int cls = 0; cls < 4; ++cls) {
     const int ph = cls >> 1, pw = cls & 1;
     C3Args a{};
-    a.N = d->N; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
+    a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
     a.x0 = dy; a.wp = wp + (size_t)cls * d->Cout * 4 * ld; a.wp_ld = ld; a.out = dx;
     a.Ho = d->H / 2; a.Wo = d->W / 2; a.padh = ph ? 0 : 1; a.padw = pw ? 0 : 1;

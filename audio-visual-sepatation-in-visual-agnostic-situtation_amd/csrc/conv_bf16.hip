@@ -65,7 +65,11 @@ __global__ void bf_pack_kernel(const float* __restrict__ w, unsigned* __restrict
   reinterpret_cast<u32x4*>(out)[i] = o;
 }
 
-static inline bool bf_enabled() { return getenv("AVSEP_NO_BF16_KERNELS") == nullptr; }
+// read once per process (like every AVSEP_* switch): the packed-weight layout and the launch can never disagree
+static inline bool bf_enabled() {
+  static const bool on = getenv("AVSEP_NO_BF16_KERNELS") == nullptr;
+  return on;
+}
 
 // geometry classes served by convbf_kernel; mode 0 forward, 1 data gradient
 static int bf_class(const avsep_conv_desc* d) {
@@ -129,7 +133,7 @@ size_t bf_workspace_bytes(const avsep_conv_desc* d, int mode) {
   if (bf_class(d) != 3 || !bf_flat(d)) return 0;
   const int M = mode == 0 ? d->Cout : d->Cin, kc = mode == 0 ? d->Cin : d->Cout;
   const long long P = (long long)d->N * d->H * d->W;
-  BfSplit sp = bf_split_plan(bf_flat_wgs(M, P), kc / BF_CK);
+  BfSplit sp = bf_split_plan(bf_flat_wgs(M, (long long)plan_batch(d) * d->H * d->W), kc / BF_CK);
   return sp.splits > 1 ? (size_t)sp.splits * M * P * sizeof(float) : 0;
 }
 
@@ -149,19 +153,47 @@ int bf_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
   return AVSEP_OK;
 }
 
+// tile decisions shared by the launches below and avsep_conv_kernel_variant
+struct BfRect { bool wide, m64, big; int gm; };
+static BfRect bf_rect_plan(int M, int Ho, int Wo, int taps, long long planN) {
+  BfRect r;
+  r.wide = Wo >= 32;
+  // 16-tap weight tiles of 128 rows (2 x 64 KB) would not fit beside the stride-2 patch: 64-row tiles there
+  r.m64 = M <= 64 || taps > 9;
+  r.gm = cdiv(M, r.m64 ? 64 : 128);
+  const long long wg256 = (long long)r.gm * cdiv(Wo, r.wide ? 32 : 16) * cdiv(Ho, r.wide ? 8 : 16) * planN;
+  r.big = wg256 >= 512 && Ho >= (r.wide ? 8 : 16);
+  return r;
+}
+void bf_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
+  const int cls = bf_class(d);
+  const int M = mode == 0 ? d->Cout : d->Cin, kc = mode == 0 ? d->Cin : d->Cout;
+  const long long pn = plan_batch(d);
+  if (cls == 3 && bf_flat(d)) {
+    const long long planP = pn * d->H * d->W;
+    const int gm = cdiv(M, M <= 64 ? 64 : 128);
+    const bool big = (long long)gm * cdiv(planP, 256) >= 512;
+    snprintf(buf, cap, "flat%d,%dx%d,split%d", bf_flat_w(d->H, d->W, d->dil), M <= 64 ? 64 : 128, big ? 256 : 128,
+             bf_split_plan(bf_flat_wgs(M, planP), kc / BF_CK).splits);
+    return;
+  }
+  int Ho = d->Ho, Wo = d->Wo, taps = d->KH * d->KW;
+  if (mode == 1 && cls == 3) { Ho = d->H; Wo = d->W; }
+  else if (mode == 1 && cls == 1) taps = 1;
+  else if (mode == 1) { Ho = d->H / 2; Wo = d->W / 2; taps = 4; }     // stride-2 data gradient: the (2x2-tap) parity classes
+  const BfRect r = bf_rect_plan(M, Ho, Wo, taps, pn);
+  snprintf(buf, cap, "%s,%dx%d", r.wide ? (r.big ? "8x32" : "4x32") : (r.big ? "16x16" : "8x16"), r.m64 ? 64 : 128, r.big ? 256 : 128);
+}
+
 // ---- launch: tile choice ------------------------------------------------------------------------------------------
 // KH_/KW_/S_/DIL_ select the instantiation; a.Ho/Wo = output tile space.  256-pixel tiles x 128 rows (512 threads)
 // when that still yields >= 2 workgroups per CU-slot, else 128-pixel tiles; 64-row tiles for Cout <= 64.
 template <int KH_, int KW_, int S_, int DIL_>
 static int bf_launch_rect(C3Args& a, hipStream_t st) {
-  const bool wide = a.Wo >= 32;
-  // 16-tap weight tiles of 128 rows (2 x 64 KB) would not fit beside the stride-2 patch: 64-row tiles there
   constexpr bool ONLY64 = KH_ * KW_ > 9;
-  const bool m64 = a.Cout <= 64 || ONLY64;
-  const int gm = cdiv(a.Cout, m64 ? 64 : 128);
-  const long long wg256 = (long long)gm * cdiv(a.Wo, wide ? 32 : 16) * cdiv(a.Ho, wide ? 8 : 16) * a.N;
-  const bool big = wg256 >= 512 && a.Ho >= (wide ? 8 : 16);
-  a.gridM = gm;
+  const BfRect r = bf_rect_plan(a.Cout, a.Ho, a.Wo, KH_ * KW_, c3_plan_n(a));
+  const bool wide = r.wide, m64 = r.m64, big = r.big;
+  a.gridM = r.gm;
   a.tilesX = cdiv(a.Wo, wide ? 32 : 16);
   a.tilesY = cdiv(a.Ho, wide ? (big ? 8 : 4) : (big ? 16 : 8));
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
@@ -185,10 +217,10 @@ static int bf_launch_rect(C3Args& a, hipStream_t st) {
 
 template <int FW_, int DIL_>
 static int bf_launch_flat(C3Args& a, int splits, hipStream_t st) {
-  const long long P = (long long)a.N * a.H * a.W;
+  const long long P = (long long)a.N * a.H * a.W, planP = c3_plan_n(a) * a.H * a.W;
   const bool m64 = a.Cout <= 64;
   a.gridM = cdiv(a.Cout, m64 ? 64 : 128);
-  const bool big = (long long)a.gridM * cdiv(P, 256) >= 512;
+  const bool big = (long long)a.gridM * cdiv(planP, 256) >= 512;
   a.tilesX = cdiv(P, big ? 256 : 128);
   a.tilesY = 1;
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX), splits);
@@ -212,7 +244,7 @@ static int bf3_launch(C3Args& a, int dil, void* ws, size_t ws_bytes, int* splits
   const int fw = bf_flat_w(a.H, a.W, dil);
   if (fw) {
     const long long P = (long long)a.N * a.H * a.W;
-    BfSplit sp = bf_split_plan(bf_flat_wgs(a.Cout, P), a.Cin / BF_CK);
+    BfSplit sp = bf_split_plan(bf_flat_wgs(a.Cout, c3_plan_n(a) * a.H * a.W), a.Cin / BF_CK);
     if (sp.splits > 1 && ws && ws_bytes >= (size_t)sp.splits * a.Cout * P * sizeof(float)) {
       a.kts = sp.kts; a.slab = (long long)a.Cout * P; a.out = (float*)ws;
       *splits_out = sp.splits;
@@ -233,7 +265,7 @@ int reduce_slabs(const float* ws, float* out, long long n, int S, hipStream_t st
 int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, void* ws, size_t ws_bytes,
            hipStream_t st) {
   C3Args a{};
-  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.C0 = d->Cin; a.C1 = 0; a.act0 = d->act0; a.Hs = d->H; a.Ws = d->W;
   a.x0 = d->x0; a.sc0 = d->scale0; a.sh0 = d->shift0;
   a.wp = wp; a.wp_ld = roundup(d->Cout, 128); a.out = y; a.bias = bias; a.stats = stats;
@@ -255,7 +287,7 @@ int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
 int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
   if (bf_class(d) == 3) {
     C3Args a{};
-    a.N = d->N; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
+    a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->H; a.Ws = d->W;
     a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
     int splits = 1;
@@ -267,7 +299,7 @@ int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
   const int bcls = bf_class(d);
   if (bcls == 1) {            // 1x1: dX at the sampled positions = W^T dY; stride 2 leaves the other positions zero
     C3Args a{};
-    a.N = d->N; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;
+    a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
     a.x0 = dy; a.wp = wp; a.wp_ld = ld; a.out = dx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.padh = a.padw = 0; a.os = d->stride; a.ooh = a.oow = 0; a.OHs = d->H; a.OWs = d->W;
@@ -280,7 +312,7 @@ int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
   for (int cls = 0; cls < 4; ++cls) {
     const int ph = cls >> 1, pw = cls & 1;
     C3Args a{};
-    a.N = d->N; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
+    a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
     a.x0 = dy; a.wp = wp + off; a.wp_ld = ld; a.out = dx;
     a.Ho = d->H / 2; a.Wo = d->W / 2;

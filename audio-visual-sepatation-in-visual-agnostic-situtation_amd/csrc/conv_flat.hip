@@ -28,8 +28,8 @@ int c3_flat_launch(C3Args& a, int dil, hipStream_t st) {
   if (P > 0x7fffffffLL || a.C1 != 0 || a.up2x) return AVSEP_ERR_ARG;
   a.tilesX = cdiv(P, 128);
   a.tilesY = 1;
-  const long long wg128 = (long long)cdiv(a.Cout, 128) * a.tilesX;
-  const bool narrow = a.Cout <= 64 || wg128 < 384 || (wg128 < 1024 && wg128 * 5 < ((wg128 + 255) / 256) * 256 * 4);
+  const long long wg128 = (long long)cdiv(a.Cout, 128) * cdiv(c3_plan_n(a) * a.H * a.W, 128);
+  const bool narrow = c3_narrow_rule(a.Cout, wg128, true);
   a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX));
   const int fw = c3_flat_width(a.H, a.W, dil);

@@ -10,7 +10,10 @@
 
 #include "halo_kernel.h"
 
-static inline bool cm_enabled() { return getenv("AVSEP_NO_MISC_PATCH") == nullptr; }
+static inline bool cm_enabled() {
+  static const bool on = getenv("AVSEP_NO_MISC_PATCH") == nullptr;      // read once per process
+  return on;
+}
 static int cm_class(const avsep_conv_desc* d) {
   if (d->up2x || d->dil != 1) return 0;
   if (d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1) return 5;
@@ -79,7 +82,7 @@ static int cm_launch(C3Args& a, hipStream_t st) {
   const bool wide = a.Wo >= 32;
   a.tilesX = cdiv(a.Wo, wide ? 32 : 16);
   a.tilesY = cdiv(a.Ho, wide ? 4 : 8);
-  const bool narrow = a.Cout <= 64 || (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * a.N < 384;
+  const bool narrow = c3_narrow_rule(a.Cout, (long long)cdiv(a.Cout, 128) * a.tilesX * a.tilesY * c3_plan_n(a), false);
   a.gridM = cdiv(a.Cout, narrow ? 64 : 128);
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX * a.tilesY * a.N));
   if (wide && !narrow) hipLaunchKernelGGL((conv3x3_kernel<4, 32, 128, false, 3, S_, 1, CK_, KH_, KW_>), grid, dim3(256), 0, st, a);
@@ -90,9 +93,16 @@ static int cm_launch(C3Args& a, hipStream_t st) {
   return AVSEP_OK;
 }
 
+void c3_variant_text(int M, int Ho, int Wo, long long planN, bool flat, bool quantise, char* buf, size_t cap);   // conv3x3.hip
+void cm_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
+  if (mode == 0) c3_variant_text(d->Cout, d->Ho, d->Wo, plan_batch(d), false, false, buf, cap);
+  else if (cm_class(d) == 1) c3_variant_text(d->Cin, d->Ho, d->Wo, plan_batch(d), false, false, buf, cap);
+  else c3_variant_text(d->Cin, d->H / 2, d->W / 2, plan_batch(d), false, false, buf, cap);
+}
+
 int cm_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st) {
   C3Args a{};
-  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = 0;
   a.Hs = d->H; a.Ws = d->W;
   a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
@@ -106,7 +116,7 @@ int cm_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
 int cm_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st) {
   const int ld = roundup(d->Cin, 128);
   C3Args a{};
-  a.N = d->N; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;       // the conv runs over dY
+  a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;       // the conv runs over dY
   a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
   a.x0 = dy; a.wp_ld = ld; a.out = dx; a.padh = a.padw = 0; a.OHs = d->H; a.OWs = d->W;
   if (cm_class(d) == 1) {

@@ -408,7 +408,8 @@ bool wn_applicable(const avsep_conv_desc* d, int mode) {
     if (d->C0 % WN_CK || (C1 != 0 && C1 != d->C0)) return false;
   }
   if ((long long)d->N * (mode == 0 ? d->C0 : d->Cout) * d->H * d->W >= 0xffffffffLL) return false;   // 32-bit element offsets
-  const WnPlan p = wn_plan(d, mode);
+  const avsep_conv_desc e = plan_desc(d);
+  const WnPlan p = wn_plan(&e, mode);
   return (long long)p.ptiles * p.gridM >= 128;      // at least half of the CUs busy (below that the split-K im2col path wins)
 }
 size_t wn_packed_floats(const avsep_conv_desc* d, int mode) {

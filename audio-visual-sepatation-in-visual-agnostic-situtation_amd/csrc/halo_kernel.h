@@ -22,7 +22,14 @@ struct C3Args {
   // [y*kts, (y+1)*kts) into partial slab y of `out` (slab elements apart); 0 = no split
   int kts;
   long long slab;
+  int planN;             // host only: batch the tile-size heuristics are planned for (avsep_conv_desc.plan_n; 0 = N)
 };
+static inline long long c3_plan_n(const C3Args& a) { return a.planN > 0 ? a.planN : a.N; }
+// 64-row instead of 128-row tiles (fp32 halo-patch kernels): small GEMM M, too few 128-row workgroups for the 256 CUs, or
+// (3x3/s1 only, `quantise`) a workgroup count that quantises badly over them; wg128 is counted on the PLANNED batch
+static inline bool c3_narrow_rule(int cout, long long wg128, bool quantise) {
+  return cout <= 64 || wg128 < 384 || (quantise && wg128 < 1024 && wg128 * 5 < ((wg128 + 255) / 256) * 256 * 4);
+}
 
 constexpr int C3_CK = 4;            // input channels per K-tile of the 3x3 path (host-side packing constant)
 

@@ -50,8 +50,9 @@ extern "C" int avsep_channel_stats(const float* x, int32_t N, int32_t C, int32_t
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    float momentum, float eps, int C, int training, float* scale, float* shift,
-                                   float* mean_o, float* invstd_o) {
+                                   float* mean_o, float* invstd_o, long long* num_batches_tracked, int updates) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && num_batches_tracked) *num_batches_tracked += updates;
   if (c >= C) return;
   double mean, var;
   if (training) {
@@ -60,8 +61,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
     if (var < 0.0) var = 0.0;
     if (running_mean) {
       double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+      float rm = running_mean[c], rv = running_var[c];
+      for (int u = 0; u < updates; ++u) {      // `updates` identical forward passes (shared encoder), rounded like separate calls
+        rm = (float)((1.0 - momentum) * rm + momentum * mean);
+        rv = (float)((1.0 - momentum) * rv + momentum * unb);
+      }
+      running_mean[c] = rm;
+      running_var[c] = rv;
     }
   } else {
     mean = running_mean[c];
@@ -79,11 +85,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
 extern "C" int avsep_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, int32_t C,
                                  int32_t training, float* scale, float* shift, float* mean, float* invstd,
-                                 avsep_stream_t stream) {
-  if (C <= 0 || !scale || !shift) return AVSEP_ERR_ARG;
+                                 int64_t* num_batches_tracked, int32_t updates, avsep_stream_t stream) {
+  if (C <= 0 || !scale || !shift || updates < 1) return AVSEP_ERR_ARG;
   if (training ? !stats : (!running_mean || !running_var)) return AVSEP_ERR_ARG;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, count, gamma,
-                     beta, running_mean, running_var, momentum, eps, C, training, scale, shift, mean, invstd);
+                     beta, running_mean, running_var, momentum, eps, C, training, scale, shift, mean, invstd,
+                     (long long*)num_batches_tracked, updates);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }

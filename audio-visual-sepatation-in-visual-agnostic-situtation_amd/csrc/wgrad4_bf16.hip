@@ -229,7 +229,10 @@ int w4_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t s
   return AVSEP_OK;
 }
 
-static inline bool w4_enabled() { return getenv("AVSEP_NO_BF16_KERNELS") == nullptr && getenv("AVSEP_NO_BF16_WGRAD") == nullptr; }
+static inline bool w4_enabled() {
+  static const bool on = getenv("AVSEP_NO_BF16_KERNELS") == nullptr && getenv("AVSEP_NO_BF16_WGRAD") == nullptr;
+  return on;
+}
 
 bool w4b_applicable(const avsep_conv_desc* d) {
   if (d->prec != AVSEP_PREC_BF16 || !w4_enabled()) return false;

@@ -232,7 +232,10 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-static inline bool wb_enabled() { return getenv("AVSEP_NO_BF16_KERNELS") == nullptr && getenv("AVSEP_NO_BF16_WGRAD") == nullptr; }
+static inline bool wb_enabled() {
+  static const bool on = getenv("AVSEP_NO_BF16_KERNELS") == nullptr && getenv("AVSEP_NO_BF16_WGRAD") == nullptr;
+  return on;
+}
 
 bool wb_applicable(const avsep_conv_desc* d) {
   if (d->prec != AVSEP_PREC_BF16 || !wb_enabled()) return false;

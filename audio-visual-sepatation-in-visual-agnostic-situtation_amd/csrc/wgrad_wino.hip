@@ -620,7 +620,8 @@ bool ww_applicable(const avsep_conv_desc* d) {
   if (d->Cin % WW_B || d->C0 % WW_B || d->Cout < 48 || (C1 != 0 && C1 != d->C0)) return false;
   if (d->H >= 32768 || d->W >= 32768 || (long long)d->H * d->W >= (1 << 24)) return false;   // 24-bit offset arithmetic
   if ((long long)d->N * (d->C0 > d->Cout ? d->C0 : d->Cout) * d->H * d->W >= 0x7fffffffLL) return false;   // 32-bit element offsets
-  const WwPlan p = ww_plan(d);
+  const avsep_conv_desc e = plan_desc(d);
+  const WwPlan p = ww_plan(&e);
   return (long long)p.gridM * p.gridC * p.splits >= 128 && p.nchunks >= 8;
 }
 size_t ww_workspace_floats(const avsep_conv_desc* d) {
@@ -675,7 +676,8 @@ bool w4d_applicable(const avsep_conv_desc* d) {
   if ((d->H & 3) || (d->W & 3) || d->H < 8 || d->W < 8 || d->Ho * 2 != d->H || d->Wo * 2 != d->W) return false;
   if (d->Cin % WW_B || d->Cout < 48 || d->H >= 32768 || d->W >= 32768 || (long long)d->H * d->W >= (1 << 24)) return false;
   if ((long long)d->N * (d->Cin > d->Cout ? d->Cin : d->Cout) * d->H * d->W >= 0x7fffffffLL) return false;
-  const WwPlan p = w4d_plan(d);
+  const avsep_conv_desc e = plan_desc(d);
+  const WwPlan p = w4d_plan(&e);
   return p.cfg < 2 && (long long)p.gridM * p.gridC * p.splits >= 128 && p.nchunks >= 8;
 }
 size_t w4d_workspace_floats(const avsep_conv_desc* d) {

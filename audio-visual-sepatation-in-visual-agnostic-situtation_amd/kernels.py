@@ -32,6 +32,11 @@ def get_precision():
     return "bf16" if _precision else "f32"
 
 
+# Batch the launch heuristics are planned for, as a multiple of the real batch (avsep_conv_desc.plan_n): the parity tests
+# set 8 so that a batch-8 step takes, layer by layer, the kernel instantiations of the batch-64 step bench.py times.
+plan_batch_scale = 1
+
+
 def out_size(h, k, s, p, d):
     return (h + 2 * p - d * (k - 1) - 1) // s + 1
 
@@ -55,6 +60,7 @@ class Conv:
         d.KH, d.KW, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
         d.C0, d.act0, d.act1, d.up2x = C0, act0, act1, int(up2x)
         d.prec = _precision if prec is None else PREC_BY_NAME[prec]
+        d.plan_n = N * plan_batch_scale if plan_batch_scale != 1 else 0
         d.x0, d.x1 = ptr(x0), ptr(x1)
         d.scale0, d.shift0, d.scale1, d.shift1 = ptr(sc0), ptr(sh0), ptr(sc1), ptr(sh1)
         self.d = d
@@ -88,6 +94,19 @@ class Conv:
         """Kernel family the library dispatches this call to (mode: "fwd" | "dgrad" | "wgrad")."""
         return lib.load().avsep_conv_kernel_name(self.ref, {"fwd": 0, "dgrad": 1, "wgrad": 2}[mode], int(with_stats)).decode()
 
+    def kernel_variant(self, mode, with_stats=True, plan_n=None):
+        """Family + the grid-size dependent launch decisions (tile shape, workgroup size, split-K) of this call; with
+        `plan_n` the answer for a descriptor planned for that batch instead."""
+        d = self.d
+        if plan_n is not None:
+            d = ConvDesc.from_buffer_copy(self.d)
+            d.plan_n = plan_n
+        buf = C.create_string_buffer(128)
+        rc = lib.load().avsep_conv_kernel_variant(C.byref(d), {"fwd": 0, "dgrad": 1, "wgrad": 2}[mode], int(with_stats), buf, 128)
+        if rc != 0:
+            raise lib.AvsepError(f"avsep_conv_kernel_variant failed ({rc})")
+        return buf.value.decode()
+
     def head_applicable(self):
         """True when this (up2x, Cout <= 4) conv takes the fused decoder-head kernels (csrc/head.hip)."""
         return bool(lib.load().avsep_conv2d_head_applicable(self.ref))
@@ -110,8 +129,42 @@ class Conv:
         return dw, db
 
 
+class _StatsArena:
+    """Zeroed fp64 statistics buffers (BatchNorm sums, 2 x C doubles each) carved out of ONE device array that a single
+    memset clears, instead of one fill launch per buffer (120 per train step).  Every consumer of a buffer (bn_finalize /
+    bn_bwd_coeffs) is launched right after its producers on the same stream, so when the bump pointer wraps, the memset
+    that re-clears the array is ordered after all of them; a slice handed out is never live across a wrap as long as no
+    more than `capacity` doubles are requested between its allocation and its last use (a step uses ~40 K of the 2 M)."""
+
+    def __init__(self, device, capacity=1 << 21):
+        self.buf = torch.zeros((capacity,), dtype=torch.float64, device=device)
+        self.cap, self.off, self.stream = capacity, 0, torch.cuda.current_stream(device)
+
+    def take(self, n):
+        n = (n + 15) // 16 * 16                        # 128-byte granules: atomics of two buffers never share a line
+        if n > self.cap // 4 or torch.cuda.current_stream(self.buf.device) != self.stream:
+            return None
+        if self.off + n > self.cap:
+            self.buf.zero_()
+            self.off = 0
+        out = self.buf[self.off:self.off + n]
+        self.off += n
+        return out
+
+
+_arenas = {}
+
+
 def zeros_stats(c, like):
-    return torch.zeros((2 * c,), dtype=torch.float64, device=like.device)
+    """[2*c] zeroed doubles on like.device (see _StatsArena)."""
+    dev = like.device
+    arena = _arenas.get(dev)
+    if arena is None:
+        arena = _arenas[dev] = _StatsArena(dev)
+    out = arena.take(2 * c)
+    if out is None:
+        return torch.zeros((2 * c,), dtype=torch.float64, device=dev)
+    return out[:2 * c]
 
 
 def channel_stats(x, stats):
@@ -119,11 +172,12 @@ def channel_stats(x, stats):
     call("avsep_channel_stats", ptr(x), N, Cc, x.numel() // (N * Cc), ptr(stats))
 
 
-def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, like):
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, like, num_batches_tracked=None, updates=1):
     Cc = gamma.numel()
     out = _f32((4, Cc), like)  # scale, shift, mean, invstd
     call("avsep_bn_finalize", ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-         float(momentum), float(eps), Cc, int(training), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]))
+         float(momentum), float(eps), Cc, int(training), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
+         ptr(num_batches_tracked), int(updates))
     return out
 
 

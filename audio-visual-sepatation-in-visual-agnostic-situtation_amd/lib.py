@@ -24,7 +24,7 @@ class AvsepError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                "N Cin H W Cout Ho Wo KH KW stride pad dil C0 act0 act1 up2x prec".split()] + \
+                "N Cin H W Cout Ho Wo KH KW stride pad dil C0 act0 act1 up2x prec plan_n".split()] + \
                [(n, C.c_void_p) for n in "x0 x1 scale0 shift0 scale1 shift1".split()]
 
 
@@ -49,6 +49,7 @@ SIGNATURES = {
     "avsep_conv2d_dgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
     "avsep_conv2d_head_applicable": (C.c_int32, [_CD]),
     "avsep_conv_kernel_name": (C.c_char_p, [_CD, _I, _I]),
+    "avsep_conv_kernel_variant": (C.c_int, [_CD, _I, _I, C.c_char_p, _Z]),
     "avsep_space_to_depth2": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "avsep_maxpool_bn_relu_bwd_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_maxpool_bn_relu_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
@@ -58,7 +59,7 @@ SIGNATURES = {
     "avsep_conv2d_wgrad_workspace_bytes": (_Z, [_CD]),
     "avsep_conv2d_wgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
     "avsep_channel_stats": (C.c_int, [_P, _I, _I, _I, _P, _P]),
-    "avsep_bn_finalize": (C.c_int, [_P, _D, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P]),
+    "avsep_bn_finalize": (C.c_int, [_P, _D, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "avsep_bn_bwd_coeffs": (C.c_int, [_P, _D, _P, _P, _P, _I, _P, _P, _P, _P]),
     "avsep_bn_bwd_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "avsep_nhwc_stats_workspace_bytes": (C.c_size_t, [C.c_int64, _I]),

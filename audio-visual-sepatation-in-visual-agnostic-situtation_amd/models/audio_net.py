@@ -169,12 +169,8 @@ class Unet(nn.Module):
 def _bn_run(bn, stats, count, training, like, repeat=1):
     """scale/shift/mean/invstd rows for one BatchNorm; updates the running buffers in training
     (`repeat` times: a shared encoder stands for `repeat` identical forward passes of the reference)."""
-    for _ in range(repeat):
-        out = K.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                            BN_MOMENTUM, BN_EPS, training, like)
-    if training:
-        bn.num_batches_tracked += repeat
-    return out
+    return K.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                         BN_MOMENTUM, BN_EPS, training, like, bn.num_batches_tracked, repeat)
 
 
 def _acc(grads, p, g):

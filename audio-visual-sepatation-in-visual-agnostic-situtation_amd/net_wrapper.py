@@ -353,6 +353,8 @@ def adjust_learning_rate(optimizer, args):
     args.lr_frame *= 0.1
     if hasattr(args, "lr_motion"):
         args.lr_motion *= 0.1
+    if hasattr(args, "lr_synthesizer"):          # SoP++/main.py:649-654
+        args.lr_synthesizer *= 0.1
     for param_group in optimizer.param_groups:
         param_group["lr"] *= 0.1
 

@@ -102,6 +102,9 @@ def main(args):
                                         extra_size=args.num_channels)
         net_syn = builder.build_synthesizer(arch=args.arch_synthesizer, fc_dim=args.num_channels, weights=args.weights_synthesizer)
         net_pit = get_attmodule(args)(att_type=args.att_type)
+        if getattr(args, "weights_net_pit", ""):
+            print("Loading weights for net_pit")
+            net_pit.load_state_dict(torch.load(args.weights_net_pit))
         nets = (net_sound.to(device), net_frame.to(device), net_syn.to(device), net_pit.to(device))
         wrapper = sopp.NetWrapper(nets, builder.build_criterion(arch=args.loss, use_pit=True), builder.build_criterion(arch=args.loss))
         optimizer = sopp.create_optimizer(nets, args, world_size=world)
@@ -125,6 +128,8 @@ def main(args):
                 args.lr_sound = g["lr"]
             elif g["name"] == "frame_features":
                 args.lr_frame = g["lr"]
+            elif g["name"] == "synthesizer":
+                args.lr_synthesizer = g["lr"]
     if args.mode == "eval":
         evaluate(wrapper, loader_val, history, 0, args, True, device, world)
         evaluate(wrapper, loader_val, history, 0, args, False, device, world)
@@ -172,13 +177,17 @@ def main(args):
             err_total = err_av = err_ao = match_sum = 0.0
             av_count = ao_count = 0
             t_iter = t_data = 0.0
+        # main.py:756-760 drops the learning rates AFTER writing the checkpoint of the same iteration; with the shipped flags
+        # every lr step falls on a checkpoint iteration, so a checkpoint would hold the undecayed rates and a run resumed
+        # from it (which starts at i + 1) would never decay.  Dropping first changes nothing else: the rates are next used
+        # by step i + 1 either way.
+        if i in args.lr_steps:
+            adjust_learning_rate(optimizer, args)
         if i % args.eval_iter == 0 and i > 1:
             evaluate(wrapper, loader_val, history, i, args, True, device, world)
             evaluate(wrapper, loader_val, history, i, args, False, device, world)
             if rank == 0:
-                ckpt.checkpoint(nets[:2], history, i, args, optimizer=optimizer)
-        if i in args.lr_steps:
-            adjust_learning_rate(optimizer, args)
+                ckpt.checkpoint(nets, history, i, args, optimizer=optimizer)
     print("Training Done!")
     return history
 
@@ -187,12 +196,18 @@ def cli(argv=None):
     args = ArgParser().parse_train_arguments(argv)
     print("Model ID: {}".format(args.id))
     args.ckpt = os.path.join(args.ckpt, args.id)                   # main.py:776-791
+    three_stage = getattr(args, "train_steps", None) is not None
+    paths = None
     if args.mode == "train":
         os.makedirs(args.ckpt, exist_ok=True)
         if args.load_ckpt:
-            args.weights_sound, args.weights_frame = ckpt.resume_paths(args)
+            paths = ckpt.resume_paths(args, three_stage=three_stage)
     elif args.mode == "eval":
-        args.weights_sound, args.weights_frame = ckpt.resume_paths(args, best=True)
+        paths = ckpt.resume_paths(args, best=True, three_stage=three_stage)
+    if paths is not None:
+        args.weights_sound, args.weights_frame = paths[:2]
+        if three_stage:
+            args.weights_synthesizer, args.weights_net_pit = paths[2:]
     args.best_err = float("inf")
     return main(args)
 

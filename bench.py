@@ -14,8 +14,13 @@ the headline arithmetic; the same run then times, outside the headline's timed r
   * "f32_miopen_hybrid": round 1's configs[1] path (visual convolutions on PyTorch-ROCm/MIOpen), for comparison only;
   * the audio-only step and the 1:1 AV/AO alternation the shipped flags produce.
 
-Launch: python bench.py --gpus N --steps K --warmup W   (N>1: under torch.distributed.run).
-Prints ONE JSON line on rank 0.
+Launch: python bench.py --gpus N --steps K --warmup W.  With N > 1 and no WORLD_SIZE in the environment bench.py
+starts its own N ranks (python -m torch.distributed.run on 127.0.0.1, one process per GPU) BEFORE anything touches the
+GPU and relays rank 0's line; under an external torch.distributed.run it is a rank.  Prints ONE JSON line on rank 0.
+
+The headline is timed WITHOUT per-kernel instrumentation; a second pass of the same configuration with HIP-event pairs
+around every convolution launch gives `roofline` / `by_kernel` (its own ms/step is reported as
+`instrumented_ms_per_step`, so the cost of the event pairs is visible).
 """
 import argparse
 import gc
@@ -201,6 +206,67 @@ def cpu_baseline(P, seed):
                       f"steps each, medians: AV {av:.2f} s/step, AO {ao:.2f} s/step"}
 
 
+def self_launch(o):
+    """--gpus N > 1 without a launcher: start N ranks of this script under torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1) and relay their output.  This parent never initialises the GPU (importing torch does not),
+    so nothing is re-executed from a process that has touched it; the children are ordinary child processes."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // o.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={o.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:                                 # rank 0's JSON line (and nothing else) arrives on stdout
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def rehearse(o):
+    """--rehearse: launcher + rendezvous + barrier / MAX-over-ranks timing + JSON protocol of the N > 1 path with the train
+    step replaced by its ONLY collective — the all-reduce of one flat fp32 buffer of the step's gradient size (44,955,332
+    elements) — so the path can be run on CPU ranks over gloo (tests/test_bench_launcher.py) or on ranks
+    sharing one GPU.  It measures nothing about the kernels and says so in the line it prints."""
+    import torch.distributed as dist
+    import avsep_amd as P
+    rank, world, dev = P.dp.init_from_env()
+    n = 44955332 if o.rehearse_elems <= 0 else o.rehearse_elems
+    flat = torch.full((n,), float(rank + 1), dtype=torch.float32, device=dev)
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    for _ in range(max(o.warmup, 1)):
+        if world > 1:
+            dist.all_reduce(flat)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(o.steps):
+        if world > 1:
+            dist.all_reduce(flat)
+    sync()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "mixtures/sec (train step, 2-src MUSIC shape)", "value": None, "unit": "mixtures/s",
+                          "rehearsal": True, "n_gpus": o.gpus, "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "backend": dist.get_backend() if world > 1 else None, "device": dev.type,
+                          "steps": o.steps, "warmup": o.warmup, "allreduce_bytes_per_step": 4 * n,
+                          "allreduce_ms": t.item() / o.steps * 1e3, "scaling": "weak",
+                          "note": "launcher / rendezvous / collective rehearsal only: no train step was run"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer=None, use_vis=True):
     """Build the model from `seed`, run `warmup` untimed + `steps` timed train steps; returns the measurements."""
     import torch.distributed as dist
@@ -236,7 +302,9 @@ def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
+    active = [g for g in opt.param_groups if use_vis or g["name"] == "sound"]
     res = {"value": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "loss": float(err),
+           "allreduce_bytes_per_step": 4 * sum(g["range"][1] - g["range"][0] for g in active) if world > 1 else 0,
            "match_loss": float(match) if match is not None else None,
            "first_step_loss": first[0] if first else None, "first_step_match_loss": first[1] if first else None}
     del wrap, opt, snd, frm, raw
@@ -299,19 +367,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--layers", default=None, help="write a per-convolution-call table of the headline step to this file")
+    ap.add_argument("--rehearse", action="store_true", help="launcher / rendezvous / all-reduce rehearsal without a train step "
+                    "(runs on CPU ranks over gloo too); prints a line marked \"rehearsal\": true")
+    ap.add_argument("--rehearse-elems", type=int, default=0, help="elements of the rehearsal's flat buffer (default: the step's)")
     o = ap.parse_args()
+
+    if o.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(o))                 # before anything touches the GPU
+    if o.rehearse:
+        return rehearse(o)
 
     import avsep_amd as P
     rank, world, dev = P.dp.init_from_env()
     if world != o.gpus:
-        raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}")
     if dev.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     import torch.distributed as dist
 
     seed, B = 1234, o.batch
+    # headline: un-instrumented.  Then the same configuration once more with HIP-event pairs around every conv launch
+    head = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup)
     timer = KernelTimer(P.kernels)
-    head = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup, timer)
+    inst = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, min(o.warmup, 1), timer)
     kernels = timer.summary(o.steps)
     if o.layers and rank == 0:
         rows = sorted(timer.layers.items(), key=lambda kv: -kv[1][0])
@@ -323,19 +401,20 @@ def main():
     extras = {}
     if world == 1 and not o.no_extra:
         other = "bf16" if o.precision == "f32" else "f32"
-        r = run_config(P, dev, world, seed, rank, other, "hip", B, o.steps, o.warmup, timer)
+        r = run_config(P, dev, world, seed, rank, other, "hip", B, o.steps, o.warmup)
+        r_inst = run_config(P, dev, world, seed, rank, other, "hip", B, o.steps, 1, timer)
         k2 = timer.summary(o.steps)
         roof2, step2, _ = roofline_of(k2, other, r["ms_per_step"], B)
         add_traffic(roof2, other, B)
-        r.update({"dtype": other, "roofline": roof2, "roofline_step": step2,
+        r.update({"dtype": other, "roofline": roof2, "roofline_step": step2, "instrumented_ms_per_step": r_inst["ms_per_step"],
                   "first_step_loss_abs_diff_vs_headline": abs(r["first_step_loss"] - head["first_step_loss"]),
                   "workload": "same step, conv operands rounded to bf16 while staged, fp32 accumulate / BatchNorm statistics / "
                               "loss / master weights / SGD (BASELINE configs[2])" if other == "bf16" else "same step in fp32",
                   "by_kernel": {k: {"ms_per_step": round(v["ms_per_step"], 3), "tflops": round(v["tflops"], 1)} for k, v in k2.items()}})
         extras[other] = r
-        hyb = run_config(P, dev, world, seed, rank, "f32", "hybrid", min(B, 32), max(3, o.steps // 2), 2)
-        extras["f32_miopen_hybrid"] = dict(hyb, workload="round-1 configs[1] path at batch %d: visual convolutions on PyTorch-ROCm/"
-                                           "MIOpen, HIP BatchNorm glue; comparison only, not this build's kernels" % min(B, 32))
+        hyb = run_config(P, dev, world, seed, rank, "f32", "hybrid", B, max(3, o.steps // 2), 2)
+        extras["f32_miopen_hybrid"] = dict(hyb, workload="round-1 configs[1] path at the headline batch %d: visual convolutions on "
+                                           "PyTorch-ROCm/MIOpen, HIP BatchNorm glue; comparison only, not this build's kernels" % B)
         ao = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, max(3, o.steps // 2), 2, use_vis=False)
         extras["ao_step_mixtures_per_s"] = ao["value"]
         extras["av_ao_1to1_blend_mixtures_per_s"] = 2.0 / (1.0 / head["value"] + 1.0 / ao["value"])
@@ -350,6 +429,9 @@ def main():
             "metric": "mixtures/sec (train step, 2-src MUSIC shape)", "value": head["value"],
             "unit": "mixtures/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "allreduce_bytes_per_step": head["allreduce_bytes_per_step"],      # ONE flat fp32 gradient all-reduce per step and rank
+            "instrumented_ms_per_step": inst["ms_per_step"],   # the pass `roofline` / `by_kernel` come from (event pairs around every conv)
             "dtype": o.precision, "data": "synthetic",
             "config": {"workload": "full HIP path, AV train step: 2-source mix, batch %d/GPU (BASELINE configs[2] shape), 65535-sample "
                        "waveforms -> HIP STFT 1022/256 -> 256x256 log-freq tiles, 3x224^2 frames/source, unet7+hidsep(sig)+"

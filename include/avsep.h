@@ -66,6 +66,11 @@ typedef struct avsep_conv_desc {
   int32_t prec;                /* AVSEP_PREC_F32 (0): exact f32 MFMA; AVSEP_PREC_BF16 (1): operands rounded to bf16 while they are
                                   staged, fp32 accumulation / statistics / outputs (BASELINE.json configs[2]); geometries without a
                                   bf16 kernel run in f32 */
+  int32_t plan_n;              /* batch the launch heuristics are PLANNED for (0 = N).  Tile sizes, split-K and the kernel family
+                                  of a call depend on how many workgroups its grid has, i.e. on N; with plan_n = 64 a batch-8
+                                  call takes the decisions of the batch-64 call (grids and workspaces stay those of N).  The
+                                  parity tests use it to run the benched dispatch at an oracle-sized batch; results never
+                                  depend on it beyond the summation order of the chosen kernel. */
   const float* x0;
   const float* x1;
   const float* scale0;         /* [C0] or NULL */
@@ -109,6 +114,11 @@ int32_t avsep_conv2d_head_applicable(const avsep_conv_desc* d);
  * "igemm_kernel<fwd|dgrad|wgrad>", "head_*_kernel", "smallco_*", "smallci_dgrad"): measurement bookkeeping
  * (bench.py groups its HIP-event timings by it), static strings, never freed. */
 const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t mode, int32_t with_stats);
+/* The same plus every launch decision that depends on the size of the grid (tile shape, 64- / 128-row tiles, 256- / 512-
+ * thread workgroups, split-K), e.g. "convbf_kernel:8x32,128x256", "conv3x3_kernel:4x32,BM64", "igemm_kernel<fwd>:BM64,split6":
+ * two descriptors with equal variants run the same kernel instantiation.  The parity tests assert that a batch-8 step
+ * planned for the bench batch (desc.plan_n) has, layer by layer, the variants of the batch-64 step bench.py times. */
+int avsep_conv_kernel_variant(const avsep_conv_desc* d, int32_t mode, int32_t with_stats, char* buf, size_t cap);
 int avsep_conv2d_dgrad_up2x(const avsep_conv_desc* d, const float* w, const float* dy, float* g0,
                             float* g1, const float* mean1, const float* invstd1, double* bstats1,
                             int32_t acc0, avsep_stream_t stream);
@@ -176,11 +186,14 @@ int avsep_nhwc_maxpool_bn_relu_bwd(const float* g, const uint32_t* taps, const f
 int avsep_channel_stats(const float* x, int32_t N, int32_t C, int32_t HW, double* stats,
                         avsep_stream_t stream);
 /* From (sum,sumsq) -> scale=gamma*invstd, shift=beta-mean*scale, mean, invstd; updates the
- * running buffers (momentum, unbiased var) when training!=0; with training==0 uses them. */
+ * running buffers (momentum, unbiased var) when training!=0; with training==0 uses them.
+ * `updates` >= 1: the running buffers receive that many momentum updates and num_batches_tracked
+ * (nn.BatchNorm2d's int64 counter, may be NULL) is incremented by it — a shared encoder stands for
+ * several identical forward passes of the reference (main.py:128-141). */
 int avsep_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps,
                       int32_t C, int32_t training, float* scale, float* shift, float* mean,
-                      float* invstd, avsep_stream_t stream);
+                      float* invstd, int64_t* num_batches_tracked, int32_t updates, avsep_stream_t stream);
 /* Backward of train-mode BN given dz (grad wrt BN output) sums: bstats[2*C] = (sum dz, sum dz*xhat).
  * Writes dgamma,dbeta and the coefficients of dy = p*dz + q*y + r (p,q,r: [C] each).     */
 int avsep_bn_bwd_coeffs(const double* bstats, double count, const float* gamma, const float* mean,

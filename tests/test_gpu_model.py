@@ -526,6 +526,142 @@ def _full_size_step_body(dev, log_freq, backend, prec, err_tol, P, O, OS, OC, OS
                 assert abs(match.item() - omatch) <= max(1e-4, err_tol)
 
 
+# ---- the dispatch bench.py times (batch 64), under the full-size oracle parity test --------------------------------------
+# Kernel family, tile shape, workgroup size and split-K of a convolution call depend on the size of its grid, i.e. on the
+# batch: at batch 2 most layers of the step do NOT run the Winograd / 512-thread bf16 instantiations that make up the
+# benched batch-64 step.  These tests run the full-size AV + AO step at batch 8 with every descriptor PLANNED for batch
+# 64 (avsep_conv_desc.plan_n: decisions of the batch-64 call, grids of the batch-8 call), assert layer by layer that the
+# launched variant is the variant of the real batch-64 descriptor, and compare with the CPU oracle at batch 8.
+BENCH_BATCH, DISPATCH_TEST_BATCH = 64, 8
+
+
+class _DispatchLog:
+    """Records (geometry, mode, launched variant, variant of the same call at the bench batch) of every conv call."""
+
+    def __init__(self, K, scale):
+        self.K, self.scale, self.rows, self.orig = K, scale, [], {}
+        for name in ("fwd", "dgrad", "wgrad", "dgrad_up2x"):
+            self._wrap(name)
+
+    def _wrap(self, name):
+        orig, log = getattr(self.K.Conv, name), self
+        self.orig[name] = orig
+
+        def wrapped(cv, *a, **kw):
+            mode = "dgrad" if name == "dgrad_up2x" else name
+            with_stats = bool(len(a) > 2 and a[2] is not None) or kw.get("stats") is not None
+            launched = cv.kernel_variant(mode, with_stats)
+            bench = log.K.ConvDesc.from_buffer_copy(cv.d)              # the descriptor bench.py builds for this layer
+            bench.N, bench.plan_n = cv.N * log.scale, 0
+            import ctypes
+            buf = ctypes.create_string_buffer(128)
+            assert log.K.lib.load().avsep_conv_kernel_variant(ctypes.byref(bench), {"fwd": 0, "dgrad": 1, "wgrad": 2}[mode],
+                                                               int(with_stats), buf, 128) == 0
+            geom = (cv.Cin, cv.H, cv.W, cv.Cout, cv.KH, cv.d.stride, cv.d.dil, cv.d.up2x)
+            log.rows.append((geom, mode, launched, buf.value.decode()))
+            return orig(cv, *a, **kw)
+        setattr(self.K.Conv, name, wrapped)
+
+    def close(self):
+        for name, orig in self.orig.items():
+            setattr(self.K.Conv, name, orig)
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle_full_size_b8(P, O, OS, OC, OST, np):
+    """One AV then one AO oracle train step (CPU, fp32) at the dispatch-test batch; computed once for both precisions."""
+    if "r" in _ORACLE_CACHE:
+        return _ORACLE_CACHE["r"]
+    a = P.arguments.train_music_args()
+    a.stft_pad_mode = "reflect"
+    raw = P.synth.make_batch(DISPATCH_TEST_BATCH, a.num_mix, a.num_frames, 224, a.audLen, seed=78)
+    mags = [torch.from_numpy(np.stack([OST.stft_mag_phase(w.numpy())[0] for w in src]))[:, None] for src in raw["audios"]]
+    mix = torch.from_numpy(np.stack([OST.stft_mag_phase(w.numpy())[0] for w in raw["audio_mix"]]))[:, None]
+    torch.manual_seed(13)
+    gen = torch.Generator().manual_seed(13)
+    osnd = O.build_sound(a.arch_sound, a.num_channels, a.fusion_type, a.att_type)
+    O.wide_init(osnd, gen)
+    ofrm = O.build_frame(a.arch_frame, a.vis_channels, a.img_pool)
+    init = ({k: v.clone() for k, v in osnd.state_dict().items()}, {k: v.clone() for k, v in ofrm.state_dict().items()})
+    owrap = OS.NetWrapper((osnd, ofrm), OC.build_criterion(a.loss, True), OC.build_criterion(a.loss))
+    oopt = OS.create_optimizer((osnd, ofrm), a)
+    draws = torch.arange(DISPATCH_TEST_BATCH) % 3 == 0
+    steps = []
+    for use_vis in (True, False):
+        osnd.levels()[-1].fusion.ao_draws = draws
+        cb = {"mag_mix": mix.clone(), "mags": [m.clone() for m in mags], "frames": raw["frames"]}
+        oerr, omatch, oouts = OS.train_step(owrap, cb, oopt, use_vis, a)
+        steps.append((oerr, omatch, [m.detach().clone() for m in oouts["pred_masks"]]))
+    _ORACLE_CACHE["r"] = (a, raw, init, draws, steps)
+    return _ORACLE_CACHE["r"]
+
+
+@pytest.mark.parametrize("prec,err_tol", [("f32", 1e-4), ("bf16", 2e-3)])
+def test_benched_dispatch_full_size_step_vs_oracle(dev, prec, err_tol):
+    """Full-size (256x256 tiles, 3x224^2 frames, unet7 + resnet18dilated) AV + AO train step on the kernel instantiations
+    bench.py times at batch 64, against the CPU oracle: mask MSE <= 1e-4 (north star), loss |d| <= 1e-4 (fp32) /
+    2e-3 (bf16 operands), and per layer launched variant == variant of the batch-64 descriptor."""
+    import numpy as np
+    P = _pkg()
+    from oracle import nets as O, step as OS, criterion as OC, stft as OST
+    K = P.kernels
+    K.ConvDesc = P.lib.ConvDesc
+    a, raw, init, draws, osteps = _oracle_full_size_b8(P, O, OS, OC, OST, np)
+    scale = BENCH_BATCH // DISPATCH_TEST_BATCH
+    K.set_precision(prec)
+    K.plan_batch_scale = scale
+    log = _DispatchLog(K, scale)
+    try:
+        mb = P.ModelBuilder()
+        snd = mb.build_sound(arch=a.arch_sound, fc_dim=a.num_channels, fusion_type=a.fusion_type, att_type=a.att_type)
+        frm = mb.build_frame(arch=a.arch_frame, fc_dim=a.vis_channels, pool_type=a.img_pool)
+        snd.load_state_dict(init[0]); frm.load_state_dict(init[1])
+        snd, frm = snd.to(dev), frm.to(dev)
+        frm.backend = "hip"
+        wrap = P.NetWrapper((snd, frm), mb.build_criterion(a.loss, use_pit=True), mb.build_criterion(a.loss))
+        opt = P.create_optimizer((snd, frm), a)
+        for (oerr, omatch, omasks), use_vis in zip(osteps, (True, False)):
+            snd.ao_draws = draws
+            gb = {"audios": [w.to(dev) for w in raw["audios"]], "audio_mix": raw["audio_mix"].to(dev),
+                  "frames": [f.to(dev) for f in raw["frames"]]}
+            err, match, outs = P.net_wrapper.train_step_async(wrap, gb, opt, use_vis, a)
+            mse = max(((x.detach().cpu() - y) ** 2).mean().item() for x, y in zip(outs["pred_masks"], omasks))
+            print(f"benched dispatch {prec} {'AV' if use_vis else 'AO'}: err hip={err.item():.6f} oracle={oerr:.6f} "
+                  f"|d|={abs(err.item() - oerr):.2e} mask-MSE={mse:.2e}")
+            assert mse <= 1e-4, f"mask MSE {mse} ({prec}, use_vis={use_vis})"
+            assert abs(err.item() - oerr) <= err_tol * max(1.0, abs(oerr)), (prec, use_vis, err.item(), oerr)
+            if use_vis:
+                assert abs(match.item() - omatch) <= max(1e-4, err_tol)
+    finally:
+        log.close()
+        K.plan_batch_scale = 1
+        K.set_precision("f32")
+    assert len(log.rows) > 150, len(log.rows)          # AV: 2 decoder passes + 20 trunk convs, fwd + dgrad + wgrad; AO: one pass
+    wrong = [r for r in log.rows if r[2] != r[3]]
+    assert not wrong, "launched variant != variant of the batch-%d call: %s" % (BENCH_BATCH, wrong[:5])
+    fams = {}
+    for geom, mode, launched, _ in log.rows:
+        fams.setdefault(launched.split(":")[0], set()).add((geom, mode))
+    print("families:", {k: len(v) for k, v in fams.items()})
+    # the families profiles/r02_layers_*.txt lists for the batch-64 step
+    if prec == "f32":
+        for must in ("wino_kernel", "winow_kernel", "wgrad4d_kernel", "conv3x3_kernel", "head_fwd_kernel", "head_dgrad_kernel",
+                     "head_wgrad_kernel"):
+            assert must in fams, (must, sorted(fams))
+        # every 3x3/s1 conv with >= 64 input channels on an even map >= 8x8 is a Winograd launch, in all three modes
+        for geom, mode, launched, _ in log.rows:
+            cin, h, w, cout, k, s, dil, up = geom
+            if k == 3 and s == 1 and not up and cin >= 64 and cout >= 64 and h >= 8 and h % 2 == 0:
+                assert launched.split(":")[0] in ("wino_kernel", "winow_kernel"), (geom, mode, launched)
+    else:
+        for must in ("convbf_kernel", "wgradbf_kernel", "wgrad4bf_kernel"):
+            assert must in fams, (must, sorted(fams))
+        big = [r for r in log.rows if r[2].startswith("convbf_kernel") and r[2].endswith("x256")]
+        assert len(big) >= 20, "the 512-thread (256-pixel) bf16 tiles must be on the tested path: %d" % len(big)
+
+
 def test_eval_path_vs_oracle(dev):
     """N1: un-warp -> threshold -> mask*mag -> iSTFT -> SI-SDR / SDR on the GPU against the numpy/torch-CPU oracle."""
     import numpy as np
@@ -946,3 +1082,53 @@ def test_training_driver_end_to_end(dev, tmp_path):
     ev = T.cli(flags + ["--mode", "eval"])
     assert ev["val_av"]["iter"] == [0] and ev["val_ao"]["iter"] == [0]
     assert abs(ev["val_ao"]["si_sdr"][0] - hist["val_ao"]["si_sdr"][0]) < 1e-3      # same weights as at iteration 4
+
+
+def test_three_stage_driver_checkpoint_resume_and_lr(dev, tmp_path):
+    """SoP++ three-stage driver (train.py --train_steps): checkpoint() must write the synthesizer and the attention module
+    like SoP++/main.py:599-631, --load_ckpt must restore all four nets + momentum + iteration + DECAYED learning rates
+    (the lr step of iteration 4 falls on the checkpoint iteration, as with the shipped flags), and --mode eval must score
+    the weights that were saved (a randomly re-initialised synthesizer would not reproduce the SI-SDR)."""
+    import os
+    P = _pkg()
+    from avsep_amd import train as T
+    from test_dataset import _make_disk_dataset
+    lst = _make_disk_dataset(str(tmp_path))
+    flags = ("--id run3 --ckpt {ck} --av_list_train {l} --ao_list_train {l} --list_val {l} --start_av_first --num_fsteps 0 "
+             "--arch_sound unet5 --arch_frame resnet18dilated --arch_synthesizer linear --img_pool maxpool --num_channels 8 "
+             "--img_activation sigmoid --sound_activation no --output_activation sigmoid --vis_channels 8 --fusion_type Base "
+             "--not_pool_vis --att_type sig --binary_mask 1 --loss bce --weighted_loss 1 --num_mix 2 --log_freq 1 --num_frames 1 "
+             "--stride_frames 2 --imgSize 64 --audLen 16383 --margin 1.0 --batch_size_per_gpu 2 --workers 0 --train_repeat 1 "
+             "--val_repeat 1 --lr_steps 4 --num_iters 5 --iter_per_av 2 --eval_iter 4 --disp_iter 2 --max_silent 0.87 "
+             "--lr_synthesizer 1e-2 --train_steps 2 3 20").format(ck=str(tmp_path / "ck"), l=lst).split()
+    hist = T.cli(flags)
+    ck = str(tmp_path / "ck" / "run3")
+    assert sorted(os.listdir(ck)) == ["frame_best.pth", "frame_latest.pth", "history_latest.pth", "net_pit_best.pth",
+                                      "net_pit_latest.pth", "optim_latest.pth", "sound_best.pth", "sound_latest.pth",
+                                      "synthesizer_best.pth", "synthesizer_latest.pth"]
+    blob = torch.load(os.path.join(ck, "optim_latest.pth"))
+    assert blob["itera"] == 4
+    lrs = {g["name"]: g["lr"] for g in blob["state"]["groups"]}
+    assert abs(lrs["sound"] - 1e-4) < 1e-12 and abs(lrs["synthesizer"] - 1e-3) < 1e-12, lrs    # decayed BEFORE the checkpoint
+    syn_saved = torch.load(os.path.join(ck, "synthesizer_latest.pth"))
+    assert (syn_saved["scale"] - 1.0).abs().max().item() > 1e-5, "the synthesizer trained (lr 1e-2): its scale left the init"
+    # eval mode scores the saved weights: same SI-SDR as the in-training evaluation at iteration 4
+    ev = T.cli(flags + ["--mode", "eval"])
+    assert abs(ev["val_ao"]["si_sdr"][0] - hist["val_ao"]["si_sdr"][0]) < 1e-3
+    assert abs(ev["val_av"]["si_sdr"][0] - hist["val_av"]["si_sdr"][0]) < 1e-3
+    # resume: iteration counter, decayed rates and all four nets come back
+    seen = {}
+    orig = P.sopp.train_step_3stage
+
+    def spy(model, batch, optimizer, use_vis, i, args):
+        if not seen:
+            seen["i"], seen["lr"] = i, {g["name"]: g["lr"] for g in optimizer.param_groups}
+            seen["scale"] = model.net_synthesizer.scale.detach().cpu().clone()
+        return orig(model, batch, optimizer, use_vis, i, args)
+    T.sopp.train_step_3stage = spy
+    try:
+        T.cli([f if f != "5" else "7" for f in flags] + ["--load_ckpt", "1"])
+    finally:
+        T.sopp.train_step_3stage = orig
+    assert seen["i"] == 5 and abs(seen["lr"]["sound"] - 1e-4) < 1e-12 and abs(seen["lr"]["synthesizer"] - 1e-3) < 1e-12, seen
+    assert torch.equal(seen["scale"], syn_saved["scale"])

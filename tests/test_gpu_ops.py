@@ -62,7 +62,8 @@ CONV_CASES = [
     (3, 64, 14, 14, 144, 1, 1, 0, 1),      # 1x1 (layer4.0 downsample)
     (2, 32, 28, 28, 48, 1, 2, 0, 1),       # 1x1 / stride 2: dgrad zero-fills the skipped pixels
     (40, 128, 28, 28, 256, 1, 2, 0, 1),    # 1x1 / stride 2 at the layer3.0 downsample shape, 128-row tiles both ways
-    # conv_wino.hip: Winograd F(2x2, 3x3) forward + data gradient (needs >= 256 workgroups, hence the batch sizes)
+    # conv_wino.hip: Winograd F(2x2, 3x3) forward + data gradient (needs >= 128 workgroups, conv_wino.hip wn_applicable,
+    # hence the batch sizes); the kernel family of these rows is ASSERTED (EXPECT_FAMILY below)
     (64, 48, 32, 32, 80, 3, 1, 1, 1),      # one 8x8-tile group per workgroup (U-Net decoder maps), ragged second M tile
     (22, 64, 56, 56, 72, 3, 1, 1, 1),      # four 4x4-tile groups (56x56: 7x7 groups per image)
     (80, 48, 28, 28, 72, 3, 1, 1, 1),      # two 2x16-tile groups (28x28)
@@ -82,6 +83,22 @@ CONV_CASES = [
 ]
 
 
+def _rows_after(marker_case, count):
+    i = CONV_CASES.index(marker_case)
+    return CONV_CASES[i:i + count]
+
+
+# kernel family a row exists to exercise: a moved dispatch threshold must fail the test, not silently fall back to the
+# direct-form kernel (which passes the same numeric bound)
+EXPECT_FAMILY = {}
+for _c in _rows_after((64, 48, 32, 32, 80, 3, 1, 1, 1), 7):
+    EXPECT_FAMILY[_c] = {"fwd": "wino_kernel", "dgrad": "wino_kernel"}
+for _c in _rows_after((64, 64, 32, 32, 80, 3, 1, 1, 1), 4):
+    EXPECT_FAMILY[_c] = {"fwd": "wino_kernel", "dgrad": "wino_kernel", "wgrad": "winow_kernel"}
+for _c in _rows_after((64, 64, 32, 32, 80, 4, 2, 1, 1), 3):
+    EXPECT_FAMILY[_c] = {"wgrad": "wgrad4d_kernel"}
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(dev, case):
     K = _pkg().kernels
@@ -96,6 +113,8 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     y_ref.backward(dy)
     xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
     cv = K.Conv(xd, Cout, k, s, p, d)
+    for mode, fam in EXPECT_FAMILY.get(case, {}).items():
+        assert cv.kernel_name(mode) == fam, (case, mode, cv.kernel_variant(mode))
     st = K.zeros_stats(Cout, xd)
     y = cv.fwd(cv.pack(wd, 0), bd, st)
     assert_close(y, y_ref, 2e-5, "fwd")
@@ -740,7 +759,8 @@ def test_channels_last_stem_tail(dev, N, C, H, W):
 
 
 @pytest.mark.parametrize("att", ["sig", "cos"])
-@pytest.mark.parametrize("B,S,K,H,W", [(3, 2, 32, 14, 28), (2, 3, 8, 5, 7), (1, 4, 128, 20, 40)])
+@pytest.mark.parametrize("B,S,K,H,W", [(3, 2, 32, 14, 28), (2, 3, 8, 5, 7), (1, 4, 128, 20, 40),
+                                       (1, 4, 128, 64, 64)])     # the limit shape of the ABI: 67 KB / 151 KB of dynamic LDS
 def test_attmodel_core_kernel(dev, att, B, S, K, H, W):
     """csrc/attention.hip (SoP++/attention_net.py:24-58: similarity maps, match term, clamp, context vectors) against the
     same formula in float64 torch with autograd: values and the gradients wrt the audio queries and the visual map,
