@@ -188,7 +188,8 @@ extern "C" int avsep_affine_act(const float* y, const float* scale, const float*
 // grid (C, chunks).  V = 4: HW % 4 == 0, 16-byte loads / stores and one 32-bit division per four elements (the scalar
 // form spent a 64-bit division and a modulo per element: ~1.5 TB/s on the trunk's tensors)
 template <int V>
-__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ dz2,
+                                                             const float* __restrict__ y,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
                                                              const float* __restrict__ res,
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
     const int n = i / HWv, q = i - n * HWv;
     const long long o = ((long long)n * C + c) * HW + (long long)q * V;
     const fv yv = *reinterpret_cast<const fv*>(y + o), dv = *reinterpret_cast<const fv*>(dz + o);
-    fv rv, av, gv;
+    fv rv, av, gv, d2;
+    if (dz2) d2 = *reinterpret_cast<const fv*>(dz2 + o);
     if (res) rv = *reinterpret_cast<const fv*>(res + o);
     if (add) av = *reinterpret_cast<const fv*>(add + o);
 #pragma unroll
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
       const float yk = yv[k];
       float pre = fmaf(yk, sc, sh);
       if (res) pre += fmaf(rv[k], rs, rh);
-      float gk = act_grad(pre, act) * dv[k];
+      float gk = act_grad(pre, act) * (dz2 ? dv[k] + d2[k] : dv[k]);
       if (add) gk += av[k];
       gv[k] = gk;
       s1 += gk;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
   }
 }
 
-extern "C" int avsep_affine_act_bwd(const float* dz, const float* y, const float* scale, const float* shift,
+extern "C" int avsep_affine_act_bwd(const float* dz, const float* dz2, const float* y, const float* scale, const float* shift,
                                     const float* residual, const float* res_scale, const float* res_shift,
                                     const float* add, const float* mean, const float* invstd, int32_t act, int32_t N,
                                     int32_t C, int32_t HW, float* dz_pre, double* bstats, avsep_stream_t stream) {
@@ -251,10 +253,10 @@ extern "C" int avsep_affine_act_bwd(const float* dz, const float* y, const float
   int chunks = (int)min((long long)cdiv(2048, C), (total + 2047) / 2048);
   if (chunks < 1) chunks = 1;
   if ((HW & 3) == 0)
-    hipLaunchKernelGGL(affine_act_bwd_kernel<4>, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, y, scale, shift,
+    hipLaunchKernelGGL(affine_act_bwd_kernel<4>, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, dz2, y, scale, shift,
                        residual, res_scale, res_shift, add, mean, invstd, act, N, C, HW, dz_pre, bstats);
   else
-    hipLaunchKernelGGL(affine_act_bwd_kernel<1>, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, y, scale, shift,
+    hipLaunchKernelGGL(affine_act_bwd_kernel<1>, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, dz2, y, scale, shift,
                        residual, res_scale, res_shift, add, mean, invstd, act, N, C, HW, dz_pre, bstats);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;

@@ -120,9 +120,13 @@ class Conv:
              ptr(bstats1), int(g0_acc is not None))
         return g0, g1
 
-    def wgrad(self, dy, want_bias=False):
-        dw = _f32((self.Cout, self.Cin, self.KH, self.KW), self.like)
-        db = _f32((self.Cout,), self.like) if want_bias else None
+    def wgrad(self, dy, want_bias=False, out=None, out_bias=None):
+        """dw (and dbias); `out` / `out_bias`: dense destinations to write into (e.g. a parameter's flat .grad view)."""
+        shape = (self.Cout, self.Cin, self.KH, self.KW)
+        if out is not None and (tuple(out.shape) != shape or not out.is_contiguous() or out.dtype != torch.float32):
+            raise lib.AvsepError("wgrad destination must be a dense fp32 OIHW tensor")
+        dw = out if out is not None else _f32(shape, self.like)
+        db = (out_bias if out_bias is not None else _f32((self.Cout,), self.like)) if want_bias else None
         nbytes = lib.load().avsep_conv2d_wgrad_workspace_bytes(self.ref)
         ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=self.like.device)
         call("avsep_conv2d_wgrad", self.ref, ptr(dy), ptr(dw), ptr(db), ptr(ws), nbytes)
@@ -181,9 +185,12 @@ def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training,
     return out
 
 
-def bn_bwd_coeffs(bstats, count, gamma, mean, invstd):
+def bn_bwd_coeffs(bstats, count, gamma, mean, invstd, dgamma=None, dbeta=None):
+    """(dgamma, dbeta, pqr); `dgamma` / `dbeta`: destinations to write into instead of fresh tensors."""
     Cc = gamma.numel()
-    dgamma, dbeta, pqr = _f32((Cc,), gamma), _f32((Cc,), gamma), _f32((3, Cc), gamma)
+    dgamma = dgamma if dgamma is not None else _f32((Cc,), gamma)
+    dbeta = dbeta if dbeta is not None else _f32((Cc,), gamma)
+    pqr = _f32((3, Cc), gamma)
     call("avsep_bn_bwd_coeffs", ptr(bstats), float(count), ptr(gamma), ptr(mean), ptr(invstd), Cc,
          ptr(dgamma), ptr(dbeta), ptr(pqr))
     return dgamma, dbeta, pqr
@@ -206,11 +213,11 @@ def affine_act(y, scale, shift, residual, act, res_scale=None, res_shift=None):
 
 
 def affine_act_bwd_(dz, y, scale, shift, residual, add, mean, invstd, act, bstats, res_scale=None, res_shift=None,
-                    out=None):
-    """dz <- act'(scale*y+shift[+res]) * dz (+ add) (in place unless `out`); accumulates bstats."""
+                    out=None, dz2=None):
+    """dz <- act'(scale*y+shift[+res]) * (dz [+ dz2]) (+ add) (in place unless `out`); accumulates bstats."""
     N, Cc = y.shape[:2]
     dst = dz if out is None else out
-    call("avsep_affine_act_bwd", ptr(dz), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift),
+    call("avsep_affine_act_bwd", ptr(dz), ptr(dz2), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift),
          ptr(add), ptr(mean), ptr(invstd), act, N, Cc, y.numel() // (N * Cc), ptr(dst), ptr(bstats))
     return dst
 

@@ -72,7 +72,7 @@ SIGNATURES = {
     "avsep_nhwc_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "avsep_nhwc_maxpool_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "avsep_affine_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "avsep_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "avsep_relu_up2x_fwd": (C.c_int, [_KD, _P, _P]),
     "avsep_relu_up2x_bwd": (C.c_int, [_KD, _P, _P, _P, _P, _P, _P, _I, _P]),
     "avsep_prepare": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -82,6 +82,10 @@ SIGNATURES = {
                                       _P, _P, _P, _P]),
     "avsep_fusion_ao_fwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "avsep_fusion_ao_bwd": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "avsep_fusion_n_av_fwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "avsep_fusion_n_av_bwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "avsep_fusion_n_ao_fwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_fusion_n_ao_bwd": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "avsep_mask_loss_fwd": (C.c_int, [_P, _P, _P, C.c_int64, _I, _I, _I, _I, _I, _P, _P, _P]),
     "avsep_mask_loss_bwd": (C.c_int, [_P, _P, _P, C.c_int64, _P, _I, _I, _I, _I, _I, _P, _P]),
     "avsep_stft_basis_floats": (_Z, [_I, _I]),

@@ -5,12 +5,10 @@
 ``run_backward`` are what the U-Net autograd node calls; ``forward(x, v_ls)`` is the standalone
 module interface ``(cat(tiles, x), (match_loss, att_maps))`` of the reference.
 """
-import itertools
 import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import lib
 from ..lib import call, ptr
@@ -32,54 +30,53 @@ class _FusionBase(nn.Module):
 
     # ------------------------------------------------------------------ C > 2 sources (BASELINE.json configs[4])
     # BUILD-DEFINED generalisation, no reference counterpart (the reference hard-codes C = P = 2, fusion_net.py:35,43-46);
-    # the rules are stated in DESIGN.md §9 (and restated on the CPU by the test infrastructure): Dc = D // C, the
-    # audio blocks are the first C*Dc pooled channels, the remainder's tile channels are zero (the fused tensor keeps
-    # 2*D channels, so the U-Net's parameter shapes do not depend on C), all C! permutations in itertools order, first
-    # maximum wins.  This path (0.3 MMAC per sample, latency only) runs as a torch sub-graph on the device inside the
-    # U-Net's autograd node; the two-source kernels of csrc/fusion.hip are untouched.
+    # the rules are stated in DESIGN.md §9 and in csrc/fusion_n.hip (restated on the CPU by the test infrastructure):
+    # Dc = D // C, the audio blocks are the first C*Dc pooled channels, the remainder's tile channels are zero (the fused
+    # tensor keeps 2*D channels, so the U-Net's parameter shapes do not depend on C), all C! permutations in itertools
+    # order, first maximum wins.  One launch forward, one backward (avsep_fusion_n_*), like the two-source kernels.
     num_src = 2
+
+    @staticmethod
+    def _ptr_array(tensors):
+        import ctypes
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
 
     def _run_forward_n(self, x, vs, draws):
         B, D, Fq, T = x.shape
         C = len(vs) if vs else self.num_src
+        dev = x.device
+        out = {"n": C, "feat": torch.empty((B, D), dtype=torch.float32, device=dev),
+               "pool_idx": torch.empty((B, D), dtype=torch.int32, device=dev)}
+        if not vs:
+            out["draws"] = draws.to(device=dev, dtype=torch.int32).contiguous()
+            call("avsep_fusion_n_ao_fwd", ptr(x), ptr(out["draws"]), B, C, D, Fq * T, ptr(out["feat"]), ptr(out["pool_idx"]))
+            return out
         Dc = D // C
-        table = torch.tensor(list(itertools.permutations(range(C))), device=x.device)
-        with torch.enable_grad():
-            xg = x.detach().requires_grad_(True)
-            vg = [v.detach().requires_grad_(True) for v in vs]
-            a = torch.amax(xg, dim=(2, 3))[:, :C * Dc].view(B, C, Dc)
-            pad = x.new_zeros(B, D - C * Dc)
-            if not vs:
-                sel = torch.gather(a, 1, table[draws.to(x.device).long()][:, :, None].expand(B, C, Dc))
-                feat = torch.cat([sel.reshape(B, C * Dc), pad], 1)
-                return {"feat": feat.detach(), "graph": (xg, vg, feat, None)}
-            if vs[0].shape[1] != Dc:
-                raise lib.AvsepError(f"visual channels {vs[0].shape[1]} != bottleneck // {C} = {Dc}")
-            v = torch.stack(vg, 1)                                                    # [B,C,Dc,H,W]
-            perms = a[:, table][..., None, None]                                      # [B,P,C,Dc,1,1]
-            if self.att_type == "cos":
-                maps = F.cosine_similarity(perms, v[:, None], dim=3)
-            else:
-                maps = torch.sigmoid(torch.sum(perms * v[:, None] / math.sqrt(Dc), dim=3))
-            scores = torch.amax(maps, dim=(3, 4)).sum(-1)                             # [B,P]
-            best = scores.argmax(1)
-            sb = scores.gather(1, best[:, None])[:, 0]
-            match_part = -sb + (scores.sum(1) - sb)                                   # [B]
-            att = maps[torch.arange(B, device=x.device), best]                        # [B,C,H,W]
-            f = torch.amax(v * att[:, :, None], dim=(3, 4))
-            feat = torch.cat([f.reshape(B, C * Dc), pad], 1)
-        return {"feat": feat.detach(), "match_part": match_part.detach(), "att_maps": att.detach().contiguous(),
-                "graph": (xg, vg, feat, match_part)}
+        if any(v.shape[1] != Dc for v in vs):
+            raise lib.AvsepError(f"visual channels {vs[0].shape[1]} != bottleneck // {C} = {Dc}")
+        H, W = vs[0].shape[-2:]
+        out.update(a_pool=torch.empty((B, D), dtype=torch.float32, device=dev),
+                   sel_idx=torch.empty((B, D), dtype=torch.int32, device=dev),
+                   att_maps=torch.empty((B, C, H, W), dtype=torch.float32, device=dev),
+                   match_part=torch.empty((B,), dtype=torch.float32, device=dev),
+                   best=torch.empty((B,), dtype=torch.int32, device=dev), HW=H * W)
+        call("avsep_fusion_n_av_fwd", ptr(x), self._ptr_array(vs), B, C, D, Fq * T, H * W, _ATT[self.att_type],
+             ptr(out["a_pool"]), ptr(out["pool_idx"]), ptr(out["feat"]), ptr(out["sel_idx"]), ptr(out["att_maps"]),
+             ptr(out["match_part"]), ptr(out["best"]))
+        return out
 
-    def _run_backward_n(self, fus, dfeat, dx_accum, dmatch):
-        xg, vg, feat, match_part = fus["graph"]
-        outs, gouts = [feat], [dfeat]
-        if match_part is not None and dmatch is not None:
-            outs.append(match_part)
-            gouts.append(dmatch.reshape(1).float().expand(match_part.shape[0]) / match_part.shape[0])
-        grads = torch.autograd.grad(outs, [xg] + vg, gouts, allow_unused=True)
-        dx_accum.add_(grads[0])
-        return [g if g is not None else torch.zeros_like(v) for g, v in zip(grads[1:], vg)]
+    def _run_backward_n(self, x, vs, fus, dfeat, dx_accum, dmatch):
+        B, D, Fq, T = x.shape
+        C = fus["n"]
+        if not vs:
+            call("avsep_fusion_n_ao_bwd", ptr(fus["draws"]), B, C, D, Fq * T, ptr(fus["pool_idx"]), ptr(dfeat), ptr(dx_accum))
+            return []
+        dvs = [torch.empty_like(v) for v in vs]
+        dm = dmatch.reshape(1).contiguous().float() if dmatch is not None else None
+        call("avsep_fusion_n_av_bwd", ptr(x), self._ptr_array(vs), B, C, D, Fq * T, fus["HW"], _ATT[self.att_type],
+             ptr(fus["a_pool"]), ptr(fus["pool_idx"]), ptr(fus["sel_idx"]), ptr(fus["best"]), ptr(dfeat), ptr(dm),
+             1.0 / B if dm is not None else 0.0, ptr(dx_accum), self._ptr_array(dvs))
+        return dvs
 
     # ------------------------------------------------------------------ kernels
     def run_forward(self, x, vs, draws):
@@ -121,8 +118,8 @@ class _FusionBase(nn.Module):
 
     def run_backward(self, x, vs, fus, dfeat, dx_accum, _unused, dmatch):
         """Adds the gradient wrt x into dx_accum; returns the visual-map gradients."""
-        if "graph" in fus:
-            return self._run_backward_n(fus, dfeat, dx_accum, dmatch)
+        if "n" in fus:
+            return self._run_backward_n(x, vs, fus, dfeat, dx_accum, dmatch)
         B, D, Fq, T = x.shape
         Dc, FT = D // 2, Fq * T
         if not vs:

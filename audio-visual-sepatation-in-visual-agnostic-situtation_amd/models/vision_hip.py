@@ -20,7 +20,7 @@ import torch
 from .. import kernels as K
 from .. import lib
 from ..lib import ACT_NONE, ACT_RELU
-from .audio_net import _acc, _bn_back, _bn_run
+from .audio_net import ParamGrads, _bn_back, _bn_run
 
 
 def _geom(conv):
@@ -131,34 +131,35 @@ def trunk_forward(net, x, training):
     return S, out
 
 
-def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None):
-    """g <- relu'(bn(y) [+ residual]) * g in place; returns the folded BatchNorm-backward coefficients of bn(y)."""
+def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None, g2=None):
+    """g <- relu'(bn(y) [+ residual]) * (g [+ g2]) in place; returns the folded BatchNorm-backward coefficients of bn(y)."""
     bst = K.zeros_stats(y.shape[1], y)
-    K.affine_act_bwd_(g, y, bnrow[0], bnrow[1], res, None, bnrow[2], bnrow[3], ACT_RELU, bst, res_scale=rs, res_shift=rh)
+    K.affine_act_bwd_(g, y, bnrow[0], bnrow[1], res, None, bnrow[2], bnrow[3], ACT_RELU, bst, res_scale=rs, res_shift=rh,
+                      dz2=g2)
     return _bn_back(grads, bn_mod, bnrow, bst, y.numel() // y.shape[1])
 
 
 def fc_backward(fc, cvf, dout, grads):
-    dw, db = cvf.wgrad(dout, want_bias=fc.bias is not None)
-    _acc(grads, fc.weight, dw)
-    _acc(grads, fc.bias, db)
+    grads.wgrad(cvf, fc.weight, dout, fc.bias)
     return cvf.dgrad(cvf.pack(_w(fc), 1), dout)
 
 
-def block_backward(R, g, grads):
-    """g = dL/dz' (consumed in place) -> dL/dz; parameter gradients are accumulated into `grads`."""
+def block_backward(R, g, grads, g2=None):
+    """dL/dz' = g (+ g2), consumed in place -> dL/dz as ONE tensor (downsample blocks) or as the pair (conv branch,
+    identity branch): the pair is summed by the consumer's first elementwise pass instead of by a launch of its own.
+    Parameter gradients are accumulated into `grads`."""
     blk = R["mod"]
     ds = blk.downsample is not None
     bnd = R.get("bnd")
     pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
-                         rs=bnd[0] if ds else None, rh=bnd[1] if ds else None)   # g = dL/d(pre-ReLU sum)
+                         rs=bnd[0] if ds else None, rh=bnd[1] if ds else None, g2=g2)   # g = dL/d(pre-ReLU sum)
     dy2 = K.bn_bwd_apply_(g, R["y2"], pqr2, out=torch.empty_like(g))
-    _acc(grads, blk.conv2.weight, R["cv2"].wgrad(dy2)[0])
+    grads.wgrad(R["cv2"], blk.conv2.weight, dy2)
     da = R["cv2"].dgrad(R["cv2"].pack(_w(blk.conv2), 1), dy2)
     del dy2
     pqr1 = _relu_bn_back(grads, da, R["y1"], R["bn1"], blk.bn1)
     K.bn_bwd_apply_(da, R["y1"], pqr1)                              # da = dL/dy1
-    _acc(grads, blk.conv1.weight, R["cv1"].wgrad(da)[0])
+    grads.wgrad(R["cv1"], blk.conv1.weight, da)
     dz = R["cv1"].dgrad(R["cv1"].pack(_w(blk.conv1), 1), da)
     del da
     if ds:
@@ -166,28 +167,29 @@ def block_backward(R, g, grads):
         K.affine_act_bwd_(g, R["yd"], None, None, None, None, bnd[2], bnd[3], ACT_NONE, bst)
         pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, g.numel() // g.shape[1])
         K.bn_bwd_apply_(g, R["yd"], pqrd)                           # g = dL/dyd
-        _acc(grads, blk.downsample[0].weight, R["cvd"].wgrad(g)[0])
-        dz.add_(R["cvd"].dgrad(R["cvd"].pack(_w(blk.downsample[0]), 1), g))
-    else:
-        dz.add_(g)
-    return dz
+        grads.wgrad(R["cvd"], blk.downsample[0].weight, g)
+        return dz, R["cvd"].dgrad(R["cvd"].pack(_w(blk.downsample[0]), 1), g)
+    return dz, g
 
 
-def stem_backward(f, S, g, grads):
+def stem_backward(f, S, g, grads, g2=None):
     y0, bn0 = S["y0"], S["bn0"]
     g = g.contiguous()
+    if g2 is not None:
+        g.add_(g2)
     bst = K.zeros_stats(y0.shape[1], y0)
     K.maxpool_bn_relu_bwd_stats(g, S["idx"], y0, bn0, bst)          # sums over the pooled grid: dz is never written
     pqr0 = _bn_back(grads, f[1], bn0, bst, y0.numel() // y0.shape[1])
     dy0 = K.maxpool_bn_relu_bwd_apply(g, S["idx"], y0, bn0, pqr0)   # pool backward + ReLU mask + BatchNorm backward
-    _acc(grads, f[0].weight, S["cv0"].wgrad(dy0)[0])                # the frames need no gradient
+    grads.wgrad(S["cv0"], f[0].weight, dy0)                         # the frames need no gradient
 
 
 def trunk_backward(net, S, dout, grads):
     g = fc_backward(net.fc, S["cvf"], dout, grads)                  # dL/dz of the last block
+    g2 = None
     for R in reversed(S["blocks"]):
-        g = block_backward(R, g, grads)
-    stem_backward(net.features, S, g, grads)
+        g, g2 = block_backward(R, g, grads, g2)
+    stem_backward(net.features, S, g, grads, g2)
 
 
 class _ResnetFn(torch.autograd.Function):
@@ -201,10 +203,10 @@ class _ResnetFn(torch.autograd.Function):
     def backward(ctx, dout):
         if not ctx.training:
             raise lib.AvsepError("backward through the visual trunk needs train mode (batch statistics)")
-        grads = {}
+        grads = ParamGrads(ctx.net)
         trunk_backward(ctx.net, ctx.S, dout.contiguous(), grads)
         ctx.S = None
-        return (None, None, *[grads.get(p) for p in param_list(ctx.net)])
+        return (None, None, *grads.finish(param_list(ctx.net), "frame"))
 
 
 def run(net, x):

@@ -13,7 +13,12 @@ import torch
 from .. import kernels as K
 from .. import lib
 from ..lib import ACT_NONE, ACT_RELU
-from .audio_net import BN_EPS, BN_MOMENTUM, _acc, _bn_run
+from .audio_net import BN_EPS, BN_MOMENTUM, _bn_run
+
+
+def _acc(grads, p, g):      # comparison-only backend: plain dict of gradients handed back to autograd
+    if g is not None:
+        grads[p] = grads[p] + g if p in grads else g
 from .vision_hip import blocks_of, param_list
 
 aten = torch.ops.aten

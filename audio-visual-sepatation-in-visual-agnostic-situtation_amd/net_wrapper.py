@@ -86,7 +86,7 @@ class NetWrapper(torch.nn.Module):
         errs, match_loss = [], 0
         # pass 1: visual features in reversed order against reversed targets; pass 2: natural order.
         # Both passes read the same spectrogram: the U-Net shares its encoder between them (forward_pair).
-        if hasattr(self.net_sound, "forward_pair") and getattr(self, "share_encoder", True) and N == 2:
+        if hasattr(self.net_sound, "forward_pair") and getattr(self, "share_encoder", True) and 2 <= N <= 4:
             passes = self.net_sound.forward_pair(log_mag_mix, feat_frames[::-1], feat_frames)
             self.unet_nodes = 1 if getattr(self.net_sound, "extra_size", None) is None else 2
         else:
@@ -170,6 +170,8 @@ class FlatSGD:
     RCCL call over xGMI (replacing DataParallel's broadcast + reduce, main.py:661) and the
     update is one fused HIP launch per group."""
 
+    ALIGN = 64      # elements: 256 bytes
+
     def __init__(self, groups, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1, overlap=None,
                  require_gpu=True):
         """`require_gpu=False` only skips the device check so that the bucket / all-reduce logic (`reduce_gradients`) can be
@@ -180,7 +182,10 @@ class FlatSGD:
         # autograd node has run, i.e. BEFORE the visual trunk's backward (~30 ms) starts: their all-reduce is issued
         # right there (asynchronously, RCCL's own stream) and overlaps that backward; step() reduces the rest.
         self.overlap = (os.environ.get("AVSEP_DP_OVERLAP", "1") != "0") if overlap is None else overlap
-        self._early, self._early_left, self.early_reductions = None, 0, 0
+        self._early, self.early_reductions = None, 0
+        self._pending, self._nodes_left, self._armed = set(), 0, False
+        self._slot, self._written, self._returned = {}, set(), set()       # direct gradient placement (grad_dest)
+        self._scratch = None
         self.param_groups = []
         params = []
         for g in groups:
@@ -190,11 +195,15 @@ class FlatSGD:
             params += ps
         if not params:
             raise ValueError("no parameters")
+        self._reports = False          # True once attach() hands this optimizer to networks whose nodes call node_finished
         dev = params[0].device
         if require_gpu:
             lib.require_gpu(params[0])
-        total = sum(p.numel() for p in params)
-        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        # every tensor starts on a 256-byte boundary of the flat buffers (the wide loads / stores of the kernels that
+        # write gradients in place, the SGD kernel and RCCL all see aligned rows); the padding holds zeros throughout
+        A = self.ALIGN
+        total = sum((p.numel() + A - 1) // A * A for p in params)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_buf = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
@@ -217,22 +226,75 @@ class FlatSGD:
                     gv = self.flat_grad[off:off + n].view_as(p.data)
                 p.grad = gv
                 self._views.append((p, gv))
-                off += n
+                if gv.is_contiguous():
+                    self._slot[p] = gv
+                off += (n + A - 1) // A * A
             g["range"][1] = off
         if self.world_size > 1 and self.overlap:
-            first = self.param_groups[0]
-            self._early_total = len(first["params"])
-            for p in first["params"]:
+            for p in self.param_groups[0]["params"]:
                 p.register_post_accumulate_grad_hook(self._on_first_group_grad)
+
+    # ---- direct gradient placement: the backward kernels write into the flat buffer ------------------------------------
+    def grad_dest(self, p):
+        """The zeroed flat .grad view of `p` if a kernel may WRITE this step's first contribution into it, else None
+        (a second contribution, a detached .grad, a channels-last view): the caller then returns the gradient to
+        autograd, whose AccumulateGrad adds it into the view."""
+        gv = self._slot.get(p)
+        if gv is None or p in self._written or p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+            return None
+        self._written.add(p)
+        return gv
+
+    def scratch_dest(self, p):
+        """For a parameter another node of this step has already placed: a view, at the same offset, of a second flat
+        buffer that the node's kernels may write; fold_scratch() then adds all of them into the gradient buffer with ONE
+        launch per contiguous run (the visual trunk runs once per source: its second node used to cost one
+        AccumulateGrad add per parameter)."""
+        gv = self._slot.get(p)
+        if gv is None or p not in self._written or p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+            return None
+        if self._scratch is None:
+            self._scratch = torch.zeros_like(self.flat_grad)
+        off = gv.storage_offset()
+        return self._scratch[off:off + gv.numel()].view_as(gv)
+
+    def fold_scratch(self, params):
+        """flat_grad += scratch over the flat ranges of `params` (merged into contiguous runs; padding holds zeros)."""
+        A = self.ALIGN
+        spans = sorted((self._slot[p].storage_offset(), (self._slot[p].numel() + A - 1) // A * A) for p in params)
+        runs = []
+        for off, n in spans:
+            if runs and runs[-1][1] == off:
+                runs[-1][1] = off + n
+            else:
+                runs.append([off, off + n])
+        for a, b in runs:
+            self.flat_grad[a:b].add_(self._scratch[a:b])
+
+    def node_finished(self, group, returned):
+        """An autograd node of network `group` has run its backward; `returned` = the parameters whose gradient it handed
+        back to autograd (their AccumulateGrad — and post-accumulate hook — is still to come), the others are in place."""
+        self._returned.update(returned)
+        if group != self.param_groups[0]["name"] or not self._armed:
+            return
+        self._nodes_left -= 1
+        if self._nodes_left == 0:
+            self._pending -= (self._written - self._returned)       # placed by a kernel and complete: no hook will fire
+            self._maybe_start_early_reduce()
 
     def _on_first_group_grad(self, p):
         """Fires once per parameter of the first group after autograd accumulated into its flat view."""
-        self._early_left -= 1
-        if self._early_left == 0 and self._early is None and self._flat_views_intact():
+        if self._armed:
+            self._pending.discard(p)
+            self._maybe_start_early_reduce()
+
+    def _maybe_start_early_reduce(self):
+        if self._armed and not self._pending and self._nodes_left <= 0 and self._early is None and self._flat_views_intact():
             import torch.distributed as dist
             a, b = self.param_groups[0]["range"]
             self._early = dist.all_reduce(self.flat_grad[a:b], group=self.process_group, async_op=True)
             self.early_reductions += 1
+            self._armed = False
 
     def _flat_views_intact(self):
         g = self.param_groups[0]
@@ -243,15 +305,21 @@ class FlatSGD:
         self.flat_grad.zero_()
         for p, gv in self._views:
             p.grad = gv
-        self._early, self._early_left = None, 0             # disarmed until arm_early_reduce()
+        self._written.clear()
+        self._returned.clear()
+        self._early, self._armed, self._nodes_left = None, False, 0     # disarmed until arm_early_reduce()
+        self._pending = set()
 
     def arm_early_reduce(self, accumulations=1):
-        """Call between forward and backward.  Autograd runs each leaf's AccumulateGrad ONCE per backward, however
-        many graph nodes use the parameter, so the post-accumulate hook fires exactly once per parameter of the first
-        group; the all-reduce of that group starts the moment the last one lands.  (`accumulations` only says whether
-        the U-Net took part in this step's graph at all.)"""
+        """Call between forward and backward; `accumulations` = autograd nodes of the first group's network in this step's
+        graph.  A first-group parameter is complete when every such node has run AND every gradient a node handed back to
+        autograd has been accumulated (AccumulateGrad runs once per leaf and backward, then the post-accumulate hook);
+        parameters whose gradient the kernels placed directly (grad_dest) and no node returned need no hook.  Nodes that
+        do not report (plain torch modules): the hooks alone count, as before."""
         if self.world_size > 1 and self.overlap and accumulations > 0:
-            self._early_left = getattr(self, "_early_total", 0)
+            self._armed = True
+            self._pending = set(self.param_groups[0]["params"])
+            self._nodes_left = accumulations if self._reports else 0
 
     def _collect(self):
         # a caller that ran module.zero_grad(set_to_none=True) (torch default, main.py:560) left
@@ -278,7 +346,7 @@ class FlatSGD:
                     seg = flat[off:off + n]
                     out[off:off + n] = (seg.view(O, KH, KW, I).permute(0, 3, 1, 2) if to_logical
                                         else seg.view(O, I, KH, KW).permute(0, 2, 3, 1)).reshape(-1)
-                off += n
+                off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         return out
 
     def state_dict(self):
@@ -336,6 +404,14 @@ class FlatSGD:
             g["started"] = True
 
 
+def attach_grad_sink(opt, *nets):
+    """Let the autograd nodes of `nets` write parameter gradients straight into `opt`'s flat gradient buffer."""
+    for n in nets:
+        object.__setattr__(n, "_grad_sink", opt)
+    opt._reports = True
+    return opt
+
+
 def create_optimizer(nets, args, process_group=None, world_size=1):
     (net_sound, net_frame) = nets
     nhwc = getattr(net_frame, "backend", None) in ("torch", "hybrid")   # the MIOpen paths want OHWI conv weights
@@ -344,8 +420,8 @@ def create_optimizer(nets, args, process_group=None, world_size=1):
     if not args.fix_vis:
         groups.append({"params": list(net_frame.features.parameters()), "lr": args.lr_frame,
                        "name": "frame_features", "channels_last": nhwc})
-    return FlatSGD(groups, momentum=args.beta1, weight_decay=args.weight_decay,
-                   process_group=process_group, world_size=world_size)
+    return attach_grad_sink(FlatSGD(groups, momentum=args.beta1, weight_decay=args.weight_decay,
+                                    process_group=process_group, world_size=world_size), net_sound, net_frame)
 
 
 def adjust_learning_rate(optimizer, args):

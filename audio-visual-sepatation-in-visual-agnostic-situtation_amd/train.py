@@ -89,11 +89,12 @@ def main(args):
     random.seed(args.seed + rank)
     torch.manual_seed(args.seed)                                   # identical replicas
     builder = ModelBuilder()
-    net_sound = builder.build_sound(arch=args.arch_sound, fc_dim=args.num_channels, weights=args.weights_sound,
-                                    fusion_type=args.fusion_type, att_type=args.att_type)
     net_frame = builder.build_frame(arch=args.arch_frame, fc_dim=args.vis_channels, pool_type=args.img_pool,
                                     weights=args.weights_frame)
     three_stage = getattr(args, "train_steps", None) is not None
+    if not three_stage:
+        net_sound = builder.build_sound(arch=args.arch_sound, fc_dim=args.num_channels, weights=args.weights_sound,
+                                        fusion_type=args.fusion_type, att_type=args.att_type)
     if three_stage:
         # SoP++/main.py:722-747: basis U-Net (extra_size = num_channels), synthesizer, attention module; the AV steps
         # walk through the three stages of SoP++/main.py:670-688 by iteration number

@@ -40,15 +40,23 @@ PEAK_HBM_GBS = 8000.0                           # HBM3E spec
 BATCH_PER_GPU = 64
 
 
-def step_args(P):
+CONFIG5_BATCH = 32       # BASELINE.json configs[4] / SURVEY 8: per-device batch 32
+
+
+def step_args(P, config=3):
     a = P.arguments.train_music_args()          # scripts/train_MUSIC.sh, the config of record
     a.stft_pad_mode = "reflect"
+    if config == 5:
+        # BASELINE.json configs[4]: 3-source mix, 512x256 STFT tiles (no log-frequency warp), 5 frames per source; the
+        # N-source rules are build-defined: one logit per source, vis_channels = 512 // 3
+        a.log_freq, a.num_mix, a.num_frames, a.num_channels = 0, 3, 5, 3
+        a.vis_channels = 512 // 3
     return a
 
 
-def build(P, dev, seed, backend):
+def build(P, dev, seed, backend, config=3):
     torch.manual_seed(seed)
-    a = step_args(P)
+    a = step_args(P, config)
     mb = P.ModelBuilder()
     snd = mb.build_sound(arch=a.arch_sound, fc_dim=a.num_channels, weights="", fusion_type=a.fusion_type,
                          att_type=a.att_type)
@@ -267,11 +275,11 @@ def rehearse(o):
         dist.destroy_process_group()
 
 
-def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer=None, use_vis=True):
+def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer=None, use_vis=True, config=3):
     """Build the model from `seed`, run `warmup` untimed + `steps` timed train steps; returns the measurements."""
     import torch.distributed as dist
     P.kernels.set_precision(prec)
-    a, snd, frm, wrap = build(P, dev, seed, backend)
+    a, snd, frm, wrap = build(P, dev, seed, backend, config)
     opt = P.create_optimizer((snd, frm), a, world_size=world)
     raw = P.synth.make_batch(B, a.num_mix, a.num_frames, 224, a.audLen, seed=seed + 1 + rank, device=dev)
 
@@ -312,6 +320,28 @@ def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer
     torch.cuda.empty_cache()
     P.kernels.set_precision("f32")
     return res
+
+
+def config5_line(P, dev, world, seed, rank, o, timer):
+    """BASELINE.json configs[4] on one GPU: 3-source mix, 5 frames per source, 512x256 tiles, batch 32 — the workload
+    that stresses the fusion / mask head (C! = 6 permutations in the N-source fusion kernel, 15 frames per mixture
+    through the visual trunk, 3 logits).  Same measurement protocol as the headline; roofline on the executed FLOPs."""
+    B5 = min(o.batch, CONFIG5_BATCH)
+    steps = max(3, o.steps // 2)
+    r = run_config(P, dev, world, seed, rank, o.precision, "hip", B5, steps, 2, config=5)
+    r_inst = run_config(P, dev, world, seed, rank, o.precision, "hip", B5, steps, 1, timer, config=5)
+    k5 = timer.summary(steps)
+    roof5, step5, _ = roofline_of(k5, o.precision, r["ms_per_step"], B5)
+    r.update({"dtype": o.precision, "batch": B5, "roofline": roof5, "roofline_step": step5,
+              "instrumented_ms_per_step": r_inst["ms_per_step"],
+              "gflop_per_mixture_executed": step5["executed_gflop_per_step"] / B5,
+              "gflop_per_mixture_direct_form": step5["algorithmic_gflop_per_step"] / B5,
+              "workload": "BASELINE configs[4] per GPU: 3-source mix, batch %d, 512x256 tiles (log_freq 0), 5x224^2 frames/source, "
+                          "unet7 + hidsep(sig) N-source fusion kernel (3! permutations) + resnet18dilated (vis_channels 170), "
+                          "BCE, SGD; SURVEY 8(d) prices it at 558 GFLOP/mixture as written in the reference (two full U-Net "
+                          "passes); the shared encoder executes less" % B5,
+              "by_kernel": {k: {"ms_per_step": round(v["ms_per_step"], 3), "tflops": round(v["tflops"], 1)} for k, v in k5.items()}})
+    return r
 
 
 def add_traffic(roof, prec, B):
@@ -367,6 +397,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--layers", default=None, help="write a per-convolution-call table of the headline step to this file")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 5], help="3: BASELINE configs[2] shape (headline); 5: configs[4] "
+                    "(3 sources, 5 frames, 512x256, batch 32) as the headline workload of this run")
     ap.add_argument("--rehearse", action="store_true", help="launcher / rendezvous / all-reduce rehearsal without a train step "
                     "(runs on CPU ranks over gloo too); prints a line marked \"rehearsal\": true")
     ap.add_argument("--rehearse-elems", type=int, default=0, help="elements of the rehearsal's flat buffer (default: the step's)")
@@ -386,10 +418,12 @@ def main():
     import torch.distributed as dist
 
     seed, B = 1234, o.batch
+    if o.config == 5:
+        B = min(B, CONFIG5_BATCH)
     # headline: un-instrumented.  Then the same configuration once more with HIP-event pairs around every conv launch
-    head = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup)
+    head = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup, config=o.config)
     timer = KernelTimer(P.kernels)
-    inst = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, min(o.warmup, 1), timer)
+    inst = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, min(o.warmup, 1), timer, config=o.config)
     kernels = timer.summary(o.steps)
     if o.layers and rank == 0:
         rows = sorted(timer.layers.items(), key=lambda kv: -kv[1][0])
@@ -401,8 +435,8 @@ def main():
     extras = {}
     if world == 1 and not o.no_extra:
         other = "bf16" if o.precision == "f32" else "f32"
-        r = run_config(P, dev, world, seed, rank, other, "hip", B, o.steps, o.warmup)
-        r_inst = run_config(P, dev, world, seed, rank, other, "hip", B, o.steps, 1, timer)
+        r = run_config(P, dev, world, seed, rank, other, "hip", B, o.steps, o.warmup, config=o.config)
+        r_inst = run_config(P, dev, world, seed, rank, other, "hip", B, o.steps, 1, timer, config=o.config)
         k2 = timer.summary(o.steps)
         roof2, step2, _ = roofline_of(k2, other, r["ms_per_step"], B)
         add_traffic(roof2, other, B)
@@ -412,12 +446,14 @@ def main():
                               "loss / master weights / SGD (BASELINE configs[2])" if other == "bf16" else "same step in fp32",
                   "by_kernel": {k: {"ms_per_step": round(v["ms_per_step"], 3), "tflops": round(v["tflops"], 1)} for k, v in k2.items()}})
         extras[other] = r
-        hyb = run_config(P, dev, world, seed, rank, "f32", "hybrid", B, max(3, o.steps // 2), 2)
+        hyb = run_config(P, dev, world, seed, rank, "f32", "hybrid", B, max(3, o.steps // 2), 2, config=o.config)
         extras["f32_miopen_hybrid"] = dict(hyb, workload="round-1 configs[1] path at the headline batch %d: visual convolutions on "
                                            "PyTorch-ROCm/MIOpen, HIP BatchNorm glue; comparison only, not this build's kernels" % B)
-        ao = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, max(3, o.steps // 2), 2, use_vis=False)
+        ao = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, max(3, o.steps // 2), 2, use_vis=False, config=o.config)
         extras["ao_step_mixtures_per_s"] = ao["value"]
         extras["av_ao_1to1_blend_mixtures_per_s"] = 2.0 / (1.0 / head["value"] + 1.0 / ao["value"])
+        if o.config != 5:
+            extras["config5"] = config5_line(P, dev, world, seed, rank, o, timer)
 
     if rank == 0:
         roof, roof_step, hbm = roofline_of(kernels, o.precision, head["ms_per_step"], B)
@@ -433,9 +469,12 @@ def main():
             "allreduce_bytes_per_step": head["allreduce_bytes_per_step"],      # ONE flat fp32 gradient all-reduce per step and rank
             "instrumented_ms_per_step": inst["ms_per_step"],   # the pass `roofline` / `by_kernel` come from (event pairs around every conv)
             "dtype": o.precision, "data": "synthetic",
-            "config": {"workload": "full HIP path, AV train step: 2-source mix, batch %d/GPU (BASELINE configs[2] shape), 65535-sample "
-                       "waveforms -> HIP STFT 1022/256 -> 256x256 log-freq tiles, 3x224^2 frames/source, unet7+hidsep(sig)+"
-                       "resnet18dilated, BCE, SGD; %s arithmetic; %s" % (B, o.precision, vis),
+            "config": {"workload": ("full HIP path, AV train step: 2-source mix, batch %d/GPU (BASELINE configs[2] shape), 65535-sample "
+                                    "waveforms -> HIP STFT 1022/256 -> 256x256 log-freq tiles, 3x224^2 frames/source, unet7+hidsep(sig)+"
+                                    "resnet18dilated, BCE, SGD; %s arithmetic; %s" if o.config != 5 else
+                                    "full HIP path, AV train step: 3-source mix, batch %d/GPU (BASELINE configs[4]), 512x256 tiles, "
+                                    "5x224^2 frames/source, unet7+hidsep(sig) N-source fusion+resnet18dilated; %s arithmetic; %s")
+                       % (B, o.precision, vis),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "loss": head["loss"], "match_loss": head["match_loss"], "first_step_loss": head["first_step_loss"],
             # dominant kernel = the MFMA kernel family with the largest time per step; achieved = its algorithmic FLOPs /

@@ -208,9 +208,10 @@ int avsep_bn_bwd_apply(const float* dz, const float* y, const float* pqr, int32_
 int avsep_affine_act(const float* y, const float* scale, const float* shift, const float* residual,
                      const float* res_scale, const float* res_shift, int32_t act, int32_t N, int32_t C,
                      int32_t HW, float* z, avsep_stream_t stream);
-/* Gradient through that z:  dz_pre = act'(pre)*dz (+ add);  also accumulates
- * bstats (sum dz_pre, sum dz_pre*xhat(y)) when bstats != NULL.                            */
-int avsep_affine_act_bwd(const float* dz, const float* y, const float* scale, const float* shift,
+/* Gradient through that z:  dz_pre = act'(pre)*(dz [+ dz2]) (+ add);  also accumulates
+ * bstats (sum dz_pre, sum dz_pre*xhat(y)) when bstats != NULL.  dz2 (may be NULL): a second gradient
+ * branch reaching z (a BasicBlock output feeds the next block's conv1 AND its residual add), summed on the fly. */
+int avsep_affine_act_bwd(const float* dz, const float* dz2, const float* y, const float* scale, const float* shift,
                          const float* residual, const float* res_scale, const float* res_shift,
                          const float* add, const float* mean, const float* invstd, int32_t act,
                          int32_t N, int32_t C, int32_t HW, float* dz_pre, double* bstats,
@@ -277,6 +278,22 @@ int avsep_fusion_av_bwd(const float* x, const float* v0, const float* v1, int32_
                         const float* dmatch, float dmatch_scale, float* dx_accum, float* dv0,
                         float* dv1, avsep_stream_t stream);
 /* AO branch (fusion_net.py:93-104): feat = swapped global-max-pooled blocks. draws: uint8[B]. */
+/* CoLoc (kind 0) for C = 2..4 sources — BUILD-DEFINED generalisation of fusion_net.py:35-72,93-104 (the reference
+ * hard-codes C = 2; rules in csrc/fusion_n.hip and DESIGN.md §9): x [B,D,F,T], v[c] [B,Dc,H,W] with Dc = D / C, the
+ * audio blocks are the first C*Dc pooled channels, all C! permutations in itertools order, first maximum wins;
+ * feat [B,D] (remainder channels zero), att_maps [B,C,H,W], match_part [B], best [B] (permutation index).
+ * v / dv: HOST arrays of C device pointers.  Audio-only: draws[b] = permutation index (itertools order) of sample b. */
+int avsep_fusion_n_av_fwd(const float* x, const float* const* v, int32_t B, int32_t C, int32_t D, int32_t FT,
+                          int32_t HW, int32_t att, float* a_pool, int32_t* pool_idx, float* feat, int32_t* sel_idx,
+                          float* att_maps, float* match_part, int32_t* best, avsep_stream_t stream);
+int avsep_fusion_n_av_bwd(const float* x, const float* const* v, int32_t B, int32_t C, int32_t D, int32_t FT,
+                          int32_t HW, int32_t att, const float* a_pool, const int32_t* pool_idx,
+                          const int32_t* sel_idx, const int32_t* best, const float* dfeat, const float* dmatch,
+                          float dmatch_scale, float* dx_accum, float* const* dv, avsep_stream_t stream);
+int avsep_fusion_n_ao_fwd(const float* x, const int32_t* draws, int32_t B, int32_t C, int32_t D, int32_t FT,
+                          float* feat, int32_t* pool_idx, avsep_stream_t stream);
+int avsep_fusion_n_ao_bwd(const int32_t* draws, int32_t B, int32_t C, int32_t D, int32_t FT,
+                          const int32_t* pool_idx, const float* dfeat, float* dx_accum, avsep_stream_t stream);
 int avsep_fusion_ao_fwd(const float* x, const uint8_t* draws, int32_t all_zero, int32_t B,
                         int32_t Dc, int32_t FT, float* feat, int32_t* pool_idx,
                         avsep_stream_t stream);

@@ -97,7 +97,9 @@ def _flat_worker(rank, world, port, out, overlap):
         opt.arm_early_reduce(1)
         loss.backward()
         active, scale = opt.reduce_gradients(None if use_vis else ("sound",))
-        res.append({"grad": (opt.flat_grad * scale).clone(), "ranges": [list(g_["range"]) for g_ in active]})
+        # per-parameter views of the flat buffer (every tensor starts on a 256-byte boundary: FlatSGD.ALIGN)
+        res.append({"grad": torch.cat([(gv * scale).reshape(-1) for _, gv in opt._views]),
+                    "ranges": [list(g_["range"]) for g_ in active]})
     torch.save({"res": res, "early": opt.early_reductions}, out + f".{rank}")
     dist.barrier()
     dist.destroy_process_group()
@@ -118,7 +120,9 @@ def test_flat_sgd_buckets_over_two_gloo_ranks(tmp_path):
         params = [p for n in nets for p in n.parameters()]
         g = torch.Generator().manual_seed(1)
         X, V, Y = torch.randn(8, 1, 6, 6, generator=g), torch.randn(8, 3, 6, 6, generator=g), torch.randn(8, 2, 6, 6, generator=g)
-        n_sound = sum(p.numel() for p in nets[0].parameters())
+        import avsep_amd as P
+        A = P.net_wrapper.FlatSGD.ALIGN
+        n_sound = sum((p.numel() + A - 1) // A * A for p in nets[0].parameters())
         for step, use_vis in enumerate((True, False, True)):
             for p in params:
                 p.grad = None

@@ -24,6 +24,17 @@ POOL_MARGIN = 1e-5      # fp32 error of the 147-term stem conv is ~1e-6 of its o
 TOL = 1e-4
 
 
+
+def _grads(VH, mod):
+    """ParamGrads without a gradient sink: a plain {parameter: gradient} mapping (`.d`), read through __getitem__."""
+    class G(VH.ParamGrads):
+        def __contains__(self, p):
+            return p in self.d
+
+        def __getitem__(self, p):
+            return self.d[p]
+    return G(mod)
+
 def _pkg():
     import avsep_amd
     return avsep_amd
@@ -111,8 +122,9 @@ def test_basic_block_layer_parity(dev, arch, dilate, li, bi, B, H):
     (out64 * cot.double()).sum().backward()
 
     R, out = VH.block_forward(blk, z.to(dev), True)
-    grads = {}
-    dz = VH.block_backward(R, cot.to(dev).clone(), grads)
+    grads = _grads(VH, blk)
+    dz, dz2 = VH.block_backward(R, cot.to(dev).clone(), grads)
+    dz = dz + dz2          # (conv branch, identity / downsample branch): the consumer's first pass sums them
     tag = f"{arch}{dilate} features[{li}][{bi}]"
     assert_close(out, out64, TOL, tag + ": output")
     assert_close(dz, zin.grad, TOL, tag + ": dz")
@@ -163,7 +175,7 @@ def test_stem_layer_parity(dev, B, H, seed0):
     cot = torch.randn(out64.shape, generator=gen)
     (out64 * cot.double()).sum().backward()
     S, z = VH.stem_forward(f, x.to(dev), True)
-    grads = {}
+    grads = _grads(VH, f)
     VH.stem_backward(f, S, cot.to(dev).clone(), grads)
     assert_close(z, out64, TOL, "stem output")
     assert_close(grads[f[0].weight], o64[0].weight.grad, TOL, "stem dw")
@@ -188,7 +200,7 @@ def test_fc_conv_layer_parity(dev, B, H, fc_dim):
     (out64 * cot.double()).sum().backward()
     fc = fc.to(dev)
     cvf, out = VH.fc_forward(fc, z.to(dev))
-    grads = {}
+    grads = _grads(VH, fc)
     dz = VH.fc_backward(fc, cvf, cot.to(dev), grads)
     assert_close(out, out64, TOL, "fc output")
     assert_close(dz, zin.grad, TOL, "fc dz")
