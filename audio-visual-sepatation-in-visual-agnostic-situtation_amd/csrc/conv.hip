@@ -595,6 +595,10 @@ bool w4b_applicable(const avsep_conv_desc* d);
 size_t w4b_workspace_floats(const avsep_conv_desc* d);
 int w4b_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
+// wgrad_smallci.hip
+bool scw_applicable(const avsep_conv_desc* d);
+size_t scw_workspace_floats(const avsep_conv_desc* d);
+int scw_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 static int check_desc(const avsep_conv_desc* d, bool fwd_only = false) {
   if (!d || !d->x0) return AVSEP_ERR_ARG;
   if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return AVSEP_ERR_ARG;
@@ -863,6 +867,7 @@ extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (ww_applicable(d)) return ww_workspace_floats(d) * sizeof(float);
   if (w4d_applicable(d)) return w4d_workspace_floats(d) * sizeof(float);
   if (w3_applicable(d)) return w3_workspace_floats(d) * sizeof(float);
+  if (scw_applicable(d)) return scw_workspace_floats(d) * sizeof(float);
   WgradPlan p = wgrad_plan(d);
   if (p.splits <= 1) return 0;
   return (size_t)p.splits * d->Cout * d->Cin * d->KH * d->KW * sizeof(float);
@@ -878,12 +883,13 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   if (need > workspace_bytes || (need && !workspace)) return AVSEP_ERR_WORKSPACE;
   if (smallco_applicable(d)) return smallco_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
   if (head_applicable(d)) return head_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
-  if (wb_applicable(d) || w4b_applicable(d) || ww_applicable(d) || w4d_applicable(d) || w3_applicable(d)) {
+  if (wb_applicable(d) || w4b_applicable(d) || ww_applicable(d) || w4d_applicable(d) || w3_applicable(d) || scw_applicable(d)) {
     int rc3 = wb_applicable(d) ? wb_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : w4b_applicable(d) ? w4b_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : ww_applicable(d) ? ww_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : w4d_applicable(d) ? w4d_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
-                                  : w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
+              : w3_applicable(d) ? w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
+                                 : scw_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
     if (rc3) return rc3;
     if (dbias) {
       hipLaunchKernelGGL(channel_sum_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, dy, d->N, d->Cout,
@@ -947,6 +953,7 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
   if (ww_applicable(d)) return "winow_kernel";
   if (w4d_applicable(d)) return "wgrad4d_kernel";
   if (w3_applicable(d)) return "wgrad3x3_kernel";
+  if (scw_applicable(d)) return "smallci_wgrad_kernel";
   return "igemm_kernel<wgrad>";
 }
 

@@ -62,6 +62,10 @@ CONV_CASES = [
     (3, 64, 14, 14, 144, 1, 1, 0, 1),      # 1x1 (layer4.0 downsample)
     (2, 32, 28, 28, 48, 1, 2, 0, 1),       # 1x1 / stride 2: dgrad zero-fills the skipped pixels
     (40, 128, 28, 28, 256, 1, 2, 0, 1),    # 1x1 / stride 2 at the layer3.0 downsample shape, 128-row tiles both ways
+    # wgrad_smallci.hip: weight gradient over <= 4 input channels (ResNet stem 7x7/s2, U-Net first conv 4x4/s2): family asserted
+    (3, 3, 32, 64, 72, 7, 2, 3, 1),        # stem geometry, two 64-channel tiles (second ragged), 5 N tiles of 147 columns
+    (2, 3, 224, 224, 64, 7, 2, 3, 1),      # the stem itself
+    (3, 1, 64, 32, 40, 4, 2, 1, 1),        # Cin = 1: one N tile, half of the waves idle
     # conv_wino.hip: Winograd F(2x2, 3x3) forward + data gradient (needs >= 128 workgroups, conv_wino.hip wn_applicable,
     # hence the batch sizes); the kernel family of these rows is ASSERTED (EXPECT_FAMILY below)
     (64, 48, 32, 32, 80, 3, 1, 1, 1),      # one 8x8-tile group per workgroup (U-Net decoder maps), ragged second M tile
@@ -97,6 +101,8 @@ for _c in _rows_after((64, 64, 32, 32, 80, 3, 1, 1, 1), 4):
     EXPECT_FAMILY[_c] = {"fwd": "wino_kernel", "dgrad": "wino_kernel", "wgrad": "winow_kernel"}
 for _c in _rows_after((64, 64, 32, 32, 80, 4, 2, 1, 1), 3):
     EXPECT_FAMILY[_c] = {"wgrad": "wgrad4d_kernel"}
+for _c in _rows_after((3, 3, 32, 64, 72, 7, 2, 3, 1), 3) + [(2, 1, 32, 48, 24, 4, 2, 1, 1)]:
+    EXPECT_FAMILY[_c] = {"wgrad": "smallci_wgrad_kernel"}
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -620,6 +626,17 @@ def test_resnet_glue_ops(dev):
     p, idx = K.maxpool3x3s2(t(x), t(sc), t(sh), 1)
     assert_close(p, p_ref, 1e-6, "max-pool of relu(affine(x))")
     assert_close(K.maxpool3x3s2_bwd(t(dp), idx, H, W), a.grad, 1e-6, "max-pool backward (wrt the activated input)")
+    # W % 8 == 0, even H: the four-outputs-per-thread kernel (the stem's 112x112 maps).  ReLU zeros tie inside most
+    # windows: the gradient check pins "first maximum in scan order wins" (what F.max_pool2d does)
+    x8 = torch.randn(3, 5, 12, 24, generator=g)
+    sc8, sh8 = torch.rand(5, generator=g) + 0.5, torch.randn(5, generator=g) * 0.5 - 0.8
+    a8 = torch.relu(x8 * v(sc8) + v(sh8)).requires_grad_(True)
+    p8_ref = F.max_pool2d(a8, 3, 2, 1)
+    dp8 = torch.randn(p8_ref.shape, generator=g)
+    p8_ref.backward(dp8)
+    p8, idx8 = K.maxpool3x3s2(t(x8), t(sc8), t(sh8), 1)
+    assert_close(p8, p8_ref, 1e-6, "max-pool (vectorised kernel)")
+    assert_close(K.maxpool3x3s2_bwd(t(dp8), idx8, 12, 24), a8.grad, 1e-6, "max-pool backward after the vectorised forward")
     # block tail
     y, r, dz = (torch.randn(N, C, H, W, generator=g) for _ in range(3))
     rs, rh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5

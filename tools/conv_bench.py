@@ -21,6 +21,13 @@ SHAPES = [
     (192, 256, 14, 14, 256, 3, 1, 1, 1),
     (192, 512, 14, 14, 512, 3, 1, 2, 2),
 ]
+LEFTOVERS = [    # the shapes profiles/r02_layers_f32.txt lists on the im2col kernel
+    (192, 3, 224, 224, 64, 7, 2, 3, 1), (64, 1, 256, 256, 64, 4, 2, 1, 1),
+    (192, 64, 56, 56, 128, 3, 2, 1, 1), (192, 128, 28, 28, 256, 3, 2, 1, 1),
+    (192, 256, 14, 14, 512, 1, 1, 0, 1), (192, 64, 56, 56, 128, 1, 2, 0, 1), (192, 128, 28, 28, 256, 1, 2, 0, 1),
+    (64, 512, 16, 16, 512, 4, 2, 1, 1), (64, 512, 8, 8, 512, 4, 2, 1, 1), (64, 512, 4, 4, 512, 4, 2, 1, 1),
+    (64, 1024, 4, 4, 512, 3, 1, 1, 1),
+]
 
 
 def main():
@@ -28,12 +35,13 @@ def main():
     ap.add_argument("mode", nargs="?", default="fwd", choices=["fwd", "dgrad", "wgrad"])
     ap.add_argument("--prec", default="f32")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--leftovers", action="store_true", help="the layer shapes still on the im2col kernel in round 2")
     ap.add_argument("--affine", action="store_true", help="forward over a folded BatchNorm + ReLU input, with statistics")
     o = ap.parse_args()
     K = P.kernels
     K.set_precision(o.prec)
     dev = torch.device("cuda:0")
-    for (N, Cin, H, W, Cout, k, s, p, d) in SHAPES:
+    for (N, Cin, H, W, Cout, k, s, p, d) in (LEFTOVERS if o.leftovers else SHAPES):
         x = torch.randn(N, Cin, H, W, device=dev)
         w = torch.randn(Cout, Cin, k, k, device=dev) * 0.02
         kw = {}
