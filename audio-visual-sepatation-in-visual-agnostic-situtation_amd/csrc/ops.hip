@@ -1326,6 +1326,84 @@ extern "C" int avsep_innerprod_bwd(const float* img, const float* snd, const flo
   return AVSEP_OK;
 }
 
+// ---- the synthesizer's inference helpers (models/synthesizer_net.py:21-38) ------------------------------------------------
+// forward_nosum: z[b,k,hw] = img[b,k]*scale[k]*snd[b,k,hw] + bias   (one pass, 16-byte accesses when HW % 4 == 0)
+__global__ __launch_bounds__(256) void innerprod_nosum_kernel(const float* __restrict__ img, const float* __restrict__ snd,
+                                                              const float* __restrict__ scale, const float* __restrict__ bias,
+                                                              int K, int HW, float* __restrict__ z) {
+  const int bk = blockIdx.y, k = bk % K;
+  const float w = img[bk] * (scale ? scale[k] : 1.f), bs = bias ? bias[0] : 0.f;
+  const long long base = (long long)bk * HW;
+  if ((HW & 3) == 0) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(snd + base);
+    f32x4* z4 = reinterpret_cast<f32x4*>(z + base);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += gridDim.x * 256) {
+      const f32x4 v = s4[i];
+      z4[i] = f32x4{fmaf(w, v.x, bs), fmaf(w, v.y, bs), fmaf(w, v.z, bs), fmaf(w, v.w, bs)};
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) z[base + i] = fmaf(w, snd[base + i], bs);
+  }
+}
+extern "C" int avsep_innerprod_nosum(const float* img, const float* snd, const float* scale, const float* bias, int32_t B, int32_t K,
+                                     int32_t HW, float* z, avsep_stream_t stream) {
+  if (!img || !snd || !z || B <= 0 || K <= 0 || HW <= 0 || (long long)B * K > 65535) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(innerprod_nosum_kernel, dim3(min(cdiv(HW, 1024), 64), B * K), dim3(256), 0, (hipStream_t)stream, img, snd, scale,
+                     bias, K, HW, z);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// forward_pixelwise: z[b,p,hw] = sum_k imgs[b,k,p]*scale[k]*snd[b,k,hw] + bias — per sample a [P x K] x [K x HW] contraction
+// (the visual-feature x audio-feature mask inner product) on v_mfma_f32_32x32x2_f32.  Workgroup = 128 audio positions of one
+// sample (wave w: 32 of them); the scaled visual vectors [K][P] sit in LDS; a wave walks the 32-row tiles of P, 16 MFMAs
+// (K / 2 k-steps) each, and stores 32 x 32 outputs as 128-byte row segments.  HBM-bound on the [B, P, HW] output.
+__global__ __launch_bounds__(256) void innerprod_pixelwise_kernel(const float* __restrict__ imgs, const float* __restrict__ snd,
+                                                                  const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                  int K, int P, int HW, float* __restrict__ z) {
+  extern __shared__ float s_a[];                   // [K][PS], PS = roundup(P, 32) + 1
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+  const int PT = (P + 31) / 32, PS = PT * 32 + 1;
+  for (int i = tid; i < K * PT * 32; i += 256) {
+    const int k = i / (PT * 32), p = i % (PT * 32);
+    s_a[k * PS + p] = p < P ? imgs[((long long)b * K + k) * P + p] * (scale ? scale[k] : 1.f) : 0.f;
+  }
+  __syncthreads();
+  const int hw = blockIdx.x * 128 + wave * 32 + li;
+  const int hwc = min(hw, HW - 1);
+  const float bs = bias ? bias[0] : 0.f;
+  const float* sp = snd + (long long)b * K * HW + hwc;
+  for (int pt = 0; pt < PT; ++pt) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s = 0; s < K / 2; ++s) {
+      const float av = s_a[(2 * s + lk) * PS + pt * 32 + li];
+      const float bv = sp[(long long)(2 * s + lk) * HW];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (hw < HW) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (p < P) z[((long long)b * P + p) * HW + hw] = acc[r] + bs;
+      }
+    }
+  }
+}
+extern "C" int avsep_innerprod_pixelwise(const float* imgs, const float* snd, const float* scale, const float* bias, int32_t B,
+                                         int32_t K, int32_t P, int32_t HW, float* z, avsep_stream_t stream) {
+  if (!imgs || !snd || !z || B <= 0 || B > 65535 || K <= 0 || (K & 1) || P <= 0 || HW <= 0) return AVSEP_ERR_ARG;
+  const size_t smem = (size_t)K * (roundup(P, 32) + 1) * sizeof(float);
+  if (smem > 160 * 1024) return AVSEP_ERR_ARG;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)innerprod_pixelwise_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(innerprod_pixelwise_kernel, dim3(cdiv(HW, 128), B), dim3(256), smem, (hipStream_t)stream, imgs, snd, scale, bias,
+                     K, P, HW, z);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
 // Separation metrics (main.py:260-266 via asteroid.metrics.get_metrics): the three inner products every
 // SDR-type ratio is made of, per row: sums[r] = (<est,ref>, <ref,ref>, <est,est>) in fp64.  grid (chunks, R)
 __global__ __launch_bounds__(256) void sdr_sums_kernel(const float* __restrict__ est, const float* __restrict__ ref,

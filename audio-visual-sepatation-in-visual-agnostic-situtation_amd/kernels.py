@@ -37,6 +37,24 @@ def get_precision():
 plan_batch_scale = 1
 
 
+_pack_cache = None
+
+
+class pack_scope:
+    """`with pack_scope():` — packed weight images are cached for the duration (Conv.pack).  The caller guarantees that no
+    weight changes inside: train_step_async wraps forward + backward, the optimizer step comes after."""
+
+    def __enter__(self):
+        global _pack_cache
+        self.prev, _pack_cache = _pack_cache, ({} if _pack_cache is None else _pack_cache)
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_cache
+        _pack_cache = self.prev
+        return False
+
+
 def out_size(h, k, s, p, d):
     return (h + 2 * p - d * (k - 1) - 1) // s + 1
 
@@ -68,9 +86,23 @@ class Conv:
         self.like = x0
 
     def pack(self, w, mode):
+        """Operand image of `w` for this call (mode 0 forward, 1 data gradient).  Inside a `pack_scope()` — one train step,
+        during which the weights do not change — the image of a (weight, geometry, mode) is built once and shared: the
+        second decoder pass of an AV step and the visual trunk's second source used to repack every weight (56 of the
+        114 pack launches of a step)."""
+        d = self.d
+        key = None
+        if _pack_cache is not None:
+            key = (w.data_ptr(), mode, d.N, d.Cin, d.H, d.W, d.Cout, d.KH, d.KW, d.stride, d.pad, d.dil, d.C0, d.up2x, d.prec,
+                   d.plan_n, bool(d.scale0), bool(d.scale1), d.act0, d.act1)
+            hit = _pack_cache.get(key)
+            if hit is not None:
+                return hit[0]
         n = lib.load().avsep_conv_packed_floats(self.ref, mode)
         out = _f32((n,), w)
         call("avsep_conv_pack_weights", self.ref, ptr(w), ptr(out), mode)
+        if key is not None:
+            _pack_cache[key] = (out, w)      # holding `w` keeps a temporary weight tensor's address from being reused
         return out
 
     def _ws(self, query):

@@ -100,6 +100,8 @@ SIGNATURES = {
     "avsep_temporal_mean_bwd": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "avsep_sgd_momentum": (C.c_int, [_P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
     "avsep_innerprod_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "avsep_innerprod_nosum": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "avsep_innerprod_pixelwise": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_innerprod_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "avsep_sdr_sums": (C.c_int, [_P, _P, _I, _I, C.c_int64, C.c_int64, _P, _P]),
 }

@@ -441,11 +441,12 @@ def train_step_async(model, batch, optimizer, use_vis, step_args=None):
     torch.set_grad_enabled(True)
     model.train()
     optimizer.zero_grad()
-    err, outputs = model.forward(batch, a, use_vis)
-    err = err.mean()
-    if isinstance(optimizer, FlatSGD):
-        optimizer.arm_early_reduce(getattr(model, "unet_nodes", 0))
-    err.backward()
+    with K.pack_scope():                 # the weights are constant from here to optimizer.step(): pack each image once
+        err, outputs = model.forward(batch, a, use_vis)
+        err = err.mean()
+        if isinstance(optimizer, FlatSGD):
+            optimizer.arm_early_reduce(getattr(model, "unet_nodes", 0))
+        err.backward()
     if isinstance(optimizer, FlatSGD):
         optimizer.step(only=None if use_vis else ("sound",))   # the visual net is not in an audio-only graph
     else:

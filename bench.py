@@ -396,6 +396,8 @@ def main():
     ap.add_argument("--backend", default="hip", choices=["hip", "hybrid", "torch"], help="visual trunk of the headline run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--no-instrumented", action="store_true", help="profiling runs under rocprofv3: only the un-instrumented "
+                    "headline pass (no HIP-event pairs, no per-kernel tables in the line)")
     ap.add_argument("--layers", default=None, help="write a per-convolution-call table of the headline step to this file")
     ap.add_argument("--config", type=int, default=3, choices=[3, 5], help="3: BASELINE configs[2] shape (headline); 5: configs[4] "
                     "(3 sources, 5 frames, 512x256, batch 32) as the headline workload of this run")
@@ -422,6 +424,16 @@ def main():
         B = min(B, CONFIG5_BATCH)
     # headline: un-instrumented.  Then the same configuration once more with HIP-event pairs around every conv launch
     head = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup, config=o.config)
+    if o.no_instrumented:
+        if rank == 0:
+            print(json.dumps({"metric": "mixtures/sec (train step, 2-src MUSIC shape)", "value": head["value"], "unit": "mixtures/s",
+                              "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": head["ms_per_step"],
+                              "dtype": o.precision, "config": {"workload": "headline pass only (--no-instrumented), batch %d" % B},
+                              "loss": head["loss"]}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     timer = KernelTimer(P.kernels)
     inst = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, min(o.warmup, 1), timer, config=o.config)
     kernels = timer.summary(o.steps)

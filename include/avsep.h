@@ -369,6 +369,14 @@ int avsep_sgd_momentum(float* p, const float* g, float* buf, size_t n, float lr,
 /* InnerProd / Bias synthesizer (models/synthesizer_net.py:12-19): z[b,hw] = sum_k img[b,k]*scale[k]*snd[b,k,hw] + bias */
 int avsep_innerprod_fwd(const float* img, const float* snd, const float* scale, const float* bias,
                         int32_t B, int32_t K, int32_t HW, float* z, avsep_stream_t stream);
+/* The synthesizer's inference helpers (models/synthesizer_net.py:21-38; scale NULL for `Bias`):
+ * forward_nosum     z[b,k,hw] = img[b,k]*scale[k]*snd[b,k,hw] + bias                         z [B,K,HW]
+ * forward_pixelwise z[b,p,hw] = sum_k imgs[b,k,p]*scale[k]*snd[b,k,hw] + bias  (imgs [B,K,P]) z [B,P,HW], K even:
+ *                   the per-sample [P x K] x [K x HW] contraction on the f32 MFMA. */
+int avsep_innerprod_nosum(const float* img, const float* snd, const float* scale, const float* bias,
+                          int32_t B, int32_t K, int32_t HW, float* z, avsep_stream_t stream);
+int avsep_innerprod_pixelwise(const float* imgs, const float* snd, const float* scale, const float* bias,
+                              int32_t B, int32_t K, int32_t P, int32_t HW, float* z, avsep_stream_t stream);
 /* backward: dsnd[b,k,hw] = img[b,k]*scale[k]*dz[b,hw] (optional) and r[b,k] = sum_hw snd[b,k,hw]*dz[b,hw],
  * from which the caller forms dimg = scale*r, dscale = sum_b img*r, dbias = sum dz. */
 int avsep_innerprod_bwd(const float* img, const float* snd, const float* scale, const float* dz,

@@ -27,7 +27,8 @@ def per_kernel(directory):
 
 
 def family(name):
-    for key in ("winow_kernel", "wino_kernel", "convbf_kernel", "wgradbf_kernel", "conv3x3_kernel", "wgrad3x3_kernel", "head_fwd_kernel", "head_wgrad_kernel",
+    for key in ("winow_kernel", "wino_kernel", "convbf_kernel", "wgradbf_kernel", "wgrad4bf_kernel", "wgrad4d_kernel", "smallci_wgrad_kernel",
+                "conv3x3_kernel", "wgrad3x3_kernel", "head_fwd_kernel", "head_wgrad_kernel", "affine_act_kernel", "maxpool_fwd4_kernel",
                 "head_dgrad_kernel", "smallco_fwd", "smallco_wgrad", "smallci_dgrad", "relu_up2x_fwd",
                 "relu_up2x_bwd", "bn_bwd_apply_kernel", "affine_act_bwd_kernel", "sgd_kernel", "w3_reduce_kernel"):
         if key in name:

@@ -179,6 +179,37 @@ def test_fusion_n_kernel(dev, C, D, att):
     assert_close(xd2.grad, xo2.grad, 1e-6, "AO dx")
 
 
+def test_synthesizer_entry_points_golden(dev, golden):
+    """InnerProd / Bias (models/synthesizer_net.py:6-70): forward (GEMV kernel), forward_nosum and forward_pixelwise (the
+    inference helpers: avsep_innerprod_nosum / avsep_innerprod_pixelwise, the [P x K] x [K x HW] mask contraction on the
+    f32 MFMA) against the fixtures generated from the reference; under autograd the helpers must give the same values
+    and differentiate; a full-size pixelwise case (K = 32, 14x14 visual positions, 256x256 audio positions) against
+    torch.bmm on the CPU."""
+    P = _pkg()
+    G = golden("synthesizer")
+    for name, mod in (("innerprod", P.models.synthesizer_net.InnerProd(8)), ("bias", P.models.synthesizer_net.Bias())):
+        mod.load_state_dict({k[len(name) + 3:]: v for k, v in G.items() if k.startswith(name + ".w.")})
+        mod = mod.to(dev)
+        for fn, arg in (("forward", G["fi"]), ("forward_nosum", G["fi"]), ("forward_pixelwise", G["fim"])):
+            with torch.no_grad():
+                assert_close(getattr(mod, fn)(arg.to(dev), G["fs"].to(dev)), G[f"{name}.{fn}"], 1e-5, f"{name}.{fn} (kernel)")
+            a, snd = arg.to(dev).requires_grad_(True), G["fs"].to(dev).requires_grad_(True)
+            out = getattr(mod, fn)(a, snd)
+            assert_close(out, G[f"{name}.{fn}"], 1e-5, f"{name}.{fn} (autograd)")
+            out.sum().backward()
+            assert a.grad is not None and snd.grad is not None
+    g = torch.Generator().manual_seed(4)
+    mod = P.models.synthesizer_net.InnerProd(32)
+    with torch.no_grad():
+        mod.scale.copy_(torch.rand(32, generator=g) + 0.5)
+        mod.bias.fill_(0.3)
+    imgs, snd = torch.randn(2, 32, 14, 14, generator=g), torch.randn(2, 32, 256, 256, generator=g)
+    with torch.no_grad():
+        ref = torch.bmm((imgs.view(2, 32, 196).transpose(1, 2) * mod.scale), snd.view(2, 32, -1)).view(2, 14, 14, 256, 256) + 0.3
+        out = mod.to(dev).forward_pixelwise(imgs.to(dev), snd.to(dev))
+    assert_close(out, ref, 2e-6, "forward_pixelwise, full size")
+
+
 def _args(**kw):
     a = argparse.Namespace(num_mix=2, log_freq=0, weighted_loss=1, binary_mask=1, output_activation="sigmoid",
                            img_activation="relu", not_pool_vis=False, fusion_type="hidsep", match_weight=0.1,
