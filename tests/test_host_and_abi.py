@@ -131,3 +131,87 @@ def test_checkpoint_files_match_the_reference_names(tmp_path):
     assert torch.load(os.path.join(a.ckpt, "history_latest.pth")) == hist
     assert P.checkpoint.resume_paths(a, best=True) == (os.path.join(a.ckpt, "sound_best.pth"),
                                                          os.path.join(a.ckpt, "frame_best.pth"))
+
+
+def test_direct_gradient_placement_host_logic():
+    """FlatSGD.grad_dest / scratch_dest / fold_scratch + models.audio_net.ParamGrads on CPU tensors (the kernels are stood
+    in for by tensor copies): the first contribution of a step lands in the parameter's slot of the flat gradient buffer,
+    a second one — same node or another node of the step — goes through the scratch buffer and one add per contiguous
+    run, a parameter whose .grad was detached is handed back to autograd, and zero_grad() re-arms everything.  Every
+    tensor starts on a 256-byte boundary and the padding stays zero."""
+    P = _pkg()
+    FlatSGD, ParamGrads = P.net_wrapper.FlatSGD, P.models.audio_net.ParamGrads
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5), torch.nn.Conv2d(5, 2, 1))
+    params = list(net.parameters())
+    opt = FlatSGD([{"params": params, "lr": 0.1, "name": "sound"}], require_gpu=False)
+    P.net_wrapper.attach_grad_sink(opt, net)
+    A = FlatSGD.ALIGN
+    assert all(gv.storage_offset() % A == 0 for _, gv in opt._views) and opt.flat_grad.numel() % A == 0
+    g1 = [torch.randn_like(p) for p in params]
+    g2 = [torch.randn_like(p) for p in params]
+
+    class Cv:                        # stands in for kernels.Conv: "writes" dw (and db) into the destinations it is handed
+        def __init__(self, dw, db):
+            self.dw, self.db = dw, db
+
+        def wgrad(self, dy, want_bias=False, out=None, out_bias=None):
+            dw = self.dw.clone() if out is None else out.copy_(self.dw)
+            db = None
+            if want_bias:
+                db = self.db.clone() if out_bias is None else out_bias.copy_(self.db)
+            return dw, db
+    opt.zero_grad()
+    node = ParamGrads(net)
+    node.wgrad(Cv(g1[0], g1[1]), params[0], None, params[1])       # first contribution: straight into the flat views
+    for i in (2, 3, 4, 5):
+        node.add(params[i], g1[i].clone())
+    node.wgrad(Cv(g2[0], g2[1]), params[0], None, params[1])       # second contribution of the SAME node: scratch + fold
+    node.add(params[4], g2[4].clone())
+    out = node.finish(params, "sound")
+    assert all(o is None for o in out), "every gradient was placed directly"
+    exp = [a + b if i in (0, 1, 4) else a for i, (a, b) in enumerate(zip(g1, g2))]
+    for (p, gv), e in zip(opt._views, exp):
+        assert torch.allclose(p.grad, e) and p.grad.data_ptr() == gv.data_ptr()
+    # a second node of the same step (the visual trunk runs once per source): everything through the scratch buffer
+    node2 = ParamGrads(net)
+    node2.wgrad(Cv(g2[0], g2[1]), params[0], None, params[1])
+    for i in (2, 3, 4, 5):
+        node2.add(params[i], g2[i].clone())
+    assert all(o is None for o in node2.finish(params, "sound"))
+    exp2 = [e + b for e, b in zip(exp, g2)]
+    for (p, _), e in zip(opt._views, exp2):
+        assert torch.allclose(p.grad, e)
+    used = torch.zeros_like(opt.flat_grad, dtype=torch.bool)
+    for _, gv in opt._views:
+        used[gv.storage_offset():gv.storage_offset() + gv.numel()] = True
+    assert float(opt.flat_grad[~used].abs().sum()) == 0.0, "padding stays zero"
+    # detached .grad (module.zero_grad(set_to_none=True) semantics): the node must hand the gradient back to autograd
+    opt.zero_grad()
+    params[2].grad = None
+    node3 = ParamGrads(net)
+    node3.add(params[2], g1[2].clone())
+    node3.add(params[3], g1[3].clone())
+    out3 = node3.finish(params, "sound")
+    assert out3[2] is not None and torch.equal(out3[2], g1[2]) and out3[3] is None
+    # no optimizer attached: plain dict semantics
+    plain = torch.nn.Conv2d(2, 2, 1)
+    n4 = ParamGrads(plain)
+    n4.add(plain.weight, torch.ones_like(plain.weight))
+    n4.add(plain.weight, torch.ones_like(plain.weight))
+    w, b = n4.finish([plain.weight, plain.bias])
+    assert torch.equal(w, 2 * torch.ones_like(plain.weight)) and b is None
+
+
+def test_pack_scope_and_plan_batch_are_scoped():
+    """kernels.pack_scope caches packed images only inside the with-block; plan_batch_scale defaults to 1 (plan_n = 0)."""
+    P = _pkg()
+    K = P.kernels
+    assert K._pack_cache is None and K.plan_batch_scale == 1
+    with K.pack_scope():
+        assert K._pack_cache == {}
+        with K.pack_scope():                       # nested scopes share the cache of the outermost
+            K._pack_cache["x"] = 1
+        assert K._pack_cache == {"x": 1}
+    assert K._pack_cache is None
+    assert P.lib.ConvDesc().plan_n == 0 and ctypes.sizeof(P.lib.ConvDesc) == 18 * 4 + 6 * 8
