@@ -15,6 +15,7 @@
 //     (8 fp32 loads -> affine/activation -> 4 packed converts -> one ds_write_b128).
 // Single source, no fused upsample (the U-Net decoder materialises relu+upsample, the fused head stays fp32).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "halo_kernel.h"   // C3Args (shared argument block)
 
@@ -101,7 +102,11 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
     p_g[e] = g;
     pok |= (unsigned)ok << e;
   }
-  float praw[PE][8];
+  // TWO register sets for the patch: the global loads of K-tile kt + 2 are in flight while K-tile kt computes and kt + 1 is
+  // converted into LDS.  With one set the loads of kt + 1 were issued at the top of iteration kt and consumed at its bottom:
+  // one K-tile of MFMAs (18-36 x 32 cycles) is shorter than an HBM round trip under load, and the waves sat parked on
+  // s_waitcnt for 38-50 % of their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r03_convbf_sq_before_prefetch2.txt)
+  float praw[2][PE][8];
   if (has_aff) {                            // scale / shift rows -> LDS once (kept out of the register pipeline)
     for (int c = tid; c < a.Cin; c += NTHR) {
       aff_sc[c] = a.sc0[c];
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
   }
   const long long a_step = (long long)NT * a.wp_ld * 32;
 
-  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+  auto issue_w = [&](int kt, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
       if (AE * NTHR == A_CH || (wave * 64 + NTHR * e) < A_CH) {      // wave-uniform: whole waves only (A_CH % 64 == 0)
@@ -130,14 +135,18 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
                                          (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
       }
     }
+  };
+  auto issue_p = [&](int kt, auto set) __attribute__((always_inline)) {
+    constexpr int R = decltype(set)::value;
     const float* xk = a.x0 + (long long)kt * BF_CK * sHW;             // uniform: scalar base + 32-bit lane offset
 #pragma unroll
     for (int e = 0; e < PE; ++e) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) praw[e][j] = (xk + (long long)j * sHW)[p_off[e]];
+      for (int j = 0; j < 8; ++j) praw[R][e][j] = (xk + (long long)j * sHW)[p_off[e]];
     }
   };
-  auto finish = [&](int kt, int buf) __attribute__((always_inline)) {
+  auto finish = [&](int kt, int buf, auto set) __attribute__((always_inline)) {
+    constexpr int R = decltype(set)::value;
 #pragma unroll
     for (int e = 0; e < PE; ++e) {
       float v[8];
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float x = praw[e][j];
+        float x = praw[R][e][j];
         if (has_aff) x = fmaf(x, sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
         v[j] = RAW ? x : act_by_slope(x, slope);
       }
@@ -197,14 +206,19 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
     kt0 = blockIdx.y * a.kts;
     nK = min(nK, kt0 + a.kts);
   }
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
   if (kt0 < nK) {
-    issue(kt0, 0);
-    finish(kt0, 0);
+    issue_w(kt0, 0);
+    issue_p(kt0, Set0{});
+    if (kt0 + 1 < nK) issue_p(kt0 + 1, Set1{});
+    finish(kt0, 0, Set0{});
   }
   __syncthreads();
-  for (int kt = kt0; kt < nK; ++kt) {
+  // one K-tile: `nxt` holds the patch of kt + 1 (loaded an iteration ago), `far` receives the patch of kt + 2
+  auto ktile = [&](int kt, auto nxt, auto far) __attribute__((always_inline)) {
     const int buf = (kt - kt0) & 1;
-    if (kt + 1 < nK) issue(kt + 1, buf ^ 1);
+    if (kt + 1 < nK) issue_w(kt + 1, buf ^ 1);
     const unsigned char* Ak = Ab + buf * A_BYTES + a_lane;
     const unsigned char* Pk = Pb + buf * P_BYTES;
     bf16x8 av[2][TM], bv[2][2];
@@ -225,8 +239,21 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nK) finish(kt + 1, buf ^ 1);
-    __syncthreads();       // also drains the LDS-DMA of the next weight tile (vmcnt(0) before s_barrier)
+    if (kt + 1 < nK) finish(kt + 1, buf ^ 1, nxt);
+    // The barrier of the K-tile.  __syncthreads() is a workgroup-scope fence: on gfx9 loads and stores share vmcnt, so it
+    // compiles to s_waitcnt vmcnt(0) and would drain the far patch loads issued just now.  What has to be complete here is
+    // (a) this wave's LDS stores (lgkmcnt) and (b) its LDS-DMA pieces of the next weight tile, which are OLDER than the
+    // PE * 8 far loads: a counted vmcnt leaves exactly those in flight.
+    if (kt + 2 < nK) {
+      issue_p(kt + 2, far);                                // `far` is the set the previous K-tile's finish() freed
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PE * 8) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  };
+  for (int kt = kt0; kt < nK; kt += 2) {
+    ktile(kt, Set1{}, Set0{});
+    if (kt + 1 < nK) ktile(kt + 1, Set0{}, Set1{});
   }
 
   // ---- epilogue: identical to halo_kernel.h (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
