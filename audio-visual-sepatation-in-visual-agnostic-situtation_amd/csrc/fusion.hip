@@ -283,20 +283,37 @@ __global__ __launch_bounds__(256) void fusion_av_bwd_kernel(FusArgs a, const flo
     }
   }
   __syncthreads();
-  // gradient to the audio vectors -> scattered to the arg-max position of the global max-pool
-  for (int i = tid; i < D; i += 256) {
-    int k = i / Dc, d = i % Dc;
-    float g = 0.f;
+  // gradient to the audio vectors -> scattered to the arg-max position of the global max-pool.  A wave owns channel d: its
+  // lanes sweep the HW positions of v_c[d] (coalesced; a thread per (k, d) walked its own row, 64 cache lines per load
+  // instruction: 2/3 of the kernel's 220 us) and reduce both audio blocks' sums at once.
+  float* s_ga = s_S + 8;                 // [D]
+  for (int d = wave; d < Dc; d += 4) {
+    float g0 = 0.f, g1 = 0.f;
     for (int c = 0; c < 2; ++c) {
       const float* vp = (c == 0 ? a.v0 : a.v1) + ((long long)b * Dc + d) * HW;
-      const float* E = s_E + (k * 2 + c) * HW;
-      if (a.att == 1) {
-        for (int hw = 0; hw < HW; ++hw) g = fmaf(E[hw], vp[hw], g);
-      } else {
-        const float* nv = s_nv + c * HW;
-        for (int hw = 0; hw < HW; ++hw) g = fmaf(E[hw] / fmaxf(nv[hw], FUS_EPS), vp[hw], g);
+      const float* E0 = s_E + (0 * 2 + c) * HW;
+      const float* E1 = s_E + (1 * 2 + c) * HW;
+      const float* nv = s_nv + c * HW;
+      for (int hw = lane; hw < HW; hw += 64) {
+        const float vv = vp[hw];
+        if (a.att == 1) {
+          g0 = fmaf(E0[hw], vv, g0);
+          g1 = fmaf(E1[hw], vv, g1);
+        } else {
+          const float dn = fmaxf(nv[hw], FUS_EPS);
+          g0 = fmaf(E0[hw] / dn, vv, g0);
+          g1 = fmaf(E1[hw] / dn, vv, g1);
+        }
       }
     }
+    g0 = wave_sum(g0);
+    g1 = wave_sum(g1);
+    if (lane == 0) { s_ga[d] = g0; s_ga[Dc + d] = g1; }
+  }
+  __syncthreads();
+  for (int i = tid; i < D; i += 256) {
+    int k = i / Dc;
+    float g = s_ga[i];
     if (a.att == 0) {
       float na = s_na[k], nac = fmaxf(na, FUS_EPS);
       g = g / nac;
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(256) void fusion_av_bwd_kernel(FusArgs a, const flo
   }
 }
 
-static size_t fusion_smem(int Dc, int HW) { return (size_t)(2 * Dc + 4 * HW + 2 * HW + 16 + 2 + 4 + 4 + 4 + 4 * HW + 2 + 8) * 4; }
+static size_t fusion_smem(int Dc, int HW) { return (size_t)(2 * Dc + 4 * HW + 2 * HW + 16 + 2 + 4 + 4 + 4 + 4 * HW + 2 + 8 + 2 * Dc) * 4; }
 
 extern "C" int avsep_fusion_av_fwd(const float* x, const float* v0, const float* v1, int32_t B, int32_t Dc, int32_t FT,
                                    int32_t HW, int32_t kind, int32_t att, float* a_pool, int32_t* pool_idx, float* feat,

@@ -374,7 +374,9 @@ __global__ __launch_bounds__(256) void relu_up2x_fwd_kernel(CatArgs a, float* __
 // ---------------------------------------------------------------------------------------------------------------
 // thread = (plane, low-res row pair (r, r+1), q) -> hi-res rows 2r+1, 2r+2, columns 4q..4q+3 (two 16-byte stores)
 __global__ __launch_bounds__(256) void relu_up2x_fwd_pair_kernel(CatArgs a, float* __restrict__ out, int lw) {
-  const int C = a.C0 + a.C1, nc = blockIdx.y, n = nc / C, c = nc % C;          // block-uniform
+  const int C = a.C0 + a.C1, nc = blockIdx.z * gridDim.y + blockIdx.y;          // plane (n, c): block-uniform; grid (x, y, z)
+  if (nc >= a.N * C) return;                                                    // y * z may overshoot the plane count
+  const int n = nc / C, c = nc % C;
   const int t = blockIdx.x * 256 + threadIdx.x, q = t & ((1 << lw) - 1), r = (t >> lw) - 1;
   const bool live = r < a.H;                                                    // r = -1 .. H-1
   const bool first = c < a.C0;
@@ -433,17 +435,30 @@ __global__ __launch_bounds__(256) void relu_up2x_fwd_pair_kernel(CatArgs a, floa
 // low-res columns and spread onto rows (r, r+1).  Fused ReLU mask, skip-gradient accumulation and BatchNorm-backward
 // sums as in relu_up2x_bwd_kernel.
 constexpr int UPB_R = 8;
+// MULTI: planes that need TP = (H / UPB_R) << lw <= 64 threads (16x16 / 32x32 low-res maps): 256 / TP planes per block, a
+// plane inside one wave, per-plane statistics by a segmented shuffle reduce (one plane per block left 75-94 % of the lanes
+// idle: 1.1 TB/s on the [64, 1024, 32, 32] gradient).  tp_log = log2(TP).
+template <bool MULTI>
 __global__ __launch_bounds__(256) void relu_up2x_bwd_sweep_kernel(CatArgs a, const float* __restrict__ dout,
                                                                   float* __restrict__ g0, float* __restrict__ g1,
                                                                   const float* __restrict__ mean1,
                                                                   const float* __restrict__ invstd1, double* bstats1,
-                                                                  int acc0, int lw) {
-  const int C = a.C0 + a.C1, nc = blockIdx.y, n = nc / C, c = nc % C;
-  const int t = blockIdx.x * 256 + threadIdx.x, q = t & ((1 << lw) - 1), r0 = (t >> lw) * UPB_R;
+                                                                  int acc0, int lw, int tp_log) {
+  const int C = a.C0 + a.C1;
+  int nc = blockIdx.z * gridDim.y + blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  if constexpr (MULTI) {
+    nc = (nc << (8 - tp_log)) + (threadIdx.x >> tp_log);
+    t = threadIdx.x & ((1 << tp_log) - 1);
+  }
+  const bool plane_ok = nc < a.N * C;
+  if (!MULTI && !plane_ok) return;
+  if (!plane_ok) nc = a.N * C - 1;                      // MULTI: lanes past the last plane compute on it and store nothing
+  const int n = nc / C, c = nc % C;
+  const int q = t & ((1 << lw) - 1), r0 = (t >> lw) * UPB_R;
   const bool first = c < a.C0;
   const int cs = first ? c : c - a.C0, Cs = first ? a.C0 : a.C1;
   float* g = first ? g0 : g1;
-  const bool live = r0 < a.H && g != nullptr;
+  const bool live = r0 < a.H && g != nullptr && plane_ok;
   const float* sc = first ? a.sc0 : a.sc1;
   const float* sh = first ? a.sh0 : a.sh1;
   const float scv = sc ? sc[cs] : 1.f, shv = sc ? sh[cs] : 0.f;
@@ -506,7 +521,17 @@ __global__ __launch_bounds__(256) void relu_up2x_bwd_sweep_kernel(CatArgs a, con
     G0 = la * Ta0 + lb * Tb0;          // share of the same two rows that belongs to row r+1
     G1 = la * Ta1 + lb * Tb1;
   }
-  if (stats) {
+  if constexpr (MULTI) {                                 // `stats` differs between the planes of a wave: no early outs
+    double d1 = stats && live ? (double)s1 : 0.0, d2 = stats && live ? (double)s2 : 0.0;
+    for (int o = (1 << tp_log) >> 1; o > 0; o >>= 1) {
+      d1 += __shfl_xor(d1, o, 64);
+      d2 += __shfl_xor(d2, o, 64);
+    }
+    if (stats && plane_ok && t == 0) {
+      atomicAdd(&bstats1[cs], d1);
+      atomicAdd(&bstats1[a.C1 + cs], d2);
+    }
+  } else if (stats) {
     const double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
     __shared__ double sh2[8];
     if ((threadIdx.x & 63) == 0) { sh2[threadIdx.x >> 6] = d1; sh2[4 + (threadIdx.x >> 6)] = d2; }
@@ -547,8 +572,11 @@ extern "C" int avsep_relu_up2x_fwd(const avsep_cat_desc* d, float* out, avsep_st
   long long planes = (long long)d->N * (d->C0 + d->C1);
   if (planes > 0x7fffffffLL || 2 * d->H > 65535) return AVSEP_ERR_ARG;
   const int plw = up2x_pair_lw(d);
-  if (plw >= 0 && planes <= 65535) {
-    hipLaunchKernelGGL(relu_up2x_fwd_pair_kernel, dim3(cdiv((long long)(d->H + 1) << plw, 256), (unsigned)planes), dim3(256), 0,
+  if (plw >= 0 && planes <= 32768LL * 65535) {
+    // planes over (y, z): [64, 1024, 16, 16] sources are 65536 planes, one more than grid.y holds (they fell back to the
+    // generic kernel: 1.9 TB/s)
+    const unsigned gy = (unsigned)(planes < 32768 ? planes : 32768), gz = (unsigned)cdiv(planes, gy);
+    hipLaunchKernelGGL(relu_up2x_fwd_pair_kernel, dim3(cdiv((long long)(d->H + 1) << plw, 256), gy, gz), dim3(256), 0,
                        (hipStream_t)stream, a, out, plw);
     AVSEP_LAUNCH_CHECK();
     return AVSEP_OK;
@@ -684,10 +712,24 @@ extern "C" int avsep_relu_up2x_bwd(const avsep_cat_desc* d, const float* dout, f
   CatArgs a = make_cat(d);
   int C = d->C0 + d->C1;
   const int plw = up2x_pair_lw(d);
-  // (small planes: one block and one pair of atomics per plane would cost more than the LDS-tiled kernel's batch slices)
-  if (plw >= 0 && d->H >= 32 && (long long)d->N * C <= 65535) {
-    hipLaunchKernelGGL(relu_up2x_bwd_sweep_kernel, dim3(cdiv((long long)cdiv(d->H, UPB_R) << plw, 256), (unsigned)(d->N * C)),
-                       dim3(256), 0, (hipStream_t)stream, a, dout, g0, g1, mean1, invstd1, bstats1, acc0, plw);
+  // (tiny planes: one block and one pair of atomics per plane would cost more than the LDS-tiled kernel's batch slices;
+  // 16x16 planes — the [64, 1024, 32, 32] gradient of u4's input — ran at 1.2 TB/s on the tiled kernel)
+  const long long planes = (long long)d->N * C;
+  if (plw >= 0 && d->H >= 8 && planes <= 32768LL * 65535) {
+    const int chunks = cdiv(d->H, UPB_R), tp = chunks << plw;                  // threads per plane
+    if (tp <= 64 && (chunks & (chunks - 1)) == 0) {                            // several planes per block
+      int tp_log = 0;
+      while ((1 << tp_log) < tp) ++tp_log;
+      const long long groups = cdiv(planes, 256 >> tp_log);
+      const unsigned gy = (unsigned)(groups < 32768 ? groups : 32768), gz = (unsigned)cdiv(groups, gy);
+      hipLaunchKernelGGL(relu_up2x_bwd_sweep_kernel<true>, dim3(1, gy, gz), dim3(256), 0, (hipStream_t)stream, a, dout, g0, g1, mean1,
+                         invstd1, bstats1, acc0, plw, tp_log);
+      AVSEP_LAUNCH_CHECK();
+      return AVSEP_OK;
+    }
+    const unsigned gy = (unsigned)(planes < 32768 ? planes : 32768), gz = (unsigned)cdiv(planes, gy);
+    hipLaunchKernelGGL(relu_up2x_bwd_sweep_kernel<false>, dim3(cdiv((long long)tp, 256), gy, gz),
+                       dim3(256), 0, (hipStream_t)stream, a, dout, g0, g1, mean1, invstd1, bstats1, acc0, plw, 0);
     AVSEP_LAUNCH_CHECK();
     return AVSEP_OK;
   }

@@ -383,6 +383,24 @@ def test_relu_up2x(dev, bcast, H, W):
     assert_close(bst, ref, 1e-5, "bstats")
 
 
+def test_relu_up2x_many_planes(dev):
+    """More (image, channel) planes than one grid dimension holds (the batch-64 step's [64, 1024, 16, 16] level has 65536):
+    the static-pair forward and the row-sweep backward spread the planes over grid (y, z)."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(8)
+    N, C0, C1, H, W = 3, 6000, 5001, 16, 4                      # 33003 planes > 32768 per grid.y slice, ragged last z slice
+    x0, x1 = torch.randn(N, C0, H, W, generator=g), torch.randn(N, C1, H, W, generator=g)
+    a0, a1 = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True)
+    out_ref = F.interpolate(F.relu(torch.cat([a0, a1], 1)), scale_factor=2, mode="bilinear", align_corners=True)
+    dout = torch.randn(out_ref.shape, generator=g)
+    out_ref.backward(dout)
+    cat = K.Cat(x0.to(dev), x1.to(dev))
+    assert_close(cat.fwd(), out_ref, 5e-6, "fwd")
+    g0, g1 = cat.bwd(dout.to(dev))
+    assert_close(g0, a0.grad, 1e-5, "g0")
+    assert_close(g1, a1.grad, 1e-5, "g1")
+
+
 def test_prepare_golden(dev, golden):
     K = _pkg().kernels
     G = golden("prepare")
