@@ -473,12 +473,29 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   out[i] = v;
 }
 
-__global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n, int S) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < S; ++z) s += ws[(long long)z * n + i];
-  out[i] = s;
+// out[i] = sum over S slabs (`stride` elements apart) of ws[z][i], i < n.  Block = 64 consecutive elements x 4 slab groups:
+// thread (e, q) sums slabs z = q, q + 4, ... with four independent loads in flight, the four partials are added in a fixed
+// order through LDS (deterministic).  The one-thread-per-element form walked its S slabs as one dependent chain: 0.15 TB/s
+// on a [256 x 1152] gradient with 32 slabs.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n,
+                                                           int S, long long stride) {
+  __shared__ float part[4][64];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int z = q;
+    for (; z + 12 < S; z += 16) {
+      s0 += ws[(long long)z * stride + i];
+      s1 += ws[(long long)(z + 4) * stride + i];
+      s2 += ws[(long long)(z + 8) * stride + i];
+      s3 += ws[(long long)(z + 12) * stride + i];
+    }
+    for (; z < S; z += 4) s0 += ws[(long long)z * stride + i];
+  }
+  part[q][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0 && i < n) out[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 
 // split-K forward combine: y = sum of slabs (+ bias); per-channel (sum, sumsq) for the following BatchNorm.
@@ -724,8 +741,13 @@ int splitk_combine(const float* ws, long long slab, int S, const avsep_conv_desc
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
+int reduce_slabs_strided(const float* ws, float* out, long long n, int S, long long stride, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, out, n, S, stride);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
 int reduce_slabs(const float* ws, float* out, long long n, int S, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws, out, n, S);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, out, n, S, n);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
@@ -829,8 +851,8 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   }
   AVSEP_LAUNCH_CHECK();
   if (sp.splits > 1) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(a.slab, 256)), dim3(256), 0, st, (const float*)workspace, dx, a.slab,
-                       sp.splits);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(a.slab, 64)), dim3(256), 0, st, (const float*)workspace, dx, a.slab,
+                       sp.splits, a.slab);
     AVSEP_LAUNCH_CHECK();
   }
   return AVSEP_OK;
@@ -918,7 +940,7 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   AVSEP_LAUNCH_CHECK();
   if (p.splits > 1) {
     long long n = (long long)a.M * a.Ncols;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, dw, n, p.splits);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n, p.splits, n);
     AVSEP_LAUNCH_CHECK();
   }
   if (dbias) {

@@ -344,13 +344,7 @@ __global__ __launch_bounds__(256, COUT * CPW <= 2 ? 3 : 2) void head_wgrad_kerne
   }
 }
 
-__global__ void head_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int S) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < S; ++z) s += part[(long long)z * n + i];
-  out[i] = s;
-}
+int reduce_slabs_strided(const float* ws, float* out, long long n, int S, long long stride, hipStream_t st);   // conv.hip
 
 // ---------------------------------------------------------------------------------------------------------------
 // data gradient straight to the low-res sources:
@@ -563,12 +557,9 @@ int head_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbia
 #undef HEAD_WG
   AVSEP_LAUNCH_CHECK();
   const int nw = d->Cout * d->Cin * 9;
-  hipLaunchKernelGGL(head_reduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, st, part, dw, nw, d->N * S);
-  AVSEP_LAUNCH_CHECK();
-  if (dbias) {
-    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(64), 0, st, bpart, dbias, d->Cout, d->N * S);
-    AVSEP_LAUNCH_CHECK();
-  }
+  int rc = reduce_slabs_strided(part, dw, nw, d->N * S, nw, st);       // 512 slabs at batch 64: four slab groups per element
+  if (rc) return rc;
+  if (dbias) return reduce_slabs_strided(bpart, dbias, d->Cout, d->N * S, d->Cout, st);
   return AVSEP_OK;
 }
 

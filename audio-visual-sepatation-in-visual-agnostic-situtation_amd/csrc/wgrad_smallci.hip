@@ -136,16 +136,7 @@ __global__ __launch_bounds__(256, 2) void smallci_wgrad_kernel(ScwArgs a) {
   }
 }
 
-// dw[co][n] = sum over the workgroup slabs (grid.x of them per channel tile), fixed order
-__global__ void smallci_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout, int NC, int slabs,
-                                            int gridM) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Cout * NC) return;
-  const int co = i / NC, n = i % NC, mt = co >> 6, row = co & 63;
-  float s = 0.f;
-  for (int z = 0; z < slabs; ++z) s += part[(((long long)z * gridM + mt) * 64 + row) * NC + n];
-  dw[i] = s;
-}
+int reduce_slabs_strided(const float* ws, float* out, long long n, int S, long long stride, hipStream_t st);   // conv.hip
 
 // ---------------------------------------------------------------------------
 // host side (called from conv.hip)
@@ -198,9 +189,7 @@ int scw_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, h
     hipLaunchKernelGGL((smallci_wgrad_kernel<1, 4, 4, 2, 1>), grid, dim3(256), smem, st, a);
   }
   AVSEP_LAUNCH_CHECK();
-  const int NC = d->Cin * d->KH * d->KW;
-  hipLaunchKernelGGL(smallci_wgrad_reduce_kernel, dim3(cdiv((long long)d->Cout * NC, 256)), dim3(256), 0, st, ws, dw, d->Cout, NC, slabs,
-                     gridM);
-  AVSEP_LAUNCH_CHECK();
-  return AVSEP_OK;
+  // a slab = [gridM * 64 rows][NC]: its first Cout * NC elements are dw's layout; summed over the workgroups in a fixed order
+  const long long NC = (long long)d->Cin * d->KH * d->KW;
+  return reduce_slabs_strided(ws, dw, d->Cout * NC, slabs, (long long)gridM * 64 * NC, st);
 }
