@@ -507,15 +507,23 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
   const float b = bias ? bias[c] : 0.f;
   const int n_per = (N + gridDim.y - 1) / gridDim.y, n_beg = blockIdx.y * n_per, n_end = min(N, n_beg + n_per);
   float s1 = 0.f, s2 = 0.f;
-  for (int n = n_beg; n < n_end; ++n) {
-    const long long base = ((long long)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-      float v = b;
-      for (int z = 0; z < S; ++z) v += ws[(long long)z * slab + base + i];
-      y[base + i] = v;
-      s1 += v;
-      s2 += v * v;
+  // the block's (image, pixel) pairs as ONE index range: the maps that need split-K are 2x2 ... 8x8, and a loop over the
+  // pixels of one image left 75-98 % of the threads idle; two slab chains in flight per element
+  const int total = (n_end - n_beg) * HW;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int n = n_beg + e / HW, i = e - (e / HW) * HW;
+    const long long base = ((long long)n * C + c) * HW + i;
+    float v0 = b, v1 = 0.f;
+    int z = 0;
+    for (; z + 1 < S; z += 2) {
+      v0 += ws[(long long)z * slab + base];
+      v1 += ws[(long long)(z + 1) * slab + base];
     }
+    if (z < S) v0 += ws[(long long)z * slab + base];
+    const float v = v0 + v1;
+    y[base] = v;
+    s1 += v;
+    s2 += v * v;
   }
   if (stats) {
     double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
