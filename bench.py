@@ -358,7 +358,8 @@ WINOGRAD_EXECUTED = {"wino_kernel": 4.0 / 9.0, "winow_kernel": 4.0 / 9.0}      #
 
 def roofline_of(kernels, prec, step_ms, B_total_per_gpu):
     """dominant MFMA kernel + whole-step fraction + the HBM-bound families, from a KernelTimer summary."""
-    mfma = {k: v for k, v in kernels.items() if v["gflop_per_step"] > 0 and not k.startswith(("head_", "smallc"))}
+    vec = ("head_", "smallco", "smallci_dgrad")          # conv families that run on the vector ALU (M or K too small for an MFMA tile)
+    mfma = {k: v for k, v in kernels.items() if v["gflop_per_step"] > 0 and not k.startswith(vec)}
     dom = max(mfma, key=lambda k: mfma[k]["ms_per_step"])
     d = mfma[dom]
     # a kernel family computes in bf16 only if it is one of the bf16 kernels; the rest of a bf16 step is exact f32
@@ -382,7 +383,7 @@ def roofline_of(kernels, prec, step_ms, B_total_per_gpu):
             "conv_kernel_ms_per_step": tot_ms, "all_convs_tflops": tot_fl / tot_ms if tot_ms else 0.0}
     hbm = {k: {"ms_per_step": v["ms_per_step"], "achieved": v["algorithmic_gb_per_s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                "frac": v["algorithmic_gb_per_s"] / PEAK_HBM_GBS, "bound": "hbm"}
-           for k, v in kernels.items() if k.startswith(("head_", "relu_up2x", "smallc"))}
+           for k, v in kernels.items() if k.startswith(vec + ("relu_up2x",))}
     return roof, step, hbm
 
 
