@@ -564,11 +564,13 @@ int smallco_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const floa
 size_t smallco_wgrad_workspace_floats(const avsep_conv_desc* d);
 int smallco_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st);
 bool head_applicable(const avsep_conv_desc* d);
-int head_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* bias, float* y, hipStream_t st);
+int head_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* bias, float* y, float* ws, hipStream_t st);
+size_t head_fwd_workspace_floats(const avsep_conv_desc* d);
+size_t head_dgrad_workspace_floats(const avsep_conv_desc* d);
 size_t head_wgrad_workspace_floats(const avsep_conv_desc* d);
 int head_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st);
 int head_dgrad(const avsep_conv_desc* d, const float* w, const float* dy, float* g0, float* g1, const float* mean1,
-               const float* invstd1, double* bstats1, int acc0, hipStream_t st);
+               const float* invstd1, double* bstats1, int acc0, float* ws, hipStream_t st);
 bool smallci_applicable(const avsep_conv_desc* d);
 int smallci_dgrad(const avsep_conv_desc* d, const float* w_oihw, const float* dy, float* dx, hipStream_t st);
 // conv_wino.hip: Winograd F(2x2, 3x3) form of the 3x3 / stride 1 / 'same' convs (forward and dgrad), fp32
@@ -760,11 +762,19 @@ int reduce_slabs(const float* ws, float* out, long long n, int S, hipStream_t st
   return AVSEP_OK;
 }
 
-extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
+static size_t fwd_workspace_no_head(const avsep_conv_desc* d) {
   if (!check_desc(d, true) && bf_applicable(d, 0)) return bf_workspace_bytes(d, 0);
   if (check_desc(d, true) || !fwd_uses_igemm(d, (const double*)1)) return 0;
   SplitPlan p = fwd_split(d);
   return p.splits > 1 ? (size_t)p.splits * d->N * d->Cout * d->Ho * d->Wo * sizeof(float) : 0;
+}
+extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
+  size_t need = fwd_workspace_no_head(d);
+  if (!check_desc(d, true) && head_applicable(d)) {      // the head kernels serve the call without statistics: cover both
+    const size_t h = head_fwd_workspace_floats(d) * sizeof(float);
+    if (h > need) need = h;
+  }
+  return need;
 }
 extern "C" size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (!check_desc(d) && !smallci_applicable(d) && bf_applicable(d, 1)) return bf_workspace_bytes(d, 1);
@@ -781,7 +791,10 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   if (rc) return rc;
   if (!w_packed || !y) return AVSEP_ERR_ARG;
   if (!stats && smallco_applicable(d)) return smallco_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
-  if (!stats && head_applicable(d)) return head_fwd(d, w_packed, packed_ld(d, 0), bias, y, (hipStream_t)stream);
+  if (!stats && head_applicable(d)) {
+    if (!workspace || workspace_bytes < head_fwd_workspace_floats(d) * sizeof(float)) return AVSEP_ERR_WORKSPACE;
+    return head_fwd(d, w_packed, packed_ld(d, 0), bias, y, (float*)workspace, (hipStream_t)stream);
+  }
   if (bf_applicable(d, 0)) return bf_fwd(d, w_packed, bias, y, stats, workspace, workspace_bytes, (hipStream_t)stream);
   if (wn_applicable(d, 0)) return wn_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (c3_applicable(d, 0)) return c3_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
@@ -1011,19 +1024,23 @@ extern "C" int avsep_conv_kernel_variant(const avsep_conv_desc* d, int32_t mode,
 }
 
 // ---------------------------------------------------------------------------
-// fused decoder head (head.hip): dgrad of a conv over the virtual up2x(relu(affine(cat))) input, taken straight to
+// fused decoder head (head_gemm.hip): dgrad of a conv over the virtual up2x(relu(affine(cat))) input, taken straight to
 // the two low-res sources
 // ---------------------------------------------------------------------------
 extern "C" int32_t avsep_conv2d_head_applicable(const avsep_conv_desc* d) {
   return (check_desc(d) == AVSEP_OK && head_applicable(d)) ? 1 : 0;
 }
+extern "C" size_t avsep_conv2d_dgrad_up2x_workspace_bytes(const avsep_conv_desc* d) {
+  return (check_desc(d) == AVSEP_OK && head_applicable(d)) ? head_dgrad_workspace_floats(d) * sizeof(float) : 0;
+}
 extern "C" int avsep_conv2d_dgrad_up2x(const avsep_conv_desc* d, const float* w, const float* dy, float* g0, float* g1,
                                        const float* mean1, const float* invstd1, double* bstats1, int32_t acc0,
-                                       avsep_stream_t stream) {
+                                       void* workspace, size_t workspace_bytes, avsep_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!w || !dy || (!g0 && !g1)) return AVSEP_ERR_ARG;
   if (bstats1 && (!mean1 || !invstd1 || !g1)) return AVSEP_ERR_ARG;
   if (!head_applicable(d)) return AVSEP_ERR_ARG;   // unsupported geometry: use avsep_conv2d_dgrad + avsep_relu_up2x_bwd
-  return head_dgrad(d, w, dy, g0, g1, mean1, invstd1, bstats1, acc0, (hipStream_t)stream);
+  if (!workspace || workspace_bytes < head_dgrad_workspace_floats(d) * sizeof(float)) return AVSEP_ERR_WORKSPACE;
+  return head_dgrad(d, w, dy, g0, g1, mean1, invstd1, bstats1, acc0, (float*)workspace, (hipStream_t)stream);
 }

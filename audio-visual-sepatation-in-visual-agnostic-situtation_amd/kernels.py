@@ -148,8 +148,9 @@ class Conv:
         x0, x1 = self.keep[0], self.keep[1]
         g0 = g0_acc if g0_acc is not None else torch.empty_like(x0)
         g1 = torch.empty_like(x1) if x1 is not None else None
+        ws, nbytes = self._ws("avsep_conv2d_dgrad_up2x_workspace_bytes")
         call("avsep_conv2d_dgrad_up2x", self.ref, ptr(w), ptr(dy), ptr(g0), ptr(g1), ptr(mean1), ptr(invstd1),
-             ptr(bstats1), int(g0_acc is not None))
+             ptr(bstats1), int(g0_acc is not None), ptr(ws), nbytes)
         return g0, g1
 
     def wgrad(self, dy, want_bias=False, out=None, out_bias=None):

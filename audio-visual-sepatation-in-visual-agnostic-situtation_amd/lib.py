@@ -55,7 +55,8 @@ SIGNATURES = {
     "avsep_maxpool_bn_relu_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_attmodel_infer_fwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "avsep_attmodel_infer_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "avsep_conv2d_dgrad_up2x": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "avsep_conv2d_dgrad_up2x_workspace_bytes": (_Z, [_CD]),
+    "avsep_conv2d_dgrad_up2x": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "avsep_conv2d_wgrad_workspace_bytes": (_Z, [_CD]),
     "avsep_conv2d_wgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
     "avsep_channel_stats": (C.c_int, [_P, _I, _I, _I, _P, _P]),

@@ -104,11 +104,13 @@ int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, flo
                        void* workspace, size_t workspace_bytes, avsep_stream_t stream);
 
 /* Fused decoder head (audio_net.py:72-76, the outermost up path: ReLU -> Upsample x2 -> Conv3x3 -> num_mix logits).
- * When avsep_conv2d_head_applicable(d) is 1 (up2x=1, 3x3/s1/p1, Cout <= 4, ReLU on both sources, W <= 256),
- * avsep_conv2d_fwd / _wgrad rebuild the 128-channel hi-res input in registers instead of reading a materialised
- * copy, and avsep_conv2d_dgrad_up2x takes the gradient straight to the two low-res sources: the same results as
- * avsep_conv2d_dgrad followed by avsep_relu_up2x_bwd (g0 [N,C0,H/2,W/2] accumulated in place when acc0, g1
- * [N,C1,H/2,W/2], bstats1[2*C1] += BatchNorm-backward sums of source 1).  w is OIHW. */
+ * When avsep_conv2d_head_applicable(d) is 1 (up2x=1, 3x3/s1/p1, Cout <= 4, ReLU on both sources, both channel counts
+ * multiples of 8, Cin <= 256), avsep_conv2d_fwd / _wgrad contract the channels at LOW resolution (interpolation and
+ * channel mix commute) instead of reading a materialised hi-res copy, and avsep_conv2d_dgrad_up2x takes the gradient
+ * straight to the two low-res sources: the same results as avsep_conv2d_dgrad followed by avsep_relu_up2x_bwd
+ * (g0 [N,C0,H/2,W/2] accumulated in place when acc0, g1 [N,C1,H/2,W/2], bstats1[2*C1] += BatchNorm-backward sums of
+ * source 1).  w is OIHW.  All three need their workspace (9*Cout low-res planes per image). */
+size_t avsep_conv2d_dgrad_up2x_workspace_bytes(const avsep_conv_desc* d);
 int32_t avsep_conv2d_head_applicable(const avsep_conv_desc* d);
 /* Name of the kernel family avsep_conv2d_fwd (mode 0, `with_stats` as it will be called), _dgrad (mode 1) or _wgrad
  * (mode 2) dispatches this descriptor to ("convbf_kernel", "wgradbf_kernel", "conv3x3_kernel", "wgrad3x3_kernel",
@@ -122,7 +124,7 @@ const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t mode, int32
 int avsep_conv_kernel_variant(const avsep_conv_desc* d, int32_t mode, int32_t with_stats, char* buf, size_t cap);
 int avsep_conv2d_dgrad_up2x(const avsep_conv_desc* d, const float* w, const float* dy, float* g0,
                             float* g1, const float* mean1, const float* invstd1, double* bstats1,
-                            int32_t acc0, avsep_stream_t stream);
+                            int32_t acc0, void* workspace, size_t workspace_bytes, avsep_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * SoP++ attention module core (SoP++/attention_net.py:24-58: `att` + `av_infer_forward`, shared by AttModel / MatchAtt):
