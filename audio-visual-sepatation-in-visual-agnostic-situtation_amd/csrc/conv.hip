@@ -477,25 +477,44 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // thread (e, q) sums slabs z = q, q + 4, ... with four independent loads in flight, the four partials are added in a fixed
 // order through LDS (deterministic).  The one-thread-per-element form walked its S slabs as one dependent chain: 0.15 TB/s
 // on a [256 x 1152] gradient with 32 slabs.
+// E elements x G = 256 / E slab groups per block: 64 x 4 for large gradients; 16 x 16 when n is small and S large (the decoder
+// head's [2 x 128 x 9] gradient has 512 slabs: 36 blocks of the 64-element form left 220 CUs idle, 106 us).
+template <int E>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n,
                                                            int S, long long stride) {
-  __shared__ float part[4][64];
-  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const long long i = (long long)blockIdx.x * 64 + e;
+  constexpr int G = 256 / E;
+  __shared__ float part[G][E];
+  const int e = threadIdx.x % E, q = threadIdx.x / E;
+  const long long i = (long long)blockIdx.x * E + e;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
     int z = q;
-    for (; z + 12 < S; z += 16) {
+    for (; z + 3 * G < S; z += 4 * G) {
       s0 += ws[(long long)z * stride + i];
-      s1 += ws[(long long)(z + 4) * stride + i];
-      s2 += ws[(long long)(z + 8) * stride + i];
-      s3 += ws[(long long)(z + 12) * stride + i];
+      s1 += ws[(long long)(z + G) * stride + i];
+      s2 += ws[(long long)(z + 2 * G) * stride + i];
+      s3 += ws[(long long)(z + 3 * G) * stride + i];
     }
-    for (; z < S; z += 4) s0 += ws[(long long)z * stride + i];
+    for (; z < S; z += G) s0 += ws[(long long)z * stride + i];
   }
   part[q][e] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (q == 0 && i < n) out[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+  if (q == 0 && i < n) {
+    float v[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = part[g][e];
+#pragma unroll
+    for (int w = G / 2; w > 0; w >>= 1)        // fixed pairwise order: deterministic
+#pragma unroll
+      for (int g = 0; g < w; ++g) v[g] = v[2 * g] + v[2 * g + 1];
+    out[i] = v[0];
+  }
+}
+static int launch_reduce_slabs(const float* ws, float* out, long long n, int S, long long stride, hipStream_t st) {
+  if (n <= 16384 && S >= 64) hipLaunchKernelGGL(reduce_slabs_kernel<16>, dim3(cdiv(n, 16)), dim3(256), 0, st, ws, out, n, S, stride);
+  else hipLaunchKernelGGL(reduce_slabs_kernel<64>, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, out, n, S, stride);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
 }
 
 // split-K forward combine: y = sum of slabs (+ bias); per-channel (sum, sumsq) for the following BatchNorm.
@@ -752,15 +771,9 @@ int splitk_combine(const float* ws, long long slab, int S, const avsep_conv_desc
   return AVSEP_OK;
 }
 int reduce_slabs_strided(const float* ws, float* out, long long n, int S, long long stride, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, out, n, S, stride);
-  AVSEP_LAUNCH_CHECK();
-  return AVSEP_OK;
+  return launch_reduce_slabs(ws, out, n, S, stride, st);
 }
-int reduce_slabs(const float* ws, float* out, long long n, int S, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, out, n, S, n);
-  AVSEP_LAUNCH_CHECK();
-  return AVSEP_OK;
-}
+int reduce_slabs(const float* ws, float* out, long long n, int S, hipStream_t st) { return launch_reduce_slabs(ws, out, n, S, n, st); }
 
 static size_t fwd_workspace_no_head(const avsep_conv_desc* d) {
   if (!check_desc(d, true) && bf_applicable(d, 0)) return bf_workspace_bytes(d, 0);
@@ -872,7 +885,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   }
   AVSEP_LAUNCH_CHECK();
   if (sp.splits > 1) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(a.slab, 64)), dim3(256), 0, st, (const float*)workspace, dx, a.slab,
+    hipLaunchKernelGGL(reduce_slabs_kernel<64>, dim3(cdiv(a.slab, 64)), dim3(256), 0, st, (const float*)workspace, dx, a.slab,
                        sp.splits, a.slab);
     AVSEP_LAUNCH_CHECK();
   }
@@ -961,7 +974,7 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   AVSEP_LAUNCH_CHECK();
   if (p.splits > 1) {
     long long n = (long long)a.M * a.Ncols;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n, p.splits, n);
+    hipLaunchKernelGGL(reduce_slabs_kernel<64>, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n, p.splits, n);
     AVSEP_LAUNCH_CHECK();
   }
   if (dbias) {

@@ -38,6 +38,10 @@ __device__ __forceinline__ float head_coef(int o, int i, int L, float r) {
   return (q.i0 == i ? 1.f - q.l : 0.f) + (q.i1 == i ? q.l : 0.f);
 }
 
+__device__ __forceinline__ float lane_value(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward, step 1: T[n][k][P] = sum_c w[co][c][tap] * relu(affine(x[n][c][P]))       (k = co*9 + tap)
 // GEMM per image: M = k (one or two 32-row tiles), N = pixels (a wave owns 64: two 32-column tiles), K = channels.
@@ -45,17 +49,18 @@ __device__ __forceinline__ float head_coef(int o, int i, int L, float r) {
 // B[k = h][n = i], so a B operand is a single dword load of channel 2s+h at pixel P0+i (two 128-byte runs per wave) and
 // the A operands (the weights, constant for the kernel) sit in LDS in lane order.
 // ---------------------------------------------------------------------------------------------------------------
-// GENERIC: channel counts that are not multiples of 8 (tests; a pair of channels may straddle the sources, the last step may
+// GENERIC: source channel counts that are not multiples of 8 or a total that is not a multiple of 16 (tests; a pair of channels may straddle the sources, the last step may
 // be half empty): per-lane plane pointers instead of one wave-uniform base.
 template <int MT, bool GENERIC>
 __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(HeadArgs a, const float* __restrict__ wp, int wp_ld, int KT,
-                                                            float* __restrict__ T, int tpw) {
-  extern __shared__ float sm[];            // [MT][KS][64] weights | [KS][64] scale | [KS][64] shift, KS = channel pairs (x4)
-  const int C = a.C0 + a.C1, KS = (C + 7) / 8 * 4;
+                                                            float* __restrict__ T) {
+  extern __shared__ float sm[];            // [MT][KS][64] weights in lane order | [2*KS] scale | [2*KS] shift; KS = channel pairs (x8)
+  const int C = a.C0 + a.C1, KS = (C + 15) / 16 * 8;
   float* sw = sm;
   float* ssc = sm + MT * KS * 64;
-  float* ssh = ssc + KS * 64;
+  float* ssh = ssc + 2 * KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+#pragma unroll 4
   for (int e = tid; e < KS * 64; e += 256) {
     const int s = e >> 6, l = e & 63, cr = 2 * s + (l >> 5), c = min(cr, C - 1);
 #pragma unroll
@@ -63,25 +68,29 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(HeadArgs a, const fl
       const int k = mt * 32 + (l & 31);
       sw[(mt * KS + s) * 64 + l] = (k < KT && cr < C) ? wp[(long long)(c * 9 + k % 9) * wp_ld + k / 9] : 0.f;
     }
+  }
+  for (int cr = tid; cr < 2 * KS; cr += 256) {
+    const int c = min(cr, C - 1);
     const bool first = c < a.C0;
     const float* sc = first ? a.sc0 : a.sc1;
     const float* sh = first ? a.sh0 : a.sh1;
     const int cs = first ? c : c - a.C0;
-    ssc[e] = sc ? sc[cs] : 1.f;
-    ssh[e] = sc ? sh[cs] : 0.f;
+    ssc[cr] = sc ? sc[cs] : 1.f;
+    ssh[cr] = sc ? sh[cs] : 0.f;
   }
   __syncthreads();
   const long long HWl = (long long)a.Hl * a.Wl;
-  const int n = blockIdx.y;
   const int KS0 = a.C0 / 2;
-  const float* x0n = a.x0 + (long long)n * a.C0 * HWl;
-  const float* x1n = a.x1 ? a.x1 + (long long)n * a.C1 * HWl : a.x0;
-  const float* b0 = x0n + lh * HWl;
-  const float* b1 = x1n + lh * HWl;
-  float* Tn = T + (long long)n * KT * HWl;
-  for (int it = 0; it < tpw; ++it) {       // a block sweeps 4 * tpw tiles of 64 pixels with one copy of the weights
-    const long long P0 = (((long long)blockIdx.x * tpw + it) * 4 + wave) * 64;
-    if (P0 >= HWl) break;
+  const long long tpi = (HWl + 63) / 64, total = tpi * a.N;        // 64-pixel tiles per image / in all
+  // persistent: the grid is one round of resident blocks, every wave strides over the (image, tile) list
+  for (long long t = (long long)blockIdx.x * 4 + wave; t < total; t += (long long)gridDim.x * 4) {
+    const int n = (int)(t / tpi);
+    const long long P0 = (t - (long long)n * tpi) * 64;
+    const float* x0n = a.x0 + (long long)n * a.C0 * HWl;
+    const float* x1n = a.x1 ? a.x1 + (long long)n * a.C1 * HWl : a.x0;
+    const float* b0 = x0n + lh * HWl;
+    const float* b1 = x1n + lh * HWl;
+    float* Tn = T + (long long)n * KT * HWl;
     // two pixels per lane (tiles P0.. and P0+32..); a pixel past the plane re-reads the last one and is never stored
     const long long pa = min(P0 + li, HWl - 1), pb = min(P0 + 32 + li, HWl - 1);
     f32x16 acc[MT][2];
@@ -92,8 +101,8 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(HeadArgs a, const fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
     constexpr int U = 4;
-    for (int s0 = 0; s0 < KS; s0 += U) {
-      float va[U], vb[U];
+    // the loads of trip s0 + U are issued before trip s0's MFMAs (a trip's 8 MFMAs are 512 cycles, a loaded round trip more)
+    auto fetch = [&](int s0, float (&va)[U], float (&vb)[U]) __attribute__((always_inline)) {
       if constexpr (!GENERIC) {            // C0, C1 multiples of 8: the four pairs of a trip sit in one source
         const float* base = s0 < KS0 ? b0 + (long long)(2 * s0) * HWl : b1 + (long long)(2 * (s0 - KS0)) * HWl;
 #pragma unroll
@@ -110,9 +119,11 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(HeadArgs a, const fl
           vb[u] = plane[pb];
         }
       }
+    };
+    auto trip = [&](int s0, const float (&va)[U], const float (&vb)[U]) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float scv = ssc[(s0 + u) * 64 + lane], shv = ssh[(s0 + u) * 64 + lane];
+        const float scv = ssc[2 * (s0 + u) + lh], shv = ssh[2 * (s0 + u) + lh];
         const float ra = fmaxf(fmaf(va[u], scv, shv), 0.f), rb = fmaxf(fmaf(vb[u], scv, shv), 0.f);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -121,6 +132,20 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(HeadArgs a, const fl
           acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, rb, acc[mt][1], 0, 0, 0);
         }
       }
+    };
+    // two register sets, two trips per iteration (KS is a multiple of 8); the scheduling barriers keep each fetch ABOVE the
+    // MFMAs it is meant to overlap (left alone the compiler sinks the loads to the bottom of the loop body)
+    float xa[U], xb[U], ya[U], yb[U];
+    fetch(0, xa, xb);
+    for (int s0 = 0; s0 < KS; s0 += 2 * U) {
+      fetch(s0 + U, ya, yb);
+      __builtin_amdgcn_sched_barrier(0);
+      trip(s0, xa, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(min(s0 + 2 * U, KS - U), xa, xb);                         // the last iteration re-reads its own second trip
+      __builtin_amdgcn_sched_barrier(0);
+      trip(s0 + U, ya, yb);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // D[m = k][n = pixel]: lane column = pixel, register r = row (r & 3) + 8 * (r >> 2) + 4 * lh
 #pragma unroll
@@ -144,32 +169,41 @@ __global__ __launch_bounds__(256) void head_fwd_lerp_kernel(HeadArgs a, const fl
   const int w = blockIdx.x * 64 + (threadIdx.x & 63), h = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;
   if (w >= W || h >= H) return;
   const long long HWl = (long long)a.Hl * a.Wl;
+  // per axis and tap offset: the two low-res indices and their weights, ZERO for a tap outside the hi-res map (the conv's
+  // padding) — no branches, so that all 36 loads of an output channel are in flight together (the branchy form waited for
+  // each tap's four loads in turn: 132 us for 108 MB of traffic)
   int r0[3], r1[3], c0[3], c1[3];
-  float lr[3], lc[3];
-  bool inr[3], inc[3];
+  float ur0[3], ur1[3], uc0[3], uc1[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int ho = h + d - 1, wo = w + d - 1;
-    inr[d] = ho >= 0 && ho < H;
-    inc[d] = wo >= 0 && wo < W;
-    const HLerp qr = head_lerp(inr[d] ? ho : 0, a.Hl, a.rh), qc = head_lerp(inc[d] ? wo : 0, a.Wl, a.rw);
-    r0[d] = qr.i0 * a.Wl; r1[d] = qr.i1 * a.Wl; lr[d] = qr.l;
-    c0[d] = qc.i0; c1[d] = qc.i1; lc[d] = qc.l;
+    const bool inr = ho >= 0 && ho < H, inc = wo >= 0 && wo < W;
+    const HLerp qr = head_lerp(inr ? ho : 0, a.Hl, a.rh), qc = head_lerp(inc ? wo : 0, a.Wl, a.rw);
+    r0[d] = qr.i0 * a.Wl; r1[d] = qr.i1 * a.Wl;
+    c0[d] = qc.i0; c1[d] = qc.i1;
+    ur0[d] = inr ? 1.f - qr.l : 0.f; ur1[d] = inr ? qr.l : 0.f;
+    uc0[d] = inc ? 1.f - qc.l : 0.f; uc1[d] = inc ? qc.l : 0.f;
   }
   const float* Tn = T + (long long)n * (9 * COUT) * HWl;
 #pragma unroll
   for (int co = 0; co < COUT; ++co) {
+    float t[9][4];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float* tp = Tn + (long long)(co * 9 + kh * 3 + kw) * HWl;
+        t[kh * 3 + kw][0] = tp[r0[kh] + c0[kw]]; t[kh * 3 + kw][1] = tp[r0[kh] + c1[kw]];
+        t[kh * 3 + kw][2] = tp[r1[kh] + c0[kw]]; t[kh * 3 + kw][3] = tp[r1[kh] + c1[kw]];
+      }
     float acc = bias ? bias[co] : 0.f;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        if (inr[kh] && inc[kw]) {
-          const float* t = Tn + (long long)(co * 9 + kh * 3 + kw) * HWl;
-          const float t00 = t[r0[kh] + c0[kw]], t01 = t[r0[kh] + c1[kw]], t10 = t[r1[kh] + c0[kw]], t11 = t[r1[kh] + c1[kw]];
-          const float top = (1.f - lc[kw]) * t00 + lc[kw] * t01, bot = (1.f - lc[kw]) * t10 + lc[kw] * t11;
-          acc += (1.f - lr[kh]) * top + lr[kh] * bot;
-        }
+        const float top = uc0[kw] * t[kh * 3 + kw][0] + uc1[kw] * t[kh * 3 + kw][1];
+        const float bot = uc0[kw] * t[kh * 3 + kw][2] + uc1[kw] * t[kh * 3 + kw][3];
+        acc += ur0[kh] * top + ur1[kh] * bot;
       }
     y[(((long long)n * COUT + co) * H + h) * W + w] = acc;
   }
@@ -243,8 +277,8 @@ __global__ __launch_bounds__(256) void head_adj_kernel(HeadArgs a, int COUT, con
 // ---------------------------------------------------------------------------------------------------------------
 // data gradient to the low-res sources: g[c][P] = relu'(affine(x[c][P])) * sum_k w[k][c] * S[k][P]  (+ g0 when acc0);
 // source-1 channels also reduce the BatchNorm-backward sums (sum g, sum g * xhat).  Pure streaming over flat pixels: a lane
-// holds the KT values of S for its two pixels, the channel loop runs with wave-uniform weights (scalar loads), x of the
-// next channel is in flight while this channel's FMAs run.  blockIdx.z = source; a block sweeps `tpb` pixel tiles of 128
+// holds the KT values of S for its four pixels, the channel loop runs with wave-uniform weights (scalar loads), x of the
+// next channels is in flight while this channel's FMAs run.  blockIdx.z = source; a block sweeps `tpb` pixel tiles of 256
 // and adds its statistics to the global sums once.
 // ---------------------------------------------------------------------------------------------------------------
 template <int COUT>
@@ -271,48 +305,54 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(HeadArgs a, const float
   const float* sh = src ? a.sh1 : a.sh0;
   const float* Sn = S + (long long)n * KT * HWl;
   const bool accum = acc0 && !src;
-  const long long tiles = (HWl + 127) / 128;
+  const long long tiles = (HWl + 255) / 256;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   for (int it = wave; it < tpb; it += 4) {
     const long long tile = (long long)blockIdx.x * tpb + it;
     if (tile >= tiles) break;                           // wave-uniform
-    const long long P = tile * 128 + 2 * lane;
-    const bool ok = P < HWl;                            // HWl is even: a pair is all-in or all-out
+    const long long P = tile * 256 + 4 * lane;
+    const bool ok = P < HWl;                            // HWl % 4 == 0: a quad is all-in or all-out
     const long long Pc = ok ? P : 0;
-    float2 sv[KT];
+    f32x4 sv[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-      sv[k] = *reinterpret_cast<const float2*>(Sn + (long long)k * HWl + Pc);
-      if (!ok) sv[k] = make_float2(0.f, 0.f);
+      sv[k] = *reinterpret_cast<const f32x4*>(Sn + (long long)k * HWl + Pc);
+      if (!ok) sv[k] = z4;
     }
-    float2 xn = *reinterpret_cast<const float2*>(xs + Pc);
+    // x of channels c+1 and c+2 is in flight while channel c's FMAs run (one 1 KB load per wave and channel)
+    f32x4 xq0 = *reinterpret_cast<const f32x4*>(xs + Pc);
+    f32x4 xq1 = *reinterpret_cast<const f32x4*>(xs + (long long)min(1, Cs - 1) * HWl + Pc);
     for (int c = 0; c < Cs; ++c) {
-      const float2 xv = xn;
-      xn = *reinterpret_cast<const float2*>(xs + (long long)min(c + 1, Cs - 1) * HWl + Pc);
-      float2 old = make_float2(0.f, 0.f);
-      if (accum) old = *reinterpret_cast<const float2*>(gs + (long long)c * HWl + Pc);
+      const f32x4 xv = xq0;
+      xq0 = xq1;
+      xq1 = *reinterpret_cast<const f32x4*>(xs + (long long)min(c + 2, Cs - 1) * HWl + Pc);
+      f32x4 old = z4;
+      if (accum) old = *reinterpret_cast<const f32x4*>(gs + (long long)c * HWl + Pc);
       const float* wc = w + (long long)(cofs + c) * 9;
-      float gx = 0.f, gy = 0.f;
+      f32x4 gv = z4;
 #pragma unroll
       for (int co = 0; co < COUT; ++co)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const float wv = wc[(long long)co * C * 9 + t];
-          gx = fmaf(wv, sv[co * 9 + t].x, gx);
-          gy = fmaf(wv, sv[co * 9 + t].y, gy);
+          gv += wv * sv[co * 9 + t];
         }
       const float scv = sc ? sc[c] : 1.f, shv = sc ? sh[c] : 0.f;
-      gx = fmaf(xv.x, scv, shv) > 0.f ? gx : 0.f;
-      gy = fmaf(xv.y, scv, shv) > 0.f ? gy : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[e] = fmaf(xv[e], scv, shv) > 0.f ? gv[e] : 0.f;
       if (stats) {
         const float mu = mean1[c], is = invstd1[c];
-        const float s1 = wave_sum(gx + gy);
-        const float s2 = wave_sum(gx * (xv.x - mu) * is + gy * (xv.y - mu) * is);
+        // 32-lane sums on the DPP path, valid in lanes 31 and 63 (common.h); the two halves meet in scalar registers
+        const float h1 = half_sum_hi((gv[0] + gv[1]) + (gv[2] + gv[3]));
+        const float h2 = half_sum_hi((gv[0] * (xv[0] - mu) + gv[1] * (xv[1] - mu)) + (gv[2] * (xv[2] - mu) + gv[3] * (xv[3] - mu)));
+        const float s1 = lane_value(h1, 31) + lane_value(h1, 63);
+        const float s2 = (lane_value(h2, 31) + lane_value(h2, 63)) * is;
         if (lane == 0) {
           atomicAdd(&sstat[c], (double)s1);
           atomicAdd(&sstat[a.C1 + c], (double)s2);
         }
       }
-      if (ok) *reinterpret_cast<float2*>(gs + (long long)c * HWl + P) = make_float2(gx + old.x, gy + old.y);
+      if (ok) *reinterpret_cast<f32x4*>(gs + (long long)c * HWl + P) = gv + old;
     }
   }
   if (stats) {
@@ -358,38 +398,43 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(HeadArgs a, int KT, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  auto load_a = [&](long long p) __attribute__((always_inline)) {
-    return (cok && p < p_end) ? *reinterpret_cast<const f32x4*>(xrow + p) : z4;       // HWl % 4 == 0: a quad is all-in or all-out
+  // a trip is 32 pixels: lane half h takes pixels 16h .. 16h+15 of its row as four float4 (64 contiguous bytes: a row's
+  // 128-byte line is consumed within the trip, nothing has to survive in L1 between trips); component j of quad q is
+  // k-step 4q + j.  Out-of-range quads load as zeros on the S side, which zeroes the product (relu(affine(0)) is not 0).
+  constexpr int Q = 4;
+  auto load_a = [&](long long p, f32x4 (&v)[Q]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = (cok && p + 4 * q < p_end) ? *reinterpret_cast<const f32x4*>(xrow + p + 4 * q) : z4;
   };
-  auto load_b = [&](int t, long long p) __attribute__((always_inline)) {
-    return (kok[t] && p < p_end) ? *reinterpret_cast<const f32x4*>(srow[t] + p) : z4;
+  auto load_b = [&](int t, long long p, f32x4 (&v)[Q]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = (kok[t] && p + 4 * q < p_end) ? *reinterpret_cast<const f32x4*>(srow[t] + p + 4 * q) : z4;
   };
-  // two 8-pixel steps per trip; the loads of the next trip are issued before this trip's MFMAs
-  long long p = p_beg + 4 * lh;
-  f32x4 xa0 = load_a(p), xa1 = load_a(p + 8);
-  f32x4 sb0[NT], sb1[NT];
+  long long p = p_beg + 16 * lh;
+  f32x4 na[Q], nb[NT][Q];
+  load_a(p, na);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { sb0[t] = load_b(t, p); sb1[t] = load_b(t, p + 8); }
-  for (long long q = p_beg; q < p_end; q += 16) {
-    const f32x4 ca0 = xa0, ca1 = xa1;
-    f32x4 cb0[NT], cb1[NT];
+  for (int t = 0; t < NT; ++t) load_b(t, p, nb[t]);
+  for (long long q0 = p_beg; q0 < p_end; q0 += 32) {
+    f32x4 ca[Q], cb[NT][Q];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { cb0[t] = sb0[t]; cb1[t] = sb1[t]; }
-    p += 16;
-    xa0 = load_a(p); xa1 = load_a(p + 8);
+    for (int q = 0; q < Q; ++q) {
+      ca[q] = na[q];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { sb0[t] = load_b(t, p); sb1[t] = load_b(t, p + 8); }
-    // an out-of-range quad was loaded as zeros on the x side: relu(affine(0)) is not 0, so the mask is re-applied on B
-    // (kok / p < p_end zero the S side, which zeroes the product)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float r0 = fmaxf(fmaf(ca0[j], scv, shv), 0.f), r1 = fmaxf(fmaf(ca1[j], scv, shv), 0.f);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, cb0[t][j], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1, cb1[t][j], acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < NT; ++t) cb[t][q] = nb[t][q];
     }
+    p += 32;
+    load_a(p, na);                                       // the next trip's loads fly during this trip's 16 * NT MFMAs
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load_b(t, p, nb[t]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float r = fmaxf(fmaf(ca[q][j], scv, shv), 0.f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(r, cb[t][q][j], acc[t], 0, 0, 0);
+      }
   }
   // D[m = channel][n = k]: lane column = k, register r = channel (r & 3) + 8 * (r >> 2) + 4 * lh
   float* slab = part + ((long long)n * SEG + seg) * KT * C;
@@ -436,11 +481,17 @@ size_t head_dgrad_workspace_floats(const avsep_conv_desc* d) { return head_plane
 int head_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* bias, float* y, float* ws, hipStream_t st) {
   HeadArgs a = head_args(d);
   const long long HWl = (long long)a.Hl * a.Wl;
-  const int KT = 9 * d->Cout, MT = (KT + 31) / 32, KS = (d->Cin + 7) / 8 * 4;
-  const bool generic = (a.C0 & 7) || (a.C1 & 7);
-  const int tpw = HWl >= 4096 ? 4 : 1;
-  dim3 g1(cdiv(HWl, 256 * tpw), d->N);
-  const size_t lds = (size_t)(MT + 2) * KS * 64 * sizeof(float);            // <= 128 KB at Cin = 256, two row tiles
+  const int KT = 9 * d->Cout, MT = (KT + 31) / 32, KS = (d->Cin + 15) / 16 * 8;
+  const bool generic = (a.C0 & 7) || (a.C1 & 7) || (d->Cin & 15);
+  const long long total = (HWl + 63) / 64 * d->N;                            // 64-pixel wave tiles
+  const size_t lds = ((size_t)MT * KS * 64 + 4 * KS) * sizeof(float);       // <= 133 KB at Cin = 256, two row tiles
+  // one round of resident blocks (4 per CU by registers at 16 KB of LDS, fewer when the weights take more)
+  int per_cu = (int)(160 * 1024 / (lds + 1024));
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  long long nb = (long long)cu_count() * per_cu;
+  if (nb > (total + 3) / 4) nb = (total + 3) / 4;
+  dim3 g1((unsigned)nb);
   static bool once = false;
   if (!once) {
     const void* fs[4] = {(const void*)head_fwd_gemm_kernel<1, false>, (const void*)head_fwd_gemm_kernel<2, false>,
@@ -449,7 +500,7 @@ int head_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* 
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return AVSEP_ERR_LAUNCH;
     once = true;
   }
-#define HEAD_FG(MT_, G_) hipLaunchKernelGGL((head_fwd_gemm_kernel<MT_, G_>), g1, dim3(256), lds, st, a, wp, wp_ld, KT, ws, tpw)
+#define HEAD_FG(MT_, G_) hipLaunchKernelGGL((head_fwd_gemm_kernel<MT_, G_>), g1, dim3(256), lds, st, a, wp, wp_ld, KT, ws)
   if (MT == 1) { if (generic) HEAD_FG(1, true); else HEAD_FG(1, false); }
   else { if (generic) HEAD_FG(2, true); else HEAD_FG(2, false); }
 #undef HEAD_FG
@@ -510,8 +561,8 @@ int head_dgrad(const avsep_conv_desc* d, const float* w, const float* dy, float*
   const long long HWl = (long long)a.Hl * a.Wl;
   int rc = head_adjoint(d, a, dy, ws, nullptr, st);
   if (rc) return rc;
-  const long long tiles = (HWl + 127) / 128;
-  const int tpb = tiles >= 64 ? 16 : 4;
+  const long long tiles = (HWl + 255) / 256;          // a wave streams 256 pixels (one float4 per lane) per tile
+  const int tpb = tiles >= 32 ? 8 : 4;
   dim3 grid(cdiv(tiles, tpb), d->N, 2);
   const size_t lds = bstats1 ? (size_t)2 * a.C1 * sizeof(double) : 0;
 #define HEAD_DG(CO_) hipLaunchKernelGGL(head_dgrad_kernel<CO_>, grid, dim3(256), lds, st, a, w, (const float*)ws, g0, g1, mean1, invstd1, bstats1, acc0, tpb)
