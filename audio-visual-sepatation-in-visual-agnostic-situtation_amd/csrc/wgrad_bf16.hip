@@ -31,26 +31,49 @@ struct WBArgs {
   int tilesX, tilesY, gridM, gridC, tiles_per_split;
 };
 
-constexpr int WB_BM = 128, WB_BC = 32;
+constexpr int WB_BC = 32;
 
 // RAW: the input needs no affine / activation (the U-Net decoder's materialised ReLU+upsample tensor): these kernels
 // are VALU-bound in their staging (SQ counters: 15-19 VALU per MFMA before this), so that work is compiled out.
-template <int TH, int TW, int DIL, bool A2, bool RAW = false>
+// HALF (Cout <= 64): the tile holds 64 output channels and the four waves are 2 channel blocks x 2 halves of the tile's rows
+// (each half writes its own slab) instead of two waves multiplying zero rows: 256 -> 64 @ 128x128 ran at 330 TFLOP/s
+// against 580 for the same work at 512 -> 128 @ 64x64.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned WB_OOB = 0x80000000u;     // a byte offset no buffer covers: the load returns zeros
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wb_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fff0000, 0x00020000);   // offsets derived from WB_OOB (-8 .. +32) stay outside
+}
+__device__ __forceinline__ f32x4 wb_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ float2 wb_ld2(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  const f32x2v v = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float wb_ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+
+template <int TH, int TW, int DIL, bool A2, bool RAW, bool HALF>
 __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
-  constexpr int NT = 256;
+  constexpr int NT = 256, WB_BM = HALF ? 64 : 128, RH = HALF ? TH / 2 : TH;
+  static_assert(!HALF || TH % 2 == 0, "row halves");
   constexpr int NPIX = TH * TW, PH = TH + 2 * DIL;
   constexpr int A_ROW = NPIX * 2 + 16;                                  // bytes per co row: 16 x odd
-  constexpr int ROW_EL = TW + 16, ROWB = ROW_EL * 2;                    // patch row: 8 | TW | 8 elements
-  constexpr int CH_RAW = PH * ROWB;
+  constexpr int COPYB = TW * 2, RSB = 3 * COPYB;                        // patch row: X | X shifted by -DIL | X shifted by +DIL
+  constexpr int CH_RAW = PH * RSB;
   constexpr int CH = (CH_RAW / 16) % 2 == 1 ? CH_RAW : CH_RAW + 16;     // bytes per ci: 16 x odd (lanes = ci)
   constexpr int A_BYTES = WB_BM * A_ROW, B_BYTES = WB_BC * CH;
-  constexpr int AQ = WB_BM * NPIX / 4, AE = AQ / NT;                    // dY quads per thread
-  constexpr int NG = TW / 8 + 2, BU = WB_BC * PH * NG, BE = (BU + NT - 1) / NT;   // 8-element groups of the patch
-  static_assert(AQ % NT == 0 && TW % 16 == 0, "tile shape");
+  constexpr int CO_PER = NPIX / 4, COSTEP = NT / CO_PER, AE = WB_BM / COSTEP;   // dY quads: a thread keeps its (row, quad), e steps co
+  constexpr int NG = TW / 8, BU = WB_BC * PH * NG, BE = (BU + NT - 1) / NT;     // 8-element groups of the patch
+  static_assert(NT % CO_PER == 0 && WB_BM % COSTEP == 0 && TW % 16 == 0, "tile shape");
+  static_assert(2 * (A_BYTES + B_BYTES) <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
-  const int wr = wave, wc = 0;
+  const int wr = HALF ? (wave & 1) : wave, wc = 0, hf = HALF ? (wave >> 1) : 0;
   const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
   const int m0 = mt * WB_BM, c0 = ct * WB_BC;
   const int tiles_img = a.tilesX * a.tilesY, tiles_all = tiles_img * a.N;
@@ -65,82 +88,95 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // ---- staging state (decoded once; per tile only (n, h0, w0) change) ------------------------------------------------
-  // dY quad e: (co, tile row, column quad) -> packed word: LDS byte offset (bits 0-16) | row (17-20) | col (21-26) | co ok (31)
-  int a_goff[AE];
-  unsigned a_pk[AE];
+  // ---- staging state ------------------------------------------------------------------------------------------------
+  // Loads are buffer loads relative to a per-tile base (dY: the tile's first pixel of channel m0; X: DIL rows above and 8
+  // columns left of it, channel c0), so a thread's byte offsets are constants and everything that must read as zero
+  // (rows / columns outside the image, channels past Cout / Cin) is ONE select of the offset against WB_OOB: no masks, no
+  // zero selects after the load (the masked form spent 10-15 vector instructions per MFMA on its staging).
+  const int tq = tid % (TW / 4), tr = (tid / (TW / 4)) % TH, tco = tid / CO_PER;
+  unsigned a_voff[AE];
 #pragma unroll
   for (int e = 0; e < AE; ++e) {
-    const int idx = tid + NT * e;
-    const int q = idx % (TW / 4), r = (idx / (TW / 4)) % TH, co = idx / (NPIX / 4);
-    a_goff[e] = min(m0 + co, a.Cout - 1) * (int)HW + r * a.W + 4 * q;                    // Cout*H*W < 2^31: host check
-    a_pk[e] = (unsigned)(co * A_ROW + (r * TW + 4 * q) * 2) | (unsigned)r << 17 | (unsigned)(4 * q) << 21 |
-              (m0 + co < a.Cout ? 0x80000000u : 0u);
+    const int co = tco + COSTEP * e;
+    a_voff[e] = m0 + co < a.Cout ? (unsigned)((co * (int)HW + tr * a.W + 4 * tq) * 4) : WB_OOB;   // WB_BM*H*W*4 < 2^31: host check
   }
-  // patch group e: (ci, patch row, group g) -> LDS byte offset | row | group | channel ok
-  int b_goff[BE];
-  unsigned b_pk[BE];
-  float b_sc[BE], b_sh[BE];
+  const int a_lds = tco * A_ROW + (tr * TW + 4 * tq) * 2;
+  unsigned b_voff[BE];
+  unsigned b_pk[BE];                 // LDS byte offset (bits 0-16) | patch row (17-20) | group (21-23)
+  float b_sc[RAW ? 1 : BE], b_sh[RAW ? 1 : BE];
 #pragma unroll
   for (int e = 0; e < BE; ++e) {
     const int idx = min(tid + NT * e, BU - 1);
     const int g = idx % NG, pr = (idx / NG) % PH, cc = idx / (NG * PH);
-    const bool chok = (BE * NT == BU || tid + NT * e < BU) && c0 + cc < a.Cin;
-    const int cs = min(c0 + cc, a.Cin - 1);
-    b_goff[e] = cs * (int)HW + (pr - DIL) * a.W + (8 * g - 8);                            // Cin*H*W < 2^31: host check
-    b_pk[e] = (unsigned)(cc * CH + pr * ROWB + g * 16) | (unsigned)pr << 17 | (unsigned)g << 21 | (chok ? 0x80000000u : 0u);
-    b_sc[e] = has_aff ? a.sc0[cs] : 1.f;
-    b_sh[e] = has_aff ? a.sh0[cs] : 0.f;
+    const bool uok = (BE * NT == BU || tid + NT * e < BU) && c0 + cc < a.Cin;
+    b_voff[e] = uok ? (unsigned)((cc * (int)HW + pr * a.W + 8 * g + 8) * 4) : WB_OOB;             // 32*H*W*4 < 2^31
+    b_pk[e] = (unsigned)(cc * CH + pr * RSB + g * 16) | (unsigned)pr << 17 | (unsigned)g << 21;
+    if constexpr (!RAW) {
+      const int cs = min(c0 + cc, a.Cin - 1);
+      b_sc[e] = has_aff ? a.sc0[cs] : 1.f;
+      b_sh[e] = has_aff ? a.sh0[cs] : 0.f;
+    }
   }
   f32x4 areg[AE];
-  f32x4 breg[BE][2];
-  unsigned amask = 0;
-  unsigned bmask[BE];              // per group: 8 element-valid bits
+  float bmain[BE][8], bl[BE][DIL], br[BE][DIL];
+  unsigned bmask[RAW ? 1 : BE];      // element-valid bits of a unit: main 0-7, left extras 8.., right extras 12..
 
   auto issue = [&](int t) __attribute__((always_inline)) {
     const int n = t / tiles_img, tt = t % tiles_img, h0 = (tt / a.tilesX) * TH, w0 = (tt % a.tilesX) * TW;
-    const float* dyb = a.dy + (long long)n * a.Cout * HW + (long long)h0 * a.W + w0;
-    const float* xb = a.x0 + (long long)n * a.Cin * HW + (long long)h0 * a.W + w0;
-    amask = 0;
+    const __amdgpu_buffer_rsrc_t ra = wb_rsrc(a.dy + ((long long)n * a.Cout + m0) * HW + (long long)h0 * a.W + w0);
+    const __amdgpu_buffer_rsrc_t rb = wb_rsrc(a.x0 + ((long long)n * a.Cin + c0) * HW + (long long)(h0 - DIL) * a.W + (w0 - 8));
+    // validity as an OR mask on the offset (bit 31 set = outside every buffer): plain integer arithmetic, because a
+    // `valid ? offset : WB_OOB` select in front of a load is turned into a branch around two copies of the load
+    auto oob = [](bool valid) __attribute__((always_inline)) {
+      unsigned m = valid ? 0u : WB_OOB;
+      asm volatile("" : "+v"(m));
+      return m;
+    };
+    {
+      const bool rok = h0 + tr < a.H;
+      const unsigned m1 = oob(rok && w0 + 4 * tq < a.W), m2 = oob(rok && w0 + 4 * tq + 2 < a.W);
 #pragma unroll
-    for (int e = 0; e < AE; ++e) {
-      unsigned pk = a_pk[e];
-      asm volatile("" : "+v"(pk));          // keep the decode inside the tile loop (see wgrad3x3_kernel)
-      const int ar = (pk >> 17) & 15, ac = (pk >> 21) & 63;
-      const bool ok = (pk >> 31) && h0 + ar < a.H && w0 + ac < a.W;
-      if constexpr (!A2) {
-        areg[e] = *reinterpret_cast<const f32x4*>(ok ? dyb + a_goff[e] : a.dy);
-      } else {                               // rows only 8-byte aligned (W % 4 == 2): two float2, the second may be past the row
-        const bool ok2 = ok && w0 + ac + 2 < a.W;
-        const float2 lo = *reinterpret_cast<const float2*>(ok ? dyb + a_goff[e] : a.dy);
-        const float2 hi = *reinterpret_cast<const float2*>(ok2 ? dyb + a_goff[e] + 2 : a.dy);
-        areg[e] = f32x4{lo.x, lo.y, ok2 ? hi.x : 0.f, ok2 ? hi.y : 0.f};
+      for (int e = 0; e < AE; ++e) {
+        if constexpr (!A2) {
+          areg[e] = wb_ld4(ra, a_voff[e] | m1);                      // W % 4 == 0: a quad is all-in or all-out
+        } else {                                                     // rows 8-byte aligned (W % 4 == 2): two pairs
+          const float2 lo = wb_ld2(ra, a_voff[e] | m1), hi = wb_ld2(ra, (a_voff[e] + 8) | m2);
+          areg[e] = f32x4{lo.x, lo.y, hi.x, hi.y};
+        }
       }
-      amask |= (unsigned)ok << e;
     }
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
       unsigned pk = b_pk[e];
-      asm volatile("" : "+v"(pk));
-      const int pr = (int)((pk >> 17) & 15) - DIL, gc = (int)((pk >> 21) & 15) * 8 - 8;   // row / first column rel. to the tile
-      const bool rok = (pk >> 31) && (unsigned)(h0 + pr) < (unsigned)a.H;
-      const int col = w0 + gc;
-      unsigned m = 0;                       // one bit per PAIR (bits 0, 2, 4, 6): W and col are even, a pair is all-in or all-out
-#pragma unroll
-      for (int p = 0; p < 4; ++p) m |= (unsigned)(rok && (unsigned)(col + 2 * p) < (unsigned)a.W) << (2 * p);
-      bmask[e] = m;
-      const float* src = xb + b_goff[e];
+      asm volatile("" : "+v"(pk));          // keep the decode inside the tile loop (cheaper than holding it in registers)
+      const int pr = (int)((pk >> 17) & 15), col = w0 + (int)((pk >> 21) & 7) * 8;          // first column of the group
+      const bool rok = (unsigned)(h0 + pr - DIL) < (unsigned)a.H;
+      const unsigned v0 = b_voff[e];
+      const bool mL = rok && col > 0 && col <= a.W, mR = rok && col + 8 < a.W;
+      unsigned m = 0;
       if constexpr (!A2) {
-        breg[e][0] = *reinterpret_cast<const f32x4*>((m & 0x01u) ? src : a.x0);           // quads are all-in or all-out (W % 4 == 0)
-        breg[e][1] = *reinterpret_cast<const f32x4*>((m & 0x10u) ? src + 4 : a.x0);
+        const bool q0 = rok && col < a.W, q1 = rok && col + 4 < a.W;
+        const f32x4 x0 = wb_ld4(rb, v0 | oob(q0)), x1 = wb_ld4(rb, (v0 + 16) | oob(q1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bmain[e][j] = x0[j]; bmain[e][4 + j] = x1[j]; }
+        m = (q0 ? 0x0fu : 0u) | (q1 ? 0xf0u : 0u);
       } else {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {        // pairs are all-in or all-out (W % 2 == 0)
-          const float2 v = *reinterpret_cast<const float2*>(((m >> (2 * p)) & 1u) ? src + 2 * p : a.x0);
-          breg[e][p >> 1][(2 * p) & 3] = v.x;
-          breg[e][p >> 1][((2 * p) & 3) + 1] = v.y;
+          const bool pp = rok && col + 2 * p < a.W;
+          const float2 v = wb_ld2(rb, (v0 + 8 * p) | oob(pp));
+          bmain[e][2 * p] = v.x; bmain[e][2 * p + 1] = v.y;
+          m |= pp ? 3u << (2 * p) : 0u;
         }
       }
+      if constexpr (DIL == 1) {
+        bl[e][0] = wb_ld1(rb, (v0 - 4) | oob(mL));
+        br[e][0] = wb_ld1(rb, (v0 + 32) | oob(mR));
+      } else {
+        const float2 l = wb_ld2(rb, (v0 - 8) | oob(mL)), r = wb_ld2(rb, (v0 + 32) | oob(mR));
+        bl[e][0] = l.x; bl[e][1] = l.y; br[e][0] = r.x; br[e][1] = r.y;
+      }
+      if constexpr (!RAW) bmask[e] = m | (mL ? 0xf00u : 0u) | (mR ? 0xf000u : 0u);
     }
   };
   auto finish = [&](int buf) __attribute__((always_inline)) {
@@ -148,30 +184,44 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
     unsigned char* Bb = Ab + A_BYTES;
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
-      unsigned pk = a_pk[e];
-      asm volatile("" : "+v"(pk));
-      const bool ok = (amask >> e) & 1u;
       const f32x4 v = areg[e];
-      uint2 o;
-      o.x = ok ? bf_pack2(v.x, v.y) : 0u;
-      o.y = ok ? bf_pack2(v.z, v.w) : 0u;
-      *reinterpret_cast<uint2*>(Ab + (pk & 0x1ffffu)) = o;
+      *reinterpret_cast<uint2*>(Ab + a_lds + e * COSTEP * A_ROW) = make_uint2(bf_pack2(v.x, v.y), bf_pack2(v.z, v.w));
     }
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
       unsigned pk = b_pk[e];
       asm volatile("" : "+v"(pk));
-      float v[8];
+      float v[8], l[DIL], r[DIL];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] = RAW ? breg[e][j >> 2][j & 3] : act_by_slope(fmaf(breg[e][j >> 2][j & 3], b_sc[e], b_sh[e]), slope);
+      for (int j = 0; j < 8; ++j) v[j] = bmain[e][j];
+#pragma unroll
+      for (int j = 0; j < DIL; ++j) { l[j] = bl[e][j]; r[j] = br[e][j]; }
+      if constexpr (!RAW) {                  // zero padding of the ACTIVATED tensor: act(affine(0)) is not 0
+        const unsigned m = bmask[e];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1u ? act_by_slope(fmaf(v[j], b_sc[e], b_sh[e]), slope) : 0.f;
+#pragma unroll
+        for (int j = 0; j < DIL; ++j) {
+          l[j] = (m & 0x100u) ? act_by_slope(fmaf(l[j], b_sc[e], b_sh[e]), slope) : 0.f;
+          r[j] = (m & 0x1000u) ? act_by_slope(fmaf(r[j], b_sc[e], b_sh[e]), slope) : 0.f;
+        }
       }
       if (BE * NT == BU || tid + NT * e < BU) {
-        // zero padding of the ACTIVATED tensor, on the packed pairs (W is even: a pair is all-in or all-out)
-        const unsigned m = bmask[e];
-        u32x4 o = {(m & 1u) ? bf_pack2(v[0], v[1]) : 0u, (m & 4u) ? bf_pack2(v[2], v[3]) : 0u,
-                   (m & 16u) ? bf_pack2(v[4], v[5]) : 0u, (m & 64u) ? bf_pack2(v[6], v[7]) : 0u};
-        *reinterpret_cast<u32x4*>(Bb + (pk & 0x1ffffu)) = o;
+        u32x4 X, S1, S2;
+        if constexpr (DIL == 1) {
+          const unsigned o12 = bf_pack2(v[1], v[2]), o34 = bf_pack2(v[3], v[4]), o56 = bf_pack2(v[5], v[6]);
+          X = u32x4{bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
+          S1 = u32x4{bf_pack2(l[0], v[0]), o12, o34, o56};
+          S2 = u32x4{o12, o34, o56, bf_pack2(v[7], r[0])};
+        } else {
+          X = u32x4{bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
+          S1 = u32x4{bf_pack2(l[0], l[1]), X.x, X.y, X.z};
+          S2 = u32x4{X.y, X.z, X.w, bf_pack2(r[0], r[1])};
+        }
+        unsigned char* dst = Bb + (pk & 0x1ffffu);
+        *reinterpret_cast<u32x4*>(dst) = X;
+        *reinterpret_cast<u32x4*>(dst + COPYB) = S1;
+        *reinterpret_cast<u32x4*>(dst + 2 * COPYB) = S2;
       }
     }
   };
@@ -181,38 +231,36 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
     finish(0);
   }
   __syncthreads();
-  const int a_lane = (wr * 32 + li) * A_ROW + lk * 16;
-  const int b_lane = (wc * 32 + li) * CH + lk * 16;
+  // (a row half's offset is folded into the lane base: every fragment address below is base + immediate)
+  const int a_lane = (wr * 32 + li) * A_ROW + lk * 16 + hf * RH * TW * 2;
+  const int b_lane = (wc * 32 + li) * CH + lk * 16 + hf * RH * RSB;
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = (t - t_begin) & 1;
     if (t + 1 < t_end) issue(t + 1);
     const unsigned char* Ap = smem + buf * (A_BYTES + B_BYTES) + a_lane;
     const unsigned char* Bp = Ap - a_lane + A_BYTES + b_lane;
+    // patch row p meets output rows p, p - DIL, p - 2 DIL through taps kh = 0, 1, 2: its three kw fragments (one aligned
+    // ds_read_b128 each, from the three pre-shifted copies) are read ONCE and the dY fragments of the RH rows stay in
+    // registers, instead of three reads of every patch row plus funnel shifts for the odd alignments
 #pragma unroll
-    for (int r = 0; r < TH; ++r) {
+    for (int q = 0; q < TW / 16; ++q) {
+      bf16x8 af[RH];
 #pragma unroll
-      for (int q = 0; q < TW / 16; ++q) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ap + (r * TW + 16 * q) * 2);
+      for (int r = 0; r < RH; ++r) af[r] = *reinterpret_cast<const bf16x8*>(Ap + (r * TW + 16 * q) * 2);
+#pragma unroll
+      for (int p = 0; p < RH + 2 * DIL; ++p) {
+        const unsigned char* row = Bp + p * RSB + (16 * q) * 2;
+        const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(row);
+        const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(row + COPYB);
+        const bf16x8 f2 = *reinterpret_cast<const bf16x8*>(row + 2 * COPYB);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-          // elements 6+w .. 17+w of patch row r + kh*DIL (w = 16q + 8*lk): dwords d0 .. d5
-          const unsigned char* row = Bp + (r + kh * DIL) * ROWB + (16 * q) * 2;
-          const uint2 lo = *reinterpret_cast<const uint2*>(row + 8);        // elements 4..7   (d0 = lo.y)
-          const u32x4 mid = *reinterpret_cast<const u32x4*>(row + 16);      // elements 8..15  (d1..d4)
-          const uint2 hi = *reinterpret_cast<const uint2*>(row + 32);       // elements 16..19 (d5 = hi.x)
-          u32x4 f0, f2;
-          if constexpr (DIL == 1) {
-            f0 = u32x4{__builtin_amdgcn_alignbit(mid.x, lo.y, 16), __builtin_amdgcn_alignbit(mid.y, mid.x, 16),
-                       __builtin_amdgcn_alignbit(mid.z, mid.y, 16), __builtin_amdgcn_alignbit(mid.w, mid.z, 16)};
-            f2 = u32x4{__builtin_amdgcn_alignbit(mid.y, mid.x, 16), __builtin_amdgcn_alignbit(mid.z, mid.y, 16),
-                       __builtin_amdgcn_alignbit(mid.w, mid.z, 16), __builtin_amdgcn_alignbit(hi.x, mid.w, 16)};
-          } else {
-            f0 = u32x4{lo.y, mid.x, mid.y, mid.z};
-            f2 = u32x4{mid.y, mid.z, mid.w, hi.x};
+          const int r = p - kh * DIL;
+          if (r >= 0 && r < RH) {
+            acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r], f0, acc[kh * 3 + 0], 0, 0, 0);
+            acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r], f1, acc[kh * 3 + 1], 0, 0, 0);
+            acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r], f2, acc[kh * 3 + 2], 0, 0, 0);
           }
-          acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, f0), acc[kh * 3 + 0], 0, 0, 0);
-          acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, mid), acc[kh * 3 + 1], 0, 0, 0);
-          acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, f2), acc[kh * 3 + 2], 0, 0, 0);
         }
       }
     }
@@ -226,7 +274,7 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (co < a.Cout && ci < a.Cin) a.out[(((long long)split * 9 + j) * a.Cout + co) * a.Cin + ci] = acc[j][r];
+      if (co < a.Cout && ci < a.Cin) a.out[(((long long)(split * (HALF ? 2 : 1) + hf) * 9 + j) * a.Cout + co) * a.Cin + ci] = acc[j][r];
     }
   }
 }
@@ -243,10 +291,11 @@ bool wb_applicable(const avsep_conv_desc* d) {
   if (d->up2x || d->C0 != d->Cin) return false;
   // maps narrower than a 16-pixel k-step (U-Net u6 / u7: 8 / 4 wide) run with the unused columns zero-masked
   return d->W >= 4 && d->H >= 2 && (d->W & 1) == 0 && d->Cout >= 32 && d->Cin >= 32 && d->N <= 65535 &&
-         (long long)(d->Cout > d->Cin ? d->Cout : d->Cin) * d->H * d->W < 0x7fffffffLL;
+         (long long)(d->Cout > d->Cin ? d->Cout : d->Cin) * d->H * d->W < 0x7fffffffLL &&
+         (long long)128 * d->H * d->W * 4 < 0x7fff0000LL;      // a workgroup's channel block as 32-bit byte offsets of its buffer loads
 }
 
-struct WBPlan { int tilesX, tilesY, gridM, gridC, splits, tps; bool wide; };
+struct WBPlan { int tilesX, tilesY, gridM, gridC, splits, tps; bool wide, half; };
 static WBPlan wb_plan(const avsep_conv_desc* d) {
   WBPlan p;
   p.wide = d->W > 16;
@@ -255,7 +304,8 @@ static WBPlan wb_plan(const avsep_conv_desc* d) {
   // arrive in, and a 4x16 tile's 36 MFMAs are shorter than an HBM round trip); the dilated 32-wide patch only fits
   // with 2-row tiles
   p.tilesY = cdiv(d->H, p.wide ? (d->dil == 2 ? 2 : 4) : 8);
-  p.gridM = cdiv(d->Cout, WB_BM);
+  p.half = d->Cout <= 64;
+  p.gridM = p.half ? 1 : cdiv(d->Cout, 128);
   p.gridC = cdiv(d->Cin, WB_BC);
   const long long tiles = (long long)p.tilesX * p.tilesY * d->N;
   // one workgroup per CU (107 KB of LDS) and nothing overlaps a workgroup's prologue / epilogue: ONE round of workgroups
@@ -272,7 +322,7 @@ static WBPlan wb_plan(const avsep_conv_desc* d) {
 }
 size_t wb_workspace_floats(const avsep_conv_desc* d) {
   WBPlan p = wb_plan(d);
-  return (size_t)p.splits * d->Cout * d->Cin * 9;          // always through slabs (tap-major) + the transposing reduce
+  return (size_t)p.splits * (p.half ? 2 : 1) * d->Cout * d->Cin * 9;          // always through slabs (tap-major) + the transposing reduce
 }
 int w3_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st);   // conv3x3.hip
 
@@ -286,10 +336,12 @@ int wb_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   dim3 grid(p.gridM * p.gridC, p.splits);
   const bool a2 = (d->W & 3) != 0;
   const bool raw = d->scale0 == nullptr && d->act0 == AVSEP_ACT_NONE;
-#define WB_L(TW_, DIL_, A2_)                                                                                                   \
-  do {                                                                                                                         \
-    if (raw) hipLaunchKernelGGL((wgradbf_kernel<TW_ == 16 ? 8 : (DIL_ == 2 ? 2 : 4), TW_, DIL_, A2_, true>), grid, dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((wgradbf_kernel<TW_ == 16 ? 8 : (DIL_ == 2 ? 2 : 4), TW_, DIL_, A2_, false>), grid, dim3(256), 0, st, a); \
+#define WB_K(TW_, DIL_, A2_, RAW_, HALF_) \
+  hipLaunchKernelGGL((wgradbf_kernel<TW_ == 16 ? 8 : (DIL_ == 2 ? 2 : 4), TW_, DIL_, A2_, RAW_, HALF_>), grid, dim3(256), 0, st, a)
+#define WB_L(TW_, DIL_, A2_)                                                                   \
+  do {                                                                                         \
+    if (raw) { if (p.half) WB_K(TW_, DIL_, A2_, true, true); else WB_K(TW_, DIL_, A2_, true, false); }     \
+    else { if (p.half) WB_K(TW_, DIL_, A2_, false, true); else WB_K(TW_, DIL_, A2_, false, false); }       \
   } while (0)
   if (d->dil == 1) {
     if (p.wide) { if (a2) WB_L(32, 1, true); else WB_L(32, 1, false); }
@@ -299,6 +351,7 @@ int wb_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
     else { if (a2) WB_L(16, 2, true); else WB_L(16, 2, false); }
   }
 #undef WB_L
+#undef WB_K
   AVSEP_LAUNCH_CHECK();
-  return w3_reduce(ws, dw, (long long)d->Cout * d->Cin, p.splits, st);
+  return w3_reduce(ws, dw, (long long)d->Cout * d->Cin, p.splits * (p.half ? 2 : 1), st);
 }
