@@ -119,126 +119,142 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
   }
   f32x4 areg[AE];
   float bmain[BE][8], bl[BE][DIL], br[BE][DIL];
-  unsigned bmask[RAW ? 1 : BE];      // element-valid bits of a unit: main 0-7, left extras 8.., right extras 12..
+  unsigned bmask[RAW ? 1 : BE];      // quad-valid bits of a unit: main quads 0, 4 (pairs 0, 2, 4, 6 when A2), left extra 8, right extra 12
 
-  auto issue = [&](int t) __attribute__((always_inline)) {
-    const int n = t / tiles_img, tt = t % tiles_img, h0 = (tt / a.tilesX) * TH, w0 = (tt % a.tilesX) * TW;
-    const __amdgpu_buffer_rsrc_t ra = wb_rsrc(a.dy + ((long long)n * a.Cout + m0) * HW + (long long)h0 * a.W + w0);
-    const __amdgpu_buffer_rsrc_t rb = wb_rsrc(a.x0 + ((long long)n * a.Cin + c0) * HW + (long long)(h0 - DIL) * a.W + (w0 - 8));
-    // validity as an OR mask on the offset (bit 31 set = outside every buffer): plain integer arithmetic, because a
-    // `valid ? offset : WB_OOB` select in front of a load is turned into a branch around two copies of the load
-    auto oob = [](bool valid) __attribute__((always_inline)) {
-      unsigned m = valid ? 0u : WB_OOB;
-      asm volatile("" : "+v"(m));
-      return m;
-    };
-    {
-      const bool rok = h0 + tr < a.H;
-      const unsigned m1 = oob(rok && w0 + 4 * tq < a.W), m2 = oob(rok && w0 + 4 * tq + 2 < a.W);
+  // ---- rolling software pipeline -------------------------------------------------------------------------------------
+  // ONE register set: while tile i's MFMAs run, every staging register is converted and written to LDS (tile i+1, loaded
+  // during the previous trip) and immediately re-loaded for tile i+2, so a load has a whole trip to arrive and nothing
+  // waits on it.  With one wave per SIMD no other wave hides a phase: the serial form (issue -> MFMAs -> wait for the
+  // loads -> convert -> barrier) ran the matrix pipe 26 % of the time.
+  // validity as an OR mask on the offset (bit 31 set = outside every buffer): plain integer arithmetic, because a
+  // `valid ? offset : WB_OOB` select in front of a load is turned into a branch around two copies of the load
+  auto oob = [](bool valid) __attribute__((always_inline)) {
+    unsigned m = valid ? 0u : WB_OOB;
+    asm("" : "+v"(m));                      // (not volatile: only opaque to the select -> branch rewrite, free to be scheduled)
+    return m;
+  };
+  struct TileRef { __amdgpu_buffer_rsrc_t ra, rb; int h0, w0; unsigned m1, m2; };
+  auto tile_ref = [&](int t_) __attribute__((always_inline)) {
+    const int t = min(t_, t_end - 1);                                // past the sweep: the last tile again (never multiplied)
+    const int n = t / tiles_img, tt = t % tiles_img;
+    TileRef R;
+    R.h0 = (tt / a.tilesX) * TH; R.w0 = (tt % a.tilesX) * TW;
+    R.ra = wb_rsrc(a.dy + ((long long)n * a.Cout + m0) * HW + (long long)R.h0 * a.W + R.w0);
+    R.rb = wb_rsrc(a.x0 + ((long long)n * a.Cin + c0) * HW + (long long)(R.h0 - DIL) * a.W + (R.w0 - 8));
+    const bool rok = R.h0 + tr < a.H;
+    R.m1 = oob(rok && R.w0 + 4 * tq < a.W);
+    R.m2 = oob(rok && R.w0 + 4 * tq + 2 < a.W);
+    return R;
+  };
+  auto load_a = [&](const TileRef& R, int e) __attribute__((always_inline)) {
+    if constexpr (!A2) {
+      areg[e] = wb_ld4(R.ra, a_voff[e] | R.m1);                      // W % 4 == 0: a quad is all-in or all-out
+    } else {                                                         // rows 8-byte aligned (W % 4 == 2): two pairs
+      const float2 lo = wb_ld2(R.ra, a_voff[e] | R.m1), hi = wb_ld2(R.ra, (a_voff[e] + 8) | R.m2);
+      areg[e] = f32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+  };
+  auto load_b = [&](const TileRef& R, int e) __attribute__((always_inline)) {
+    const unsigned pk = b_pk[e];
+    const int pr = (int)((pk >> 17) & 15), col = R.w0 + (int)((pk >> 21) & 7) * 8;          // first column of the group
+    const bool rok = (unsigned)(R.h0 + pr - DIL) < (unsigned)a.H;
+    const unsigned v0 = b_voff[e];
+    const bool mL = rok && col > 0 && col <= a.W, mR = rok && col + 8 < a.W;
+    unsigned m = 0;
+    if constexpr (!A2) {
+      const bool q0 = rok && col < a.W, q1 = rok && col + 4 < a.W;
+      const f32x4 x0 = wb_ld4(R.rb, v0 | oob(q0)), x1 = wb_ld4(R.rb, (v0 + 16) | oob(q1));
 #pragma unroll
-      for (int e = 0; e < AE; ++e) {
-        if constexpr (!A2) {
-          areg[e] = wb_ld4(ra, a_voff[e] | m1);                      // W % 4 == 0: a quad is all-in or all-out
-        } else {                                                     // rows 8-byte aligned (W % 4 == 2): two pairs
-          const float2 lo = wb_ld2(ra, a_voff[e] | m1), hi = wb_ld2(ra, (a_voff[e] + 8) | m2);
-          areg[e] = f32x4{lo.x, lo.y, hi.x, hi.y};
-        }
+      for (int j = 0; j < 4; ++j) { bmain[e][j] = x0[j]; bmain[e][4 + j] = x1[j]; }
+      m = (q0 ? 0x01u : 0u) | (q1 ? 0x10u : 0u);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {          // pairs are all-in or all-out (W % 2 == 0)
+        const bool pp = rok && col + 2 * p < a.W;
+        const float2 v = wb_ld2(R.rb, (v0 + 8 * p) | oob(pp));
+        bmain[e][2 * p] = v.x; bmain[e][2 * p + 1] = v.y;
+        m |= pp ? 1u << (2 * p) : 0u;
       }
     }
+    if constexpr (DIL == 1) {
+      bl[e][0] = wb_ld1(R.rb, (v0 - 4) | oob(mL));
+      br[e][0] = wb_ld1(R.rb, (v0 + 32) | oob(mR));
+    } else {
+      const float2 l = wb_ld2(R.rb, (v0 - 8) | oob(mL)), r = wb_ld2(R.rb, (v0 + 32) | oob(mR));
+      bl[e][0] = l.x; bl[e][1] = l.y; br[e][0] = r.x; br[e][1] = r.y;
+    }
+    if constexpr (!RAW) bmask[e] = m | (mL ? 0x100u : 0u) | (mR ? 0x1000u : 0u);
+  };
+  auto store_a = [&](int buf, int e) __attribute__((always_inline)) {
+    const f32x4 v = areg[e];
+    *reinterpret_cast<uint2*>(smem + buf * (A_BYTES + B_BYTES) + a_lds + e * COSTEP * A_ROW) =
+        make_uint2(bf_pack2(v.x, v.y), bf_pack2(v.z, v.w));
+  };
+  auto store_b = [&](int buf, int e) __attribute__((always_inline)) {
+    unsigned char* Bb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES;
+    const unsigned pk = b_pk[e];
+    float v[8], l[DIL], r[DIL];
 #pragma unroll
-    for (int e = 0; e < BE; ++e) {
-      unsigned pk = b_pk[e];
-      asm volatile("" : "+v"(pk));          // keep the decode inside the tile loop (cheaper than holding it in registers)
-      const int pr = (int)((pk >> 17) & 15), col = w0 + (int)((pk >> 21) & 7) * 8;          // first column of the group
-      const bool rok = (unsigned)(h0 + pr - DIL) < (unsigned)a.H;
-      const unsigned v0 = b_voff[e];
-      const bool mL = rok && col > 0 && col <= a.W, mR = rok && col + 8 < a.W;
-      unsigned m = 0;
-      if constexpr (!A2) {
-        const bool q0 = rok && col < a.W, q1 = rok && col + 4 < a.W;
-        const f32x4 x0 = wb_ld4(rb, v0 | oob(q0)), x1 = wb_ld4(rb, (v0 + 16) | oob(q1));
+    for (int j = 0; j < 8; ++j) v[j] = bmain[e][j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { bmain[e][j] = x0[j]; bmain[e][4 + j] = x1[j]; }
-        m = (q0 ? 0x0fu : 0u) | (q1 ? 0xf0u : 0u);
-      } else {
+    for (int j = 0; j < DIL; ++j) { l[j] = bl[e][j]; r[j] = br[e][j]; }
+    if constexpr (!RAW) {
+      // zero padding of the ACTIVATED tensor (act(affine(0)) is not 0): the validity of a quad / pair is folded into its
+      // scale and shift (both 0 -> act(0) = 0) instead of a select per element
+      const unsigned m = bmask[e];
+      constexpr int NQ = A2 ? 4 : 2, QE = 8 / NQ;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {        // pairs are all-in or all-out (W % 2 == 0)
-          const bool pp = rok && col + 2 * p < a.W;
-          const float2 v = wb_ld2(rb, (v0 + 8 * p) | oob(pp));
-          bmain[e][2 * p] = v.x; bmain[e][2 * p + 1] = v.y;
-          m |= pp ? 3u << (2 * p) : 0u;
-        }
+      for (int q = 0; q < NQ; ++q) {
+        const bool ok = (m >> (q * QE)) & 1u;
+        const float sq = ok ? b_sc[e] : 0.f, hq = ok ? b_sh[e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < QE; ++j) v[q * QE + j] = act_by_slope(fmaf(v[q * QE + j], sq, hq), slope);
       }
+      const bool okl = m & 0x100u, okr = m & 0x1000u;
+      const float sl = okl ? b_sc[e] : 0.f, hl = okl ? b_sh[e] : 0.f, sr = okr ? b_sc[e] : 0.f, hr = okr ? b_sh[e] : 0.f;
+#pragma unroll
+      for (int j = 0; j < DIL; ++j) {
+        l[j] = act_by_slope(fmaf(l[j], sl, hl), slope);
+        r[j] = act_by_slope(fmaf(r[j], sr, hr), slope);
+      }
+    }
+    if (BE * NT == BU || tid + NT * e < BU) {
+      u32x4 X, S1, S2;
       if constexpr (DIL == 1) {
-        bl[e][0] = wb_ld1(rb, (v0 - 4) | oob(mL));
-        br[e][0] = wb_ld1(rb, (v0 + 32) | oob(mR));
+        const unsigned o12 = bf_pack2(v[1], v[2]), o34 = bf_pack2(v[3], v[4]), o56 = bf_pack2(v[5], v[6]);
+        X = u32x4{bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
+        S1 = u32x4{bf_pack2(l[0], v[0]), o12, o34, o56};
+        S2 = u32x4{o12, o34, o56, bf_pack2(v[7], r[0])};
       } else {
-        const float2 l = wb_ld2(rb, (v0 - 8) | oob(mL)), r = wb_ld2(rb, (v0 + 32) | oob(mR));
-        bl[e][0] = l.x; bl[e][1] = l.y; br[e][0] = r.x; br[e][1] = r.y;
+        X = u32x4{bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
+        S1 = u32x4{bf_pack2(l[0], l[1]), X.x, X.y, X.z};
+        S2 = u32x4{X.y, X.z, X.w, bf_pack2(r[0], r[1])};
       }
-      if constexpr (!RAW) bmask[e] = m | (mL ? 0xf00u : 0u) | (mR ? 0xf000u : 0u);
+      unsigned char* dst = Bb + (pk & 0x1ffffu);
+      *reinterpret_cast<u32x4*>(dst) = X;
+      *reinterpret_cast<u32x4*>(dst + COPYB) = S1;
+      *reinterpret_cast<u32x4*>(dst + 2 * COPYB) = S2;
     }
   };
-  auto finish = [&](int buf) __attribute__((always_inline)) {
-    unsigned char* Ab = smem + buf * (A_BYTES + B_BYTES);
-    unsigned char* Bb = Ab + A_BYTES;
-#pragma unroll
-    for (int e = 0; e < AE; ++e) {
-      const f32x4 v = areg[e];
-      *reinterpret_cast<uint2*>(Ab + a_lds + e * COSTEP * A_ROW) = make_uint2(bf_pack2(v.x, v.y), bf_pack2(v.z, v.w));
-    }
-#pragma unroll
-    for (int e = 0; e < BE; ++e) {
-      unsigned pk = b_pk[e];
-      asm volatile("" : "+v"(pk));
-      float v[8], l[DIL], r[DIL];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = bmain[e][j];
-#pragma unroll
-      for (int j = 0; j < DIL; ++j) { l[j] = bl[e][j]; r[j] = br[e][j]; }
-      if constexpr (!RAW) {                  // zero padding of the ACTIVATED tensor: act(affine(0)) is not 0
-        const unsigned m = bmask[e];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1u ? act_by_slope(fmaf(v[j], b_sc[e], b_sh[e]), slope) : 0.f;
-#pragma unroll
-        for (int j = 0; j < DIL; ++j) {
-          l[j] = (m & 0x100u) ? act_by_slope(fmaf(l[j], b_sc[e], b_sh[e]), slope) : 0.f;
-          r[j] = (m & 0x1000u) ? act_by_slope(fmaf(r[j], b_sc[e], b_sh[e]), slope) : 0.f;
-        }
-      }
-      if (BE * NT == BU || tid + NT * e < BU) {
-        u32x4 X, S1, S2;
-        if constexpr (DIL == 1) {
-          const unsigned o12 = bf_pack2(v[1], v[2]), o34 = bf_pack2(v[3], v[4]), o56 = bf_pack2(v[5], v[6]);
-          X = u32x4{bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
-          S1 = u32x4{bf_pack2(l[0], v[0]), o12, o34, o56};
-          S2 = u32x4{o12, o34, o56, bf_pack2(v[7], r[0])};
-        } else {
-          X = u32x4{bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
-          S1 = u32x4{bf_pack2(l[0], l[1]), X.x, X.y, X.z};
-          S2 = u32x4{X.y, X.z, X.w, bf_pack2(r[0], r[1])};
-        }
-        unsigned char* dst = Bb + (pk & 0x1ffffu);
-        *reinterpret_cast<u32x4*>(dst) = X;
-        *reinterpret_cast<u32x4*>(dst + COPYB) = S1;
-        *reinterpret_cast<u32x4*>(dst + 2 * COPYB) = S2;
-      }
-    }
-  };
+  // the tile barrier: LDS traffic only.  __syncthreads() is a workgroup fence and compiles to s_waitcnt vmcnt(0), which
+  // would drain the loads of the next tile issued during this trip
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  if (t_begin < t_end) {
-    issue(t_begin);
-    finish(0);
-  }
-  __syncthreads();
   // (a row half's offset is folded into the lane base: every fragment address below is base + immediate)
   const int a_lane = (wr * 32 + li) * A_ROW + lk * 16 + hf * RH * TW * 2;
   const int b_lane = (wc * 32 + li) * CH + lk * 16 + hf * RH * RSB;
-  for (int t = t_begin; t < t_end; ++t) {
-    const int buf = (t - t_begin) & 1;
-    if (t + 1 < t_end) issue(t + 1);
+  // One trip: tile i's MFMAs from LDS buffer `buf`, in NGRP groups (one patch row of one 16-pixel column block each), with
+  // the staging work (STAGE: registers of tile i+1 -> LDS buffer buf^1, reload for tile t_next) spread over the groups IN
+  // SOURCE ORDER and pinned there — left to itself the scheduler puts all of it before or after the 72 MFMAs, and with one
+  // wave per SIMD that is serial time (matrix pipe busy 26-30 %).
+  constexpr int NPR = RH + 2 * DIL, NGRP = (TW / 16) * NPR, NGRP_A = NGRP - BE;
+  static_assert(NGRP_A >= 1, "groups");
+  auto trip = [&](int buf, int t_next, auto stage_) __attribute__((always_inline)) {
+    constexpr bool STAGE = decltype(stage_)::value;
     const unsigned char* Ap = smem + buf * (A_BYTES + B_BYTES) + a_lane;
     const unsigned char* Bp = Ap - a_lane + A_BYTES + b_lane;
+    TileRef R;
+    if constexpr (STAGE) R = tile_ref(t_next);
     // patch row p meets output rows p, p - DIL, p - 2 DIL through taps kh = 0, 1, 2: its three kw fragments (one aligned
     // ds_read_b128 each, from the three pre-shifted copies) are read ONCE and the dY fragments of the RH rows stay in
     // registers, instead of three reads of every patch row plus funnel shifts for the odd alignments
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
 #pragma unroll
       for (int r = 0; r < RH; ++r) af[r] = *reinterpret_cast<const bf16x8*>(Ap + (r * TW + 16 * q) * 2);
 #pragma unroll
-      for (int p = 0; p < RH + 2 * DIL; ++p) {
+      for (int p = 0; p < NPR; ++p) {
         const unsigned char* row = Bp + p * RSB + (16 * q) * 2;
         const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(row);
         const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(row + COPYB);
@@ -262,10 +278,40 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
             acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r], f2, acc[kh * 3 + 2], 0, 0, 0);
           }
         }
+        if constexpr (STAGE) {
+          const int g = q * NPR + p;
+#pragma unroll
+          for (int e = 0; e < AE; ++e)
+            if (e * NGRP_A / AE == g) { store_a(buf ^ 1, e); load_a(R, e); }
+#pragma unroll
+          for (int e = 0; e < BE; ++e)
+            if (NGRP_A + e == g) { store_b(buf ^ 1, e); load_b(R, e); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (t + 1 < t_end) finish(buf ^ 1);
-    __syncthreads();
+  };
+  const int nt = t_end - t_begin;
+  if (nt > 0) {
+    {
+      const TileRef R = tile_ref(t_begin);
+#pragma unroll
+      for (int e = 0; e < AE; ++e) load_a(R, e);
+#pragma unroll
+      for (int e = 0; e < BE; ++e) load_b(R, e);
+    }
+    {
+      const TileRef R = tile_ref(t_begin + 1);
+#pragma unroll
+      for (int e = 0; e < AE; ++e) { store_a(0, e); load_a(R, e); }
+#pragma unroll
+      for (int e = 0; e < BE; ++e) { store_b(0, e); load_b(R, e); }
+    }
+    lds_barrier();
+    for (int i = 0; i < nt; ++i) {          // tile i from LDS buffer i & 1; the registers hold tile i+1 and receive tile i+2
+      trip(i & 1, t_begin + i + 2, std::true_type{});
+      lds_barrier();
+    }
   }
   // epilogue: row = output channel, MFMA column (lane) = input channel, accumulator = tap; tap-major slab
   const int ci = c0 + wc * 32 + li;
