@@ -134,16 +134,21 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
     return m;
   };
   struct TileRef { __amdgpu_buffer_rsrc_t ra, rb; int h0, w0; unsigned m1, m2; };
-  auto tile_ref = [&](int t_) __attribute__((always_inline)) {
-    const int t = min(t_, t_end - 1);                                // past the sweep: the last tile again (never multiplied)
-    const int n = t / tiles_img, tt = t % tiles_img;
+  // tiles are visited in order: (image, tile row, tile column) advance as counters (a division per trip was ~100 scalar
+  // instructions in front of the first MFMA); past the sweep the counters stop on the last tile (loaded again, never multiplied)
+  int cur_t = t_begin, cur_n = t_begin / tiles_img, cur_ty = (t_begin % tiles_img) / a.tilesX, cur_tx = (t_begin % tiles_img) % a.tilesX;
+  auto next_tile = [&]() __attribute__((always_inline)) {
     TileRef R;
-    R.h0 = (tt / a.tilesX) * TH; R.w0 = (tt % a.tilesX) * TW;
-    R.ra = wb_rsrc(a.dy + ((long long)n * a.Cout + m0) * HW + (long long)R.h0 * a.W + R.w0);
-    R.rb = wb_rsrc(a.x0 + ((long long)n * a.Cin + c0) * HW + (long long)(R.h0 - DIL) * a.W + (R.w0 - 8));
+    R.h0 = cur_ty * TH; R.w0 = cur_tx * TW;
+    R.ra = wb_rsrc(a.dy + ((long long)cur_n * a.Cout + m0) * HW + (long long)R.h0 * a.W + R.w0);
+    R.rb = wb_rsrc(a.x0 + ((long long)cur_n * a.Cin + c0) * HW + (long long)(R.h0 - DIL) * a.W + (R.w0 - 8));
     const bool rok = R.h0 + tr < a.H;
     R.m1 = oob(rok && R.w0 + 4 * tq < a.W);
     R.m2 = oob(rok && R.w0 + 4 * tq + 2 < a.W);
+    if (cur_t + 1 < t_end) {
+      ++cur_t;
+      if (++cur_tx == a.tilesX) { cur_tx = 0; if (++cur_ty == a.tilesY) { cur_ty = 0; ++cur_n; } }
+    }
     return R;
   };
   auto load_a = [&](const TileRef& R, int e) __attribute__((always_inline)) {
@@ -244,64 +249,68 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
   const int a_lane = (wr * 32 + li) * A_ROW + lk * 16 + hf * RH * TW * 2;
   const int b_lane = (wc * 32 + li) * CH + lk * 16 + hf * RH * RSB;
   // One trip: tile i's MFMAs from LDS buffer `buf`, in NGRP groups (one patch row of one 16-pixel column block each), with
-  // the staging work (STAGE: registers of tile i+1 -> LDS buffer buf^1, reload for tile t_next) spread over the groups IN
+  // the staging work (registers of tile i+1 -> LDS buffer buf^1, reload for tile i+2) spread over the groups IN
   // SOURCE ORDER and pinned there — left to itself the scheduler puts all of it before or after the 72 MFMAs, and with one
   // wave per SIMD that is serial time (matrix pipe busy 26-30 %).
   constexpr int NPR = RH + 2 * DIL, NGRP = (TW / 16) * NPR, NGRP_A = NGRP - BE;
   static_assert(NGRP_A >= 1, "groups");
-  auto trip = [&](int buf, int t_next, auto stage_) __attribute__((always_inline)) {
-    constexpr bool STAGE = decltype(stage_)::value;
+  auto trip = [&](int buf) __attribute__((always_inline)) {
     const unsigned char* Ap = smem + buf * (A_BYTES + B_BYTES) + a_lane;
     const unsigned char* Bp = Ap - a_lane + A_BYTES + b_lane;
-    TileRef R;
-    if constexpr (STAGE) R = tile_ref(t_next);
+    const TileRef R = next_tile();
     // patch row p meets output rows p, p - DIL, p - 2 DIL through taps kh = 0, 1, 2: its three kw fragments (one aligned
     // ds_read_b128 each, from the three pre-shifted copies) are read ONCE and the dY fragments of the RH rows stay in
-    // registers, instead of three reads of every patch row plus funnel shifts for the odd alignments
+    // registers, instead of three reads of every patch row plus funnel shifts for the odd alignments.  The fragments of
+    // group g+1 are read before group g's MFMAs (the order is pinned, so nothing else hides the LDS latency).
+    bf16x8 af[2][RH], fb[2][3];
+    auto read_a = [&](int q, int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < TW / 16; ++q) {
-      bf16x8 af[RH];
+      for (int r = 0; r < RH; ++r) af[slot][r] = *reinterpret_cast<const bf16x8*>(Ap + (r * TW + 16 * q) * 2);
+    };
+    auto read_b = [&](int g, int slot) __attribute__((always_inline)) {
+      const unsigned char* row = Bp + (g % NPR) * RSB + (16 * (g / NPR)) * 2;
+      fb[slot][1] = *reinterpret_cast<const bf16x8*>(row);
+      fb[slot][0] = *reinterpret_cast<const bf16x8*>(row + COPYB);
+      fb[slot][2] = *reinterpret_cast<const bf16x8*>(row + 2 * COPYB);
+    };
+    read_a(0, 0);
+    read_b(0, 0);
 #pragma unroll
-      for (int r = 0; r < RH; ++r) af[r] = *reinterpret_cast<const bf16x8*>(Ap + (r * TW + 16 * q) * 2);
-#pragma unroll
-      for (int p = 0; p < NPR; ++p) {
-        const unsigned char* row = Bp + p * RSB + (16 * q) * 2;
-        const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(row);
-        const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(row + COPYB);
-        const bf16x8 f2 = *reinterpret_cast<const bf16x8*>(row + 2 * COPYB);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int r = p - kh * DIL;
-          if (r >= 0 && r < RH) {
-            acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r], f0, acc[kh * 3 + 0], 0, 0, 0);
-            acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r], f1, acc[kh * 3 + 1], 0, 0, 0);
-            acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r], f2, acc[kh * 3 + 2], 0, 0, 0);
-          }
-        }
-        if constexpr (STAGE) {
-          const int g = q * NPR + p;
-#pragma unroll
-          for (int e = 0; e < AE; ++e)
-            if (e * NGRP_A / AE == g) { store_a(buf ^ 1, e); load_a(R, e); }
-#pragma unroll
-          for (int e = 0; e < BE; ++e)
-            if (NGRP_A + e == g) { store_b(buf ^ 1, e); load_b(R, e); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < NGRP; ++g) {
+      const int q = g / NPR, p = g % NPR, cur = g & 1;
+      if (g + 1 < NGRP) {
+        if ((g + 1) % NPR == 0) read_a(q + 1, (q + 1) & 1);
+        read_b(g + 1, cur ^ 1);
       }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int r = p - kh * DIL;
+        if (r >= 0 && r < RH) {
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q & 1][r], fb[cur][kw], acc[kh * 3 + kw], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < AE; ++e)
+        if (e * NGRP_A / AE == g) { store_a(buf ^ 1, e); load_a(R, e); }
+#pragma unroll
+      for (int e = 0; e < BE; ++e)
+        if (NGRP_A + e == g) { store_b(buf ^ 1, e); load_b(R, e); }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   const int nt = t_end - t_begin;
   if (nt > 0) {
     {
-      const TileRef R = tile_ref(t_begin);
+      const TileRef R = next_tile();
 #pragma unroll
       for (int e = 0; e < AE; ++e) load_a(R, e);
 #pragma unroll
       for (int e = 0; e < BE; ++e) load_b(R, e);
     }
     {
-      const TileRef R = tile_ref(t_begin + 1);
+      const TileRef R = next_tile();
 #pragma unroll
       for (int e = 0; e < AE; ++e) { store_a(0, e); load_a(R, e); }
 #pragma unroll
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void wgradbf_kernel(WBArgs a) {
     }
     lds_barrier();
     for (int i = 0; i < nt; ++i) {          // tile i from LDS buffer i & 1; the registers hold tile i+1 and receive tile i+2
-      trip(i & 1, t_begin + i + 2, std::true_type{});
+      trip(i & 1);
       lds_barrier();
     }
   }
