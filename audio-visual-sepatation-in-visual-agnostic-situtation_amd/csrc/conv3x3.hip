@@ -254,8 +254,8 @@ int c1x4_stft_fwd(const float* xt, const float* wp, float* out, int R, int NH, i
 }
 
 // ===========================================================================
-// Weight gradient of the 3x3/s1/p1 conv with the same LDS halo patch.
-//   dW[co][ci][tap] = sum_pix dY[co][pix] * X[ci][pix + tap]
+// Weight gradient of the 3x3/p1 conv (stride 1, or stride 2: ResNet layer2.0 / layer3.0 conv1) with the same LDS halo patch.
+//   dW[co][ci][tap] = sum_pix dY[co][pix] * X[ci][S*pix + tap]
 // GEMM: M = co (128 per workgroup), N = (tap, ci) with 32 input channels on the lanes and the 9 taps as
 // 9 MFMA column tiles, K = pixels of a TH x TW tile (MFMA lane half = pixel parity).  8 waves: wave w owns
 // output rows [32(w&3), +32) x taps {0..4} (w<4) or {5..8} (w>=4) — waves w and w+4 share a SIMD, so every
@@ -265,7 +265,7 @@ int c1x4_stft_fwd(const float* xt, const float* wp, float* out, int R, int NH, i
 // slabs (deterministic, no atomics).
 // ===========================================================================
 struct W3Args {
-  int N, Cin, H, W, Cout;
+  int N, Cin, H, W, Cout, Ho, Wo;     // H x W: input map, Ho x Wo: dY (equal at stride 1)
   int C0, C1, act0, act1, up2x, Hs, Ws;
   float rh, rw;
   const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
@@ -296,23 +296,23 @@ __device__ __forceinline__ float w3_src(const W3Args& a, int n, int c, int hs, i
 // parameter so that every B address is ONE per-lane base register + an immediate (with a run-time tap0 each tap
 // needs its own address register and a v_add per read: measured 1.35 VALU instructions per MFMA in this loop, and the
 // f32 MFMA shares the vector ALUs).
-template <int TH, int TW, int PW, int MAXT, int TAP0, int NTAP, int DIL = 1>
+template <int TH, int TW, int PW, int MAXT, int TAP0, int NTAP, int DIL = 1, int S = 1>
 __device__ __forceinline__ void w3_mfma_tile(const float* Ap, const float* Bp, f32x16 (&acc)[MAXT]) {
 #pragma unroll 1
   for (int py = 0; py < TH; ++py) {
     const float* ar = Ap + py * TW;
-    const float* br = Bp + py * PW;
+    const float* br = Bp + py * S * PW;
     float av[2], bv[2][NTAP];                               // operands of the next k-step are read one step ahead
     av[0] = ar[0];
 #pragma unroll
-    for (int j = 0; j < NTAP; ++j) bv[0][j] = br[(((TAP0 + j) / 3) * PW + (TAP0 + j) % 3) * DIL];
+    for (int j = 0; j < NTAP; ++j) bv[0][j] = br[(((TAP0 + j) / 3) * PW + (TAP0 + j) % 3) * DIL];   // (+ S * px below)
 #pragma unroll 4
     for (int px = 0; px < TW; px += 2) {
       const int cur = (px >> 1) & 1;
       if (px + 2 < TW) {
         av[cur ^ 1] = ar[px + 2];
 #pragma unroll
-        for (int j = 0; j < NTAP; ++j) bv[cur ^ 1][j] = br[(((TAP0 + j) / 3) * PW + (TAP0 + j) % 3) * DIL + px + 2];
+        for (int j = 0; j < NTAP; ++j) bv[cur ^ 1][j] = br[(((TAP0 + j) / 3) * PW + (TAP0 + j) % 3) * DIL + (px + 2) * S];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -324,10 +324,11 @@ __device__ __forceinline__ void w3_mfma_tile(const float* Ap, const float* Bp, f
 
 // DIL: dilation (pad = DIL); A2: rows of dY are only 8-byte aligned (W % 4 == 2, e.g. the 14x14 ResNet maps), the A tile
 // is then loaded as pairs of float2.  The U-Net instantiations are <.., 1, false>.
-template <int TH, int TW, bool UP2X, int BM, int DIL = 1, bool A2 = false>
+template <int TH, int TW, bool UP2X, int BM, int DIL = 1, bool A2 = false, int S = 1>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   static_assert(!(UP2X && DIL != 1), "the fused upsample path is undilated");
-  constexpr int NPIX = TH * TW, PH = TH + 2 * DIL, PW = TW + 2 * DIL;
+  static_assert(S == 1 || (DIL == 1 && !UP2X), "stride 2: plain 3x3 / pad 1");
+  constexpr int NPIX = TH * TW, PH = (TH - 1) * S + 2 * DIL + 1, PW = (TW - 1) * S + 2 * DIL + 1;
   constexpr int PS = (PH * PW) | 1;                       // odd per-channel stride: lanes = channels -> no bank conflicts
   constexpr int LDA = NPIX + 1;
   constexpr int NT = 512;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   const int m0 = mt * BM, c0 = ct * W3_CC;
   const int tiles_img = a.tilesX * a.tilesY, tiles_all = tiles_img * a.N;
   const int t_begin = split * a.tiles_per_split, t_end = min(tiles_all, t_begin + a.tiles_per_split);
-  const long long HW = (long long)a.H * a.W;
+  const long long HW = (long long)a.Ho * a.Wo;            // dY plane
 
   // BM=128: 4 row blocks x tap groups {0-4},{5-8} (waves w and w+4 share a SIMD: 9 MFMAs per SIMD and k-step);
   // BM=64: 2 row blocks x tap groups {0-2},{3,4},{5,6},{7,8}
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   for (int e = 0; e < AE; ++e) {
     int idx = tid + NT * e;
     int q = idx % (TW / 4), r = (idx / (TW / 4)) % TH, co = idx / (NPIX / 4);
-    a_goff[e] = min(m0 + co, a.Cout - 1) * (int)HW + r * a.W + 4 * q;   // Cout*H*W < 2^31 is checked on the host
+    a_goff[e] = min(m0 + co, a.Cout - 1) * (int)HW + r * a.Wo + 4 * q;   // Cout*H*W < 2^31 is checked on the host
     a_pk[e] = (unsigned)(co * LDA + r * TW + 4 * q) | (unsigned)r << 16 | (unsigned)(4 * q) << 20 |
               (m0 + co < a.Cout ? 0x80000000u : 0u);
   }
@@ -402,19 +403,19 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   unsigned amask = 0, pmask = 0;
   auto issue = [&](int t) __attribute__((always_inline)) {
     const int n = t / tiles_img, tt = t % tiles_img, h0 = (tt / a.tilesX) * TH, w0 = (tt % a.tilesX) * TW;
-    const float* dyb = a.dy + (long long)n * a.Cout * HW + (long long)h0 * a.W + w0;
-    const float* xb = xsrc + (long long)n * Csrc * sHW + (long long)h0 * a.Ws + w0;
+    const float* dyb = a.dy + (long long)n * a.Cout * HW + (long long)h0 * a.Wo + w0;
+    const float* xb = xsrc + (long long)n * Csrc * sHW + (long long)(h0 * S) * a.Ws + w0 * S;
     amask = pmask = 0;
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
       unsigned pk = a_pk[e];
       asm volatile("" : "+v"(pk));          // opaque: keeps the decode inside the tile loop (LICM would re-expand it into registers)
       const int a_r = (pk >> 16) & 15, a_c = (pk >> 20) & 63;
-      const bool ok = (pk >> 31) && h0 + a_r < a.H && w0 + a_c < a.W;
+      const bool ok = (pk >> 31) && h0 + a_r < a.Ho && w0 + a_c < a.Wo;
       if constexpr (!A2) {
         areg[e] = *reinterpret_cast<const f32x4*>(ok ? dyb + a_goff[e] : a.dy);
       } else {                 // the second pair of the quad may lie past the row end
-        const bool ok2 = ok && w0 + a_c + 2 < a.W;
+        const bool ok2 = ok && w0 + a_c + 2 < a.Wo;
         const float2 lo = *reinterpret_cast<const float2*>(ok ? dyb + a_goff[e] : a.dy);
         const float2 hi = *reinterpret_cast<const float2*>(ok2 ? dyb + a_goff[e] + 2 : a.dy);
         areg[e] = f32x4{lo.x, lo.y, ok2 ? hi.x : 0.f, ok2 ? hi.y : 0.f};
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
       unsigned pk = p_pk[e];
       asm volatile("" : "+v"(pk));
       const int p_r = (int)((pk >> 16) & 15) - DIL, p_col = (int)((pk >> 20) & 63) - DIL;
-      const bool ok = (pk >> 31) && (unsigned)(h0 + p_r) < (unsigned)a.H && (unsigned)(w0 + p_col) < (unsigned)a.W;
+      const bool ok = (pk >> 31) && (unsigned)(h0 * S + p_r) < (unsigned)a.H && (unsigned)(w0 * S + p_col) < (unsigned)a.W;
       praw[e] = *(ok ? xb + p_goff[e] : xsrc);
       pmask |= (unsigned)ok << e;
     }
@@ -482,16 +483,16 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
     const int buf = (t - t_begin) & 1;
     if (t + 1 < t_end) issue(t + 1);
     const float* Ap = As[buf] + (wrow * 32 + li) * LDA + lk;
-    const float* Bp = Ps[buf] + li * PS + lk;
+    const float* Bp = Ps[buf] + li * PS + lk * S;
     // one straight-line MFMA stream per tap group (wave-uniform switch; compile-time taps -> immediate LDS offsets)
     if constexpr (BM == 128) {
-      if (tg == 0) w3_mfma_tile<TH, TW, PW, MAXT, 0, 5, DIL>(Ap, Bp, acc);
-      else w3_mfma_tile<TH, TW, PW, MAXT, 5, 4, DIL>(Ap, Bp, acc);
+      if (tg == 0) w3_mfma_tile<TH, TW, PW, MAXT, 0, 5, DIL, S>(Ap, Bp, acc);
+      else w3_mfma_tile<TH, TW, PW, MAXT, 5, 4, DIL, S>(Ap, Bp, acc);
     } else {
-      if (tg == 0) w3_mfma_tile<TH, TW, PW, MAXT, 0, 3, DIL>(Ap, Bp, acc);
-      else if (tg == 1) w3_mfma_tile<TH, TW, PW, MAXT, 3, 2, DIL>(Ap, Bp, acc);
-      else if (tg == 2) w3_mfma_tile<TH, TW, PW, MAXT, 5, 2, DIL>(Ap, Bp, acc);
-      else w3_mfma_tile<TH, TW, PW, MAXT, 7, 2, DIL>(Ap, Bp, acc);
+      if (tg == 0) w3_mfma_tile<TH, TW, PW, MAXT, 0, 3, DIL, S>(Ap, Bp, acc);
+      else if (tg == 1) w3_mfma_tile<TH, TW, PW, MAXT, 3, 2, DIL, S>(Ap, Bp, acc);
+      else if (tg == 2) w3_mfma_tile<TH, TW, PW, MAXT, 5, 2, DIL, S>(Ap, Bp, acc);
+      else w3_mfma_tile<TH, TW, PW, MAXT, 7, 2, DIL, S>(Ap, Bp, acc);
     }
     if (t + 1 < t_end) {
       finish(buf ^ 1);
@@ -518,6 +519,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
 }
 
 bool w3_applicable(const avsep_conv_desc* d) {
+  if (d->KH == 3 && d->KW == 3 && d->stride == 2 && d->dil == 1 && d->pad == 1)       // ResNet layer2.0 / layer3.0 conv1
+    return !d->up2x && d->C0 == d->Cin && (d->H & 1) == 0 && (d->W & 1) == 0 && d->Wo >= 12 && (d->Wo & 1) == 0 && d->Cout > 4 &&
+           d->Cin >= 32 && d->N <= 65535 && (long long)(d->Cout > d->Cin ? d->Cout : d->Cin) * d->H * d->W < 0x7fffffffLL;
   if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil)) return false;
   if (d->up2x && (d->dil != 1 || (d->W & 3))) return false;
   return d->W >= 12 && d->H >= 2 && (d->W & 1) == 0 && d->Cout > 4 && d->Cin >= 32 && d->N <= 65535 &&
@@ -528,9 +532,11 @@ bool w3_applicable(const avsep_conv_desc* d) {
 struct W3Plan { int tilesX, tilesY, gridM, gridC, splits, tps; bool wide; };
 static W3Plan w3_plan(const avsep_conv_desc* d) {
   W3Plan p;
-  p.wide = d->W >= 32 && d->dil == 1;      // the dilated patch of a 2x32 tile would not leave room for two workgroups per CU
-  p.tilesX = cdiv(d->W, p.wide ? 32 : 16);
-  p.tilesY = cdiv(d->H, p.wide ? 2 : 4);
+  // tiles are tiles of dY.  Wide (2 x 32) tiles: not for the dilated patch (it would not leave room for two workgroups per
+  // CU); stride 2 takes 2 x 16 tiles (5 x 33 patch)
+  p.wide = d->Wo >= 32 && d->dil == 1 && d->stride == 1;
+  p.tilesX = cdiv(d->Wo, p.wide ? 32 : 16);
+  p.tilesY = cdiv(d->Ho, (p.wide || d->stride == 2) ? 2 : 4);
   p.gridM = cdiv(d->Cout, d->Cout <= 64 ? 64 : 128);
   p.gridC = cdiv(d->Cin, W3_CC);
   long long tiles = (long long)p.tilesX * p.tilesY * d->N;
@@ -568,7 +574,7 @@ int w3_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t s
 int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st) {
   W3Plan p = w3_plan(d);
   W3Args a{};
-  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Ho = d->Ho; a.Wo = d->Wo;
   a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = d->up2x;
   a.Hs = d->up2x ? d->H / 2 : d->H; a.Ws = d->up2x ? d->W / 2 : d->W;
   a.rh = (d->up2x && d->H > 1) ? (float)(a.Hs - 1) / (float)(d->H - 1) : 0.f;
@@ -582,8 +588,15 @@ int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
     if (d->Cout <= 64) hipLaunchKernelGGL((wgrad3x3_kernel<TH_, TW_, UP_, 64, DIL_, A2_>), grid, dim3(512), 0, st, a);  \
     else hipLaunchKernelGGL((wgrad3x3_kernel<TH_, TW_, UP_, 128, DIL_, A2_>), grid, dim3(512), 0, st, a);              \
   } while (0)
-  const bool a2 = (d->W & 3) != 0;
-  if (d->up2x) {
+  const bool a2 = (d->Wo & 3) != 0;
+#define W3_LAUNCH_S2(A2_)                                                                                                \
+  do {                                                                                                                   \
+    if (d->Cout <= 64) hipLaunchKernelGGL((wgrad3x3_kernel<2, 16, false, 64, 1, A2_, 2>), grid, dim3(512), 0, st, a);     \
+    else hipLaunchKernelGGL((wgrad3x3_kernel<2, 16, false, 128, 1, A2_, 2>), grid, dim3(512), 0, st, a);                  \
+  } while (0)
+  if (d->stride == 2) {
+    if (a2) W3_LAUNCH_S2(true); else W3_LAUNCH_S2(false);
+  } else if (d->up2x) {
     if (p.wide) W3_LAUNCH(2, 32, true, 1, false);
     else W3_LAUNCH(4, 16, true, 1, false);
   } else if (d->dil == 1 && !a2) {                // the U-Net's instantiations
@@ -598,6 +611,7 @@ int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
     W3_LAUNCH(4, 16, false, 2, true);
   }
 #undef W3_LAUNCH
+#undef W3_LAUNCH_S2
   AVSEP_LAUNCH_CHECK();
   if (p.splits > 1) {
     long long P = (long long)d->Cout * d->Cin;

@@ -83,7 +83,7 @@ class NetWrapper(torch.nn.Module):
             raise Exception("Unkown activation!")
         fused = args.output_activation != "softmax"   # softmax over the singleton channel is identically 1 (:132)
         gt_nat = self._gt_stack
-        errs, match_loss = [], 0
+        errs, sums_both, matches = [], [], []
         # pass 1: visual features in reversed order against reversed targets; pass 2: natural order.
         # Both passes read the same spectrogram: the U-Net shares its encoder between them (forward_pair).
         if hasattr(self.net_sound, "forward_pair") and getattr(self, "share_encoder", True) and 2 <= N <= 4:
@@ -99,14 +99,20 @@ class NetWrapper(torch.nn.Module):
                 gt = gt_nat.flip(0).contiguous() if reverse else gt_nat
                 pred, sums, FT = mask_loss(feat_sound, gt, weight, act, kind)
                 B, S = feat_sound.shape[:2]
-                err = (torch.diagonal(sums, dim1=1, dim2=2).sum() / (B * S * FT)).to(torch.float32)
+                sums_both.append(sums)
                 pred_masks = [pred[:, n].unsqueeze(1) for n in range(N)]
             else:
                 pred_masks = [activate(feat_sound[:, n].unsqueeze(1), args.output_activation) for n in range(N)]
-                err = self.crit_av(pred_masks, gt_masks[::-1] if reverse else gt_masks, weight)
-            errs.append(err.reshape(1))
-            match_loss = match_loss + meta[0]
-        err = ((errs[0] + errs[1]) / 2 + args.match_weight * match_loss).reshape(1)
+                errs.append(self.crit_av(pred_masks, gt_masks[::-1] if reverse else gt_masks, weight).reshape(1))
+            matches.append(meta[0])
+        match_loss = matches[0] + matches[1]
+        if fused:
+            # (err_rev + err_nat) / 2 with err = trace-sum / (B S FT): one reduction over both passes' [B,S,S] sums
+            tot = torch.diagonal(torch.stack(sums_both), dim1=2, dim2=3).sum()
+            mean_err = (tot * (0.5 / (B * S * FT))).to(torch.float32)
+        else:
+            mean_err = (errs[0] + errs[1]) / 2
+        err = torch.add(mean_err, match_loss, alpha=args.match_weight).reshape(1)
         return err, {"pred_masks": pred_masks, "gt_masks": gt_masks, "mag_mix": mag_mix, "mags": mags,
                      "weight": weight, "match_loss": match_loss.reshape(1), "att_maps": meta[1],
                      "logits": feat_sound}
