@@ -23,6 +23,7 @@
 // rectangle has on them.  Patch row / group strides are padded so that the 32 lanes of a ds_read_b64 hit 64 distinct
 // banks.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
       fy = 2 * yc + ((img >> 1) & 1);
       fx = 2 * xc + (img & 1);
     }
-    p_off[e] = (unsigned)(((long long)n * a.C0 + cc) * HW + (long long)fy * a.W + fx);   // C1 == C0 when there is a source 1
+    // BYTE offset from the source's base (the K-tile offset is scalar): element offsets < 2^30, host check
+    p_off[e] = ok ? 4u * (unsigned)(((long long)n * a.C0 + cc) * HW + (long long)fy * a.W + fx) : 0xffffffffu;   // C1 == C0 when there is a source 1
     p_pk[e] = (unsigned)(cc * PS + g * GS + r * PWG + col) | ((unsigned)cc << 20) | ((unsigned)ok << 24);
   }
   if constexpr (!RAW) {                       // folded BatchNorm rows of both sources -> LDS once (identity where absent)
@@ -164,18 +166,31 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
   const float slope0 = act_slope(a.act0), slope1 = act_slope(a.act1);
   float praw[PE];
   f32x4 areg[AE];
+  unsigned w_off[AE];                         // byte offsets of this thread's pieces inside a weight tile
+#pragma unroll
+  for (int pc = 0; pc < AE; ++pc) w_off[pc] = (unsigned)(tid * 4 + pc * (NT * 4)) * 4u;
 
   // The staged tile of a K-tile moves in AE + PE independent pieces (one global load, later one LDS store, each) so that
   // the MFMA loop can hang them behind individual MFMAs.  The weight tile is one contiguous 32 KB block per (K-tile,
   // M-tile).  (An LDS-DMA for it would cost an s_waitcnt vmcnt(0) — a full memory round trip — in front of the first
   // ds_read of every K-tile: the compiler orders every LDS read behind an outstanding LDS-DMA it cannot tell apart.)
   constexpr int NPIECE = AE + PE;
-  auto issue_piece = [&](int kt, int pc) __attribute__((always_inline)) {
+  // Global loads are BUFFER loads: scalar resource (source 0 / source 1 / the transformed weights), scalar K-tile offset, one
+  // constant 32-bit lane offset per piece — no 64-bit vector address arithmetic in the loop (plain global loads spent
+  // 8 v_lshl_add_u64 + 4 add / addc per K-tile on it, and the f32 MFMA does not overlap vector instructions).  An element
+  // outside the image has the offset 0xffffffff, which no buffer covers: it loads as 0 (the zero padding of a RAW input).
+  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x0, 0, 0xfffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x1 ? a.x1 : a.x0), 0, 0xfffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_up = __builtin_amdgcn_make_buffer_rsrc((void*)a.up, 0, 0xfffffff0, 0x00020000);
+  auto issue_piece = [&](int kt_, int pc) __attribute__((always_inline)) {
+    const int kt = __builtin_amdgcn_readfirstlane(kt_);
     if (pc < AE) {
-      areg[pc] = *reinterpret_cast<const f32x4*>(a.up + ((long long)kt * a.gridM + mt) * A_FLOATS + tid * 4 + pc * (NT * 4));
+      const unsigned soff = (unsigned)(kt * a.gridM + mt) * (unsigned)(A_FLOATS * 4);        // < 2^32: host check
+      areg[pc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_up, (int)w_off[pc], (int)soff, 0));
     } else if (pc < NPIECE) {
-      const float* xk = kt >= kt_switch ? a.x1 + (long long)(kt - kt_switch) * CK * HW : a.x0 + (long long)kt * CK * HW;
-      praw[pc - AE] = xk[p_off[pc - AE]];
+      const bool src1 = kt >= kt_switch;
+      const unsigned soff = (unsigned)(src1 ? kt - kt_switch : kt) * (unsigned)(CK * 4) * (unsigned)HW;
+      praw[pc - AE] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src1 ? rs_x1 : rs_x0, (int)p_off[pc - AE], (int)soff, 0));
     }
   };
   auto finish_piece = [&](int kt, int buf, int pc) __attribute__((always_inline)) {
@@ -189,7 +204,8 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
         const int c = kt * CK + ((p_pk[e] >> 20) & 15);
         v = act_by_slope(fmaf(v, aff_sc[c], aff_sh[c]), slope);
       }
-      if (PE * NT == NPATCH || tid + NT * e < NPATCH) (Pb + buf * P_FLOATS)[p_pk[e] & 0xfffffu] = ((p_pk[e] >> 24) & 1u) ? v : 0.f;
+      if constexpr (!RAW) v = ((p_pk[e] >> 24) & 1u) ? v : 0.f;        // (a RAW element outside the image already loaded as 0)
+      if (PE * NT == NPATCH || tid + NT * e < NPATCH) (Pb + buf * P_FLOATS)[p_pk[e] & 0xfffffu] = v;
     }
   };
 
@@ -257,8 +273,11 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
 #pragma unroll
   for (int st = 0; st < 4; ++st) transform(0, st);
 
-  for (int kt = 0; kt < nK; ++kt) {
-    const int buf = kt & 1;
+  // Two K-tiles per trip with the LDS buffer index a compile-time constant: with `buf = kt & 1` at run time every LDS
+  // access of the loop paid a vector add for `base + buf * size` (about 26 of the 88 vector instructions per 32 MFMAs, and
+  // the f32 MFMA does not overlap them).
+  auto ktile = [&](int kt, auto buf_) __attribute__((always_inline)) {
+    constexpr int buf = decltype(buf_)::value;
     const int kt1 = min(kt + 1, nK - 1), kt2 = min(kt + 2, nK - 1);
 #pragma unroll
     for (int kp = 0; kp < CK / 2; ++kp) {
@@ -283,6 +302,10 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
       }
       if (kp == CK / 2 - 2) __syncthreads();
     }
+  };
+  for (int kt = 0; kt < nK; kt += 2) {
+    ktile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nK) ktile(kt + 1, std::integral_constant<int, 1>{});
   }
   __syncthreads();          // the last block's operand prefetch has read LDS: drain before the epilogue reuses it
 
@@ -407,7 +430,7 @@ bool wn_applicable(const avsep_conv_desc* d, int mode) {
     const int C1 = d->Cin - d->C0;
     if (d->C0 % WN_CK || (C1 != 0 && C1 != d->C0)) return false;
   }
-  if ((long long)d->N * (mode == 0 ? d->C0 : d->Cout) * d->H * d->W >= 0xffffffffLL) return false;   // 32-bit element offsets
+  if ((long long)d->N * (mode == 0 ? d->C0 : d->Cout) * d->H * d->W >= 0x3fffffffLL) return false;   // 32-bit BYTE offsets
   const avsep_conv_desc e = plan_desc(d);
   const WnPlan p = wn_plan(&e, mode);
   return (long long)p.ptiles * p.gridM >= 128;      // at least half of the CUs busy (below that the split-K im2col path wins)
