@@ -23,6 +23,7 @@
 // the same 4x8 sub-pixel region of BOTH column parities of one row-parity class, so its loads stay 8-byte pairs of
 // adjacent full-resolution pixels.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -151,35 +152,39 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
       g_ok[g] = __builtin_amdgcn_readfirstlane(gt.w);
     }
   };
-  // piece pc of the chunk whose groups are loaded: global load into registers (a safe in-image address when masked;
-  // zeroed at the store)
+  // piece pc of the chunk whose groups are loaded: BUFFER load into registers — scalar resource, scalar group offset, the
+  // piece's constant byte offset in a vector register; a masked piece gets the offset 0xffffffff, which no buffer covers,
+  // and loads as 0 (no 64-bit vector address arithmetic, and for RAW inputs no valid bits and no selects at the store:
+  // the f32 MFMA does not overlap vector instructions).  The input resource starts (W + 2) * PSTEP elements BEFORE the
+  // source so that the patch origin (y0-1, x0-2) of every group is a non-negative scalar offset; nothing is read there.
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xs - (a.W + 2) * PSTEP), 0, 0xfffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, 0xfffffff0, 0x00020000);
+  auto ld2 = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) __attribute__((always_inline)) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+  };
   auto issue_piece = [&](int pc) __attribute__((always_inline)) {
     if (pc < PEX) {
       const int g = pc / PEG, e = pc % PEG;
       const int r = (xk[pc] >> 14) & 15, k = (xk[pc] >> 18) & 31;
       const int y = g_y0[g] - 1 + r, x = g_x0[g] - 2 + 2 * k;
       const bool ok = (PEG * NT == NXG || tid + NT * e < NXG) && g_ok[g] && (unsigned)y < (unsigned)a.Hq && (unsigned)x < (unsigned)a.Wq;
-      // patch origin (y0-1, x0-2) of the group inside channel cs0 of image n (may lie before the tensor: never dereferenced
-      // unmasked); masked pieces read the group's own origin pixel
-      const float* pb = xs + ((long long)(g_n[g] * Cs + cs0) * HW + g_pix[g] - (a.W + 2) * PSTEP);
-      const unsigned off = ok ? (unsigned)xrel[pc] : (unsigned)((a.W + 2) * PSTEP);
+      const unsigned soff = 4u * (unsigned)((g_n[g] * Cs + cs0) * iHW + g_pix[g]);      // N * C * H * W < 2^30: host check
+      const unsigned off = ok ? 4u * (unsigned)xrel[pc] : 0xffffffffu;
       if constexpr (SUB) {
         const bool ok1 = ok && x + 1 < a.Wq;
-        xraw[pc] = *reinterpret_cast<const f32x2*>(pb + off);
-        xraw2[pc] = *reinterpret_cast<const f32x2*>(pb + (ok1 ? off + 2 : off));
-        okhi = (okhi & ~(1u << pc)) | ((unsigned)ok1 << pc);
+        xraw[pc] = ld2(rs_x, off, soff);
+        xraw2[pc] = ld2(rs_x, ok1 ? off + 8 : 0xffffffffu, soff);
+        if constexpr (!RAW) okhi = (okhi & ~(1u << pc)) | ((unsigned)ok1 << pc);
       } else {
-        xraw[pc] = *reinterpret_cast<const f32x2*>(pb + off);
+        xraw[pc] = ld2(rs_x, off, soff);
       }
-      okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
+      if constexpr (!RAW) okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
     } else if (pc < NPIECE) {
       const int p = pc - PEX, g = p / PDG;
       const int row = (dk[p] >> 14) & 15, col = (dk[p] >> 18) & 31, co = (int)(dk[p] >> 24);
       const bool ok = g_ok[g] && g_y0[g] + row < a.Hq && g_x0[g] + col < a.Wq && m0 + co < a.Cout;   // W, col even: a pair is in or out together
-      const float* pb = a.dy + ((long long)(g_n[g] * a.Cout + m0) * HW + g_pix[g]);
-      const unsigned off = ok ? (unsigned)drel[p] : 0u;
-      draw[p] = *reinterpret_cast<const f32x2*>(pb + off);
-      okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
+      const unsigned soff = 4u * (unsigned)((g_n[g] * a.Cout + m0) * iHW + g_pix[g]);
+      draw[p] = ld2(rs_d, ok ? 4u * (unsigned)drel[p] : 0xffffffffu, soff);
     }
   };
   auto affine_act2 = [&](f32x2 v, int ci) __attribute__((always_inline)) {
@@ -189,11 +194,11 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
     return f32x2{fmaxf(v[0], w2[0]), fmaxf(v[1], w2[1])};
   };
   auto finish_piece = [&](int buf, int pc) __attribute__((always_inline)) {
-    const bool ok = (okbits >> pc) & 1u;
     if (pc < PEX) {
       f32x2 v = xraw[pc];
       if constexpr (!RAW) v = affine_act2(v, xk[pc] >> 24);
-      const bool ok1 = SUB ? (okhi >> pc) & 1u : ok;
+      const bool ok = RAW || ((okbits >> pc) & 1u);            // RAW: a masked piece already loaded as 0
+      const bool ok1 = RAW || (SUB ? (bool)((okhi >> pc) & 1u) : ok);
       if (PEG * NT == NXG || tid + NT * (pc % PEG) < NXG) {
         float* q = &Xs[buf][xk[pc] & 0x3fffu];
         if constexpr (SUB) {                  // v = both column parities at sub-column x, v2 at x + 1: one element of each group each
@@ -209,12 +214,12 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
         }
       }
     } else if (pc < NPIECE) {
-      const int p = pc - PEX;
+      const int p = pc - PEX;                 // (a masked dY piece loaded as 0)
       if constexpr (SUB) {
-        Ds[buf][dk[p] & 0x3fffu] = ok ? draw[p][0] : 0.f;
-        Ds[buf][(dk[p] & 0x3fffu) + GD] = ok ? draw[p][1] : 0.f;
+        Ds[buf][dk[p] & 0x3fffu] = draw[p][0];
+        Ds[buf][(dk[p] & 0x3fffu) + GD] = draw[p][1];
       } else {
-        *reinterpret_cast<f32x2*>(&Ds[buf][dk[p] & 0x3fffu]) = ok ? draw[p] : f32x2{0.f, 0.f};
+        *reinterpret_cast<f32x2*>(&Ds[buf][dk[p] & 0x3fffu]) = draw[p];
       }
     }
   };
@@ -619,7 +624,7 @@ bool ww_applicable(const avsep_conv_desc* d) {
   const int C1 = d->Cin - d->C0;
   if (d->Cin % WW_B || d->C0 % WW_B || d->Cout < 48 || (C1 != 0 && C1 != d->C0)) return false;
   if (d->H >= 32768 || d->W >= 32768 || (long long)d->H * d->W >= (1 << 24)) return false;   // 24-bit offset arithmetic
-  if ((long long)d->N * (d->C0 > d->Cout ? d->C0 : d->Cout) * d->H * d->W >= 0x7fffffffLL) return false;   // 32-bit element offsets
+  if ((long long)d->N * (d->C0 > d->Cout ? d->C0 : d->Cout) * d->H * d->W >= 0x3fffffffLL) return false;   // 32-bit BYTE offsets of the buffer loads
   const avsep_conv_desc e = plan_desc(d);
   const WwPlan p = ww_plan(&e);
   return (long long)p.gridM * p.gridC * p.splits >= 128 && p.nchunks >= 8;
