@@ -133,6 +133,7 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
 
   // ---- patch loader state: one 32-bit element offset + one packed (LDS slot | channel | valid) word per element ----
   unsigned p_off[PE], p_pk[PE];
+  int p_lds[PE];
 #pragma unroll
   for (int e = 0; e < PE; ++e) {
     const int idx = min(tid + NT * e, NPATCH - 1);
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
     // BYTE offset from the source's base (the K-tile offset is scalar): element offsets < 2^30, host check
     p_off[e] = ok ? 4u * (unsigned)(((long long)n * a.C0 + cc) * HW + (long long)fy * a.W + fx) : 0xffffffffu;   // C1 == C0 when there is a source 1
     p_pk[e] = (unsigned)(cc * PS + g * GS + r * PWG + col) | ((unsigned)cc << 20) | ((unsigned)ok << 24);
+    p_lds[e] = cc * PS + g * GS + r * PWG + col;       // (its own register: the store address is then base + immediate)
   }
   if constexpr (!RAW) {                       // folded BatchNorm rows of both sources -> LDS once (identity where absent)
     for (int c = tid; c < a.Cin; c += NT) {
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
         v = act_by_slope(fmaf(v, aff_sc[c], aff_sh[c]), slope);
       }
       if constexpr (!RAW) v = ((p_pk[e] >> 24) & 1u) ? v : 0.f;        // (a RAW element outside the image already loaded as 0)
-      if (PE * NT == NPATCH || tid + NT * e < NPATCH) (Pb + buf * P_FLOATS)[p_pk[e] & 0xfffffu] = v;
+      if (PE * NT == NPATCH || tid + NT * e < NPATCH) (Pb + buf * P_FLOATS)[RAW ? p_lds[e] : (int)(p_pk[e] & 0xfffffu)] = v;   // (non-RAW: registers)
     }
   };
 
