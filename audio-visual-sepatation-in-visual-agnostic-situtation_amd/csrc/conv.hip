@@ -65,7 +65,9 @@ __device__ __forceinline__ float load_virtual(const CArgs& a, long long nb0, lon
   return (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
 }
 
-template <int MODE, int BM, int BN, int BK, int WM, int WN>
+// UP2X: the fused bilinear x2 gather is compiled in only where it is used (as a run-time flag it put four corner loads,
+// their interpolation and a scalar branch per element into every instantiation's K loop).
+template <int MODE, int BM, int BN, int BK, int WM, int WN, bool UP2X = false>
 __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
     nbdy = (long long)n * a.Cout * HoWo;
   }
   const bool has0 = a.sc0 != nullptr, has1 = a.sc1 != nullptr;
+  const float slope0 = act_slope(a.act0), slope1 = act_slope(a.act1);   // branch-free activation (common.h)
   const int pixoff = hi0 * a.Ws + wi0;   // fwd: offset of the (possibly out-of-range) window origin
 
   float braw[NBR], bsc[NSC], bsh[NSC];
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
         const int hi = hi0 + dh, wi = wi0 + dw;
         const bool ok = cvalid && (k + e < K) && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
         const int cc = min(ci, a.Cin - 1);
-        if (a.up2x) {  // kernel-uniform: the bilinear gather finishes here (raw value is final)
+        if constexpr (UP2X) {  // the bilinear gather finishes here (raw value is final)
           braw[e] = ok ? load_virtual(a, nb0, nb1, cc, hi, wi) : 0.f;
           bsc[e] = 1.f;
           bsh[e] = 0.f;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
         int tt = tab >= 0 ? tab : 0;
         int ci = tt & 0xffff, hi = hb + ((tt >> 16) & 0xff), wi = wb + ((tt >> 24) & 0xff);
         bool ok = pv && tab >= 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        if (a.up2x) {
+        if constexpr (UP2X) {
           braw[e] = ok ? load_virtual(a, b0, b1, ci, hi, wi) : 0.f;
         } else {
           bool first = ci < a.C0;
@@ -304,10 +307,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
 #pragma unroll
       for (int e = 0; e < BROWS; ++e) {
         float v = braw[e];
-        if (!a.up2x) {
+        if constexpr (!UP2X) {
           bool first = (bfirst >> e) & 1u;
           if (first ? has0 : has1) v = fmaf(v, bsc[e], bsh[e]);
-          v = act_apply(v, first ? a.act0 : a.act1);
+          v = act_by_slope(v, first ? slope0 : slope1);
         }
         Bs[buf][brow0 + e][bcol] = ((bmask >> e) & 1u) ? v : 0.f;
       }
@@ -328,11 +331,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(CArgs a) {
 #pragma unroll
       for (int e = 0; e < BE; ++e) {
         float v = braw[e];
-        if (!a.up2x) {
+        if constexpr (!UP2X) {
           int col = grp + PG * e;
           int code = s_code[col];   // bit0: affine present, bits1-2: activation
           if (code & 1) v = fmaf(v, s_sc[col], s_sh[col]);
-          v = act_apply(v, code >> 1);
+          v = act_by_slope(v, act_slope(code >> 1));
         }
         Bs[buf][pl][grp + PG * e] = ((bmask >> e) & 1u) ? v : 0.f;
       }
@@ -829,12 +832,12 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
   }
   if (fwd_big(d)) {
     a.gridM = cdiv(a.M, 128);
-    hipLaunchKernelGGL((igemm_kernel<M_FWD, 128, 128, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 128), sp.splits), dim3(256), 0,
-                       st, a);
+    if (d->up2x) hipLaunchKernelGGL((igemm_kernel<M_FWD, 128, 128, 16, 2, 2, true>), dim3(a.gridM * cdiv(ncols, 128), sp.splits), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<M_FWD, 128, 128, 16, 2, 2, false>), dim3(a.gridM * cdiv(ncols, 128), sp.splits), dim3(256), 0, st, a);
   } else {
     a.gridM = cdiv(a.M, 64);
-    hipLaunchKernelGGL((igemm_kernel<M_FWD, 64, 64, 16, 2, 2>), dim3(a.gridM * cdiv(ncols, 64), sp.splits), dim3(256), 0, st,
-                       a);
+    if (d->up2x) hipLaunchKernelGGL((igemm_kernel<M_FWD, 64, 64, 16, 2, 2, true>), dim3(a.gridM * cdiv(ncols, 64), sp.splits), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<M_FWD, 64, 64, 16, 2, 2, false>), dim3(a.gridM * cdiv(ncols, 64), sp.splits), dim3(256), 0, st, a);
   }
   AVSEP_LAUNCH_CHECK();
   if (sp.splits > 1) {
@@ -964,12 +967,12 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   hipStream_t st = (hipStream_t)stream;
   if (p.big) {
     a.gridM = cdiv(a.M, 128);
-    hipLaunchKernelGGL((igemm_kernel<M_WGRAD, 128, 128, 32, 2, 2>), dim3(a.gridM * cdiv(a.Ncols, 128), p.splits), dim3(256),
-                       0, st, a);
+    if (d->up2x) hipLaunchKernelGGL((igemm_kernel<M_WGRAD, 128, 128, 32, 2, 2, true>), dim3(a.gridM * cdiv(a.Ncols, 128), p.splits), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<M_WGRAD, 128, 128, 32, 2, 2, false>), dim3(a.gridM * cdiv(a.Ncols, 128), p.splits), dim3(256), 0, st, a);
   } else {
     a.gridM = cdiv(a.M, 64);
-    hipLaunchKernelGGL((igemm_kernel<M_WGRAD, 64, 64, 32, 2, 2>), dim3(a.gridM * cdiv(a.Ncols, 64), p.splits), dim3(256), 0,
-                       st, a);
+    if (d->up2x) hipLaunchKernelGGL((igemm_kernel<M_WGRAD, 64, 64, 32, 2, 2, true>), dim3(a.gridM * cdiv(a.Ncols, 64), p.splits), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<M_WGRAD, 64, 64, 32, 2, 2, false>), dim3(a.gridM * cdiv(a.Ncols, 64), p.splits), dim3(256), 0, st, a);
   }
   AVSEP_LAUNCH_CHECK();
   if (p.splits > 1) {
