@@ -448,15 +448,22 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad4d_kernel(W4dArgs a) {
       g_ok[g] = __builtin_amdgcn_readfirstlane(gt.w);
     }
   };
+  // buffer loads as in winow_kernel: scalar resource and group offset, the piece's constant byte offset in a vector register,
+  // 0xffffffff (outside every buffer: loads as 0) for a masked piece — no 64-bit vector adds, no valid bits / selects
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x0 - (a.W + 2)), 0, 0xfffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, 0xfffffff0, 0x00020000);
+  auto ld2 = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) __attribute__((always_inline)) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+  };
   auto issue_piece = [&](int pc) __attribute__((always_inline)) {
     if (pc < PEX) {
       const int g = pc / PEG, e = pc % PEG;
       const int r = (xk[pc] >> 14) & 15, k = (xk[pc] >> 18) & 31;
       const int y = g_y0[g] - 1 + r, x = g_x0[g] - 2 + 2 * k;
       const bool ok = (PEG * NT == NXG || tid + NT * e < NXG) && g_ok[g] && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-      const float* pb = a.x0 + ((long long)(g_n[g] * a.Cin + c0) * HW + g_pix[g] - (a.W + 2));
-      xraw[pc] = *reinterpret_cast<const f32x2*>(pb + (ok ? (unsigned)xrel[pc] : (unsigned)(a.W + 2)));
-      okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
+      const unsigned soff = 4u * (unsigned)((g_n[g] * a.Cin + c0) * (int)HW + g_pix[g]);     // N * C * H * W < 2^30: host check
+      xraw[pc] = ld2(rs_x, ok ? 4u * (unsigned)xrel[pc] : 0xffffffffu, soff);
+      if constexpr (!RAW) okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
     } else if (pc < NPIECE) {
       // the group index of the thread's dY pair is a lane value when G > 1: select among the scalar records
       int n = g_n[0], y0 = g_y0[0], x0 = g_x0[0], gok = g_ok[0];
@@ -466,12 +473,10 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad4d_kernel(W4dArgs a) {
       const int oy = (y0 >> 1) + drow, ox = (x0 >> 1) + dcol;
       const bool ok = gok && oy < a.Ho && ox < a.Wo && m0 + dco < a.Cout;       // Wo, dcol even: a pair is in or out together
       const unsigned off = (unsigned)((long long)(n * a.Cout + m0) * HWo) + (unsigned)(__mul24(y0 >> 1, a.Wo) + (x0 >> 1) + drel);
-      draw = *reinterpret_cast<const f32x2*>(a.dy + (ok ? off : 0u));
-      okbits = (okbits & ~(1u << pc)) | ((unsigned)ok << pc);
+      draw = ld2(rs_d, ok ? 4u * off : 0xffffffffu, 0u);
     }
   };
   auto finish_piece = [&](int buf, int pc) __attribute__((always_inline)) {
-    const bool ok = (okbits >> pc) & 1u;
     if (pc < PEX) {
       f32x2 v = xraw[pc];
       if constexpr (!RAW) {
@@ -479,15 +484,17 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad4d_kernel(W4dArgs a) {
         v = __builtin_elementwise_fma(v, f32x2{ss[0], ss[0]}, f32x2{ss[1], ss[1]});
         const f32x2 w2 = v * f32x2{slope, slope};
         v = f32x2{fmaxf(v[0], w2[0]), fmaxf(v[1], w2[1])};
+        const bool ok = (okbits >> pc) & 1u;                     // (a RAW piece outside the image already loaded as 0)
+        v = f32x2{ok ? v[0] : 0.f, ok ? v[1] : 0.f};
       }
       if (PEG * NT == NXG || tid + NT * (pc % PEG) < NXG) {
         float* q = &Xs[buf][xk[pc] & 0x3fffu];
-        q[0] = ok ? v[0] : 0.f;
-        q[1] = ok ? v[1] : 0.f;
+        q[0] = v[0];
+        q[1] = v[1];
       }
     } else if (pc < NPIECE) {
-      Ds[buf][dslot] = ok ? draw[0] : 0.f;
-      Ds[buf][dslot + 1] = ok ? draw[1] : 0.f;
+      Ds[buf][dslot] = draw[0];
+      Ds[buf][dslot + 1] = draw[1];
     }
   };
 
@@ -682,7 +689,7 @@ bool w4d_applicable(const avsep_conv_desc* d) {
   if (!(d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->dil == 1) || d->up2x || d->C0 != d->Cin) return false;
   if ((d->H & 3) || (d->W & 3) || d->H < 8 || d->W < 8 || d->Ho * 2 != d->H || d->Wo * 2 != d->W) return false;
   if (d->Cin % WW_B || d->Cout < 48 || d->H >= 32768 || d->W >= 32768 || (long long)d->H * d->W >= (1 << 24)) return false;
-  if ((long long)d->N * (d->Cin > d->Cout ? d->Cin : d->Cout) * d->H * d->W >= 0x7fffffffLL) return false;
+  if ((long long)d->N * (d->Cin > d->Cout ? d->Cin : d->Cout) * d->H * d->W >= 0x3fffffffLL) return false;
   const avsep_conv_desc e = plan_desc(d);
   const WwPlan p = w4d_plan(&e);
   return p.cfg < 2 && (long long)p.gridM * p.gridC * p.splits >= 128 && p.nchunks >= 8;
