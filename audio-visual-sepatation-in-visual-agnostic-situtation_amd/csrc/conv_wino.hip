@@ -211,13 +211,7 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
     }
   };
 
-  f32x16 acc[4][2];         // [xi column j][channel block]
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[q][cb][r] = 0.f;
+  f32x16 acc[4][2];         // [xi column j][channel block]; NOT zeroed: the first block's eight MFMAs take C = 0 (256 v_mov less)
 
   // transform row i of B^T:  t = d[rA] + sgn * d[rB]   ((0,2,-) (1,2,+) (2,1,-) (1,3,-))
   const int rA = wi == 0 ? 0 : (wi == 2 ? 2 : 1), rB = wi == 2 ? 1 : (wi == 3 ? 3 : 2);
@@ -241,6 +235,7 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
   // Staging is unconditional (tile indices clamped; the tail re-stages the last tile into a dead buffer): a branch
   // around it would fork the accumulator state.
   const int nK = a.Cin / CK;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float av[2][4][2], v[2][4], tt[4];
   f32x2 bA[2], bB[2];                       // column pairs of the two patch rows of the block being transformed
   auto read_b = [&](int buf, int kp, int which) __attribute__((always_inline)) {
@@ -278,8 +273,9 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
   // Two K-tiles per trip with the LDS buffer index a compile-time constant: with `buf = kt & 1` at run time every LDS
   // access of the loop paid a vector add for `base + buf * size` (about 26 of the 88 vector instructions per 32 MFMAs, and
   // the f32 MFMA does not overlap them).
-  auto ktile = [&](int kt, auto buf_) __attribute__((always_inline)) {
+  auto ktile = [&](int kt, auto buf_, auto first_) __attribute__((always_inline)) {
     constexpr int buf = decltype(buf_)::value;
+    constexpr bool FIRST = decltype(first_)::value;            // the very first K-tile: its first block initialises the accumulators
     const int kt1 = min(kt + 1, nK - 1), kt2 = min(kt + 2, nK - 1);
 #pragma unroll
     for (int kp = 0; kp < CK / 2; ++kp) {
@@ -288,7 +284,8 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const int q = m >> 1, cb = m & 1;
-        acc[q][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][q][cb], v[cur][q], acc[q][cb], 0, 0, 0);
+        if (FIRST && kp == 0) acc[q][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][q][cb], v[cur][q], zero16, 0, 0, 0);
+        else acc[q][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][q][cb], v[cur][q], acc[q][cb], 0, 0, 0);
         if (m < 2) read_b(nbuf, nkp, m);
         if (m >= 2 && m < 6) read_a(nbuf, nkp, nxt, m - 2);
         if (m >= 4) transform(nxt, m - 4);
@@ -305,9 +302,11 @@ __global__ __launch_bounds__(WN_THREADS) void wino_kernel(WArgs a) {
       if (kp == CK / 2 - 2) __syncthreads();
     }
   };
-  for (int kt = 0; kt < nK; kt += 2) {
-    ktile(kt, std::integral_constant<int, 0>{});
-    if (kt + 1 < nK) ktile(kt + 1, std::integral_constant<int, 1>{});
+  ktile(0, std::integral_constant<int, 0>{}, std::true_type{});
+  if (nK > 1) ktile(1, std::integral_constant<int, 1>{}, std::false_type{});
+  for (int kt = 2; kt < nK; kt += 2) {
+    ktile(kt, std::integral_constant<int, 0>{}, std::false_type{});
+    if (kt + 1 < nK) ktile(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
   }
   __syncthreads();          // the last block's operand prefetch has read LDS: drain before the epilogue reuses it
 
