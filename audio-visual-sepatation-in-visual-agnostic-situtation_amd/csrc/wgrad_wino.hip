@@ -293,8 +293,9 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
   //   blocks 4-5 : LDS stores of chunk c+1 (loaded six blocks earlier); barrier after block 6 (the last block that
   //   reads this chunk's buffers); block 7 prefetches from the other buffer; blocks 6-7 : global loads of chunk c+2.
   // Staging is unconditional (chunk indices clamped): a branch around it would fork the accumulator state.
-  for (int c = 0; c < nc; ++c) {
-    const int buf = c & 1;
+  // (two chunks per trip, LDS buffer index a compile-time constant: every LDS address of the loop is base + immediate)
+  auto chunk = [&](int c, auto buf_) __attribute__((always_inline)) {
+    constexpr int buf = decltype(buf_)::value;
     const int c2 = min(c + 2, nc - 1);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -325,6 +326,10 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
       }
       if (ks == 6) __syncthreads();
     }
+  };
+  for (int c = 0; c < nc; c += 2) {
+    chunk(c, std::integral_constant<int, 0>{});
+    if (c + 1 < nc) chunk(c + 1, std::integral_constant<int, 1>{});
   }
   __syncthreads();          // the last block's operand prefetch has read LDS: drain before the epilogue reuses it
 
