@@ -492,13 +492,10 @@ int head_fwd(const avsep_conv_desc* d, const float* wp, int wp_ld, const float* 
   long long nb = (long long)cu_count() * per_cu;
   if (nb > (total + 3) / 4) nb = (total + 3) / 4;
   dim3 g1((unsigned)nb);
-  static bool once = false;
-  if (!once) {
-    const void* fs[4] = {(const void*)head_fwd_gemm_kernel<1, false>, (const void*)head_fwd_gemm_kernel<2, false>,
-                         (const void*)head_fwd_gemm_kernel<1, true>, (const void*)head_fwd_gemm_kernel<2, true>};
-    for (const void* f : fs)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return AVSEP_ERR_LAUNCH;
-    once = true;
+  if (lds > 64 * 1024) {   // set per call for the instantiation about to launch (no process state: any thread, any device)
+    const void* f = MT == 1 ? (generic ? (const void*)head_fwd_gemm_kernel<1, true> : (const void*)head_fwd_gemm_kernel<1, false>)
+                            : (generic ? (const void*)head_fwd_gemm_kernel<2, true> : (const void*)head_fwd_gemm_kernel<2, false>);
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AVSEP_ERR_LAUNCH;
   }
 #define HEAD_FG(MT_, G_) hipLaunchKernelGGL((head_fwd_gemm_kernel<MT_, G_>), g1, dim3(256), lds, st, a, wp, wp_ld, KT, ws)
   if (MT == 1) { if (generic) HEAD_FG(1, true); else HEAD_FG(1, false); }

@@ -41,8 +41,9 @@ _pack_cache = None
 
 
 class pack_scope:
-    """`with pack_scope():` — packed weight images are cached for the duration (Conv.pack).  The caller guarantees that no
-    weight changes inside: train_step_async wraps forward + backward, the optimizer step comes after."""
+    """`with pack_scope():` — packed weight images are cached for the duration (Conv.pack).  train_step_async wraps
+    forward + backward, the optimizer step comes after; an in-place update of a weight inside a scope changes the tensor's
+    version counter, which is part of the cache key, so the image is rebuilt instead of going stale."""
 
     def __enter__(self):
         global _pack_cache
@@ -93,7 +94,7 @@ class Conv:
         d = self.d
         key = None
         if _pack_cache is not None:
-            key = (w.data_ptr(), mode, d.N, d.Cin, d.H, d.W, d.Cout, d.KH, d.KW, d.stride, d.pad, d.dil, d.C0, d.up2x, d.prec,
+            key = (w.data_ptr(), w._version, mode, d.N, d.Cin, d.H, d.W, d.Cout, d.KH, d.KW, d.stride, d.pad, d.dil, d.C0, d.up2x, d.prec,
                    d.plan_n, bool(d.scale0), bool(d.scale1), d.act0, d.act1)
             hit = _pack_cache.get(key)
             if hit is not None:
@@ -253,91 +254,6 @@ def affine_act_bwd_(dz, y, scale, shift, residual, add, mean, invstd, act, bstat
     call("avsep_affine_act_bwd", ptr(dz), ptr(dz2), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift),
          ptr(add), ptr(mean), ptr(invstd), act, N, Cc, y.numel() // (N * Cc), ptr(dst), ptr(bstats))
     return dst
-
-
-# ---- channels-last ([N,C,H,W] tensors with torch.channels_last strides = dense [N*H*W, C]) ----------------------
-def _cl(t):
-    """(M, C) of a dense channels-last 4-D tensor."""
-    lib.ptr_cl(t)
-    return t.numel() // t.shape[1], t.shape[1]
-
-
-def _nhwc_ws(M, Cc, like):
-    nbytes = lib.load().avsep_nhwc_stats_workspace_bytes(M, Cc)
-    return torch.empty((nbytes // 4,), dtype=torch.float32, device=like.device), nbytes
-
-
-def nhwc_channel_stats(x, stats):
-    M, Cc = _cl(x)
-    ws, nbytes = _nhwc_ws(M, Cc, x)
-    call("avsep_nhwc_channel_stats", lib.ptr_cl(x), M, Cc, ptr(stats), ptr(ws), nbytes)
-
-
-def nhwc_bn_train_stats(x, gamma, beta, rmean, rvar, momentum, eps, num_batches_tracked=None):
-    """Train-mode BatchNorm2d statistics of a channels-last tensor + finalisation: rows (scale, shift, mean, invstd);
-    updates the running statistics and (if given) the int64 num_batches_tracked buffer."""
-    M, Cc = _cl(x)
-    ws, nbytes = _nhwc_ws(M, Cc, x)
-    out = _f32((4, Cc), x)
-    call("avsep_nhwc_bn_train_stats", lib.ptr_cl(x), M, Cc, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-         ptr(num_batches_tracked), float(momentum), float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(ws), nbytes)
-    return out
-
-
-def nhwc_affine_act(y, scale, shift, residual, act, res_scale=None, res_shift=None):
-    M, Cc = _cl(y)
-    z = torch.empty_like(y)                       # preserves the channels_last strides
-    call("avsep_nhwc_affine_act", lib.ptr_cl(y), ptr(scale), ptr(shift), lib.ptr_cl(residual), ptr(res_scale),
-         ptr(res_shift), act, M, Cc, lib.ptr_cl(z))
-    return z
-
-
-def nhwc_affine_act_bwd_(dz, y, scale, shift, residual, mean, invstd, act, bstats, res_scale=None, res_shift=None,
-                         stats_only=False, dz2=None, gamma=None, coeffs=False):
-    """dz <- act'(scale*y+shift [+res]) * (dz [+ dz2]) in place (or statistics only); writes bstats.  With `coeffs` the
-    second stage also produces (dgamma, dbeta, pqr) of bn(y) with weight `gamma`, which are returned."""
-    M, Cc = _cl(y)
-    ws, nbytes = _nhwc_ws(M, Cc, y) if (bstats is not None or coeffs) else (None, 0)
-    dgamma = dbeta = pqr = None
-    if coeffs:
-        dgamma, dbeta, pqr = _f32((Cc,), y), _f32((Cc,), y), _f32((3, Cc), y)
-    call("avsep_nhwc_affine_act_bwd", lib.ptr_cl(dz), lib.ptr_cl(dz2), lib.ptr_cl(y), ptr(scale), ptr(shift), lib.ptr_cl(residual),
-         ptr(res_scale), ptr(res_shift), ptr(mean), ptr(invstd), act, M, Cc, None if stats_only else lib.ptr_cl(dz),
-         ptr(bstats), ptr(gamma), ptr(dgamma), ptr(dbeta), ptr(pqr), ptr(ws), nbytes)
-    return (dgamma, dbeta, pqr) if coeffs else dz
-
-
-def nhwc_bn_bwd_apply_(dz, y, pqr, out=None):
-    M, Cc = _cl(y)
-    dst = dz if out is None else out
-    call("avsep_nhwc_bn_bwd_apply", lib.ptr_cl(dz), lib.ptr_cl(y), ptr(pqr), M, Cc, lib.ptr_cl(dst))
-    return dst
-
-
-def nhwc_maxpool_bn_relu(y, scale, shift):
-    """MaxPool2d(3,2,1) of relu(scale*y+shift), channels-last, activated map never materialised -> (pooled, taps)."""
-    M, Cc = _cl(y)
-    N, _, H, W = y.shape
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=y.device).contiguous(memory_format=torch.channels_last)
-    taps = torch.empty((N * Ho * Wo * (Cc // 4),), dtype=torch.int32, device=y.device)
-    call("avsep_nhwc_maxpool_bn_relu_fwd", lib.ptr_cl(y), ptr(scale), ptr(shift), N, H, W, Cc, lib.ptr_cl(out), ptr(taps))
-    return out, taps
-
-
-def nhwc_maxpool_bn_relu_bwd(g, taps, y, bnrow, gamma):
-    """Backward of nhwc_maxpool_bn_relu + the stem BatchNorm: returns (dgamma, dbeta, dy)."""
-    M, Cc = _cl(y)
-    _cl(g)
-    N, _, H, W = y.shape
-    ws, nbytes = _nhwc_ws(M, Cc, y)
-    dgamma, dbeta, pqr = _f32((Cc,), y), _f32((Cc,), y), _f32((3, Cc), y)
-    args = (lib.ptr_cl(g), ptr(taps), lib.ptr_cl(y), ptr(bnrow[0]), ptr(bnrow[1]), ptr(bnrow[2]), ptr(bnrow[3]), ptr(gamma),
-            N, H, W, Cc, ptr(dgamma), ptr(dbeta), ptr(pqr))
-    call("avsep_nhwc_maxpool_bn_relu_bwd", *args, None, ptr(ws), nbytes)
-    dy = torch.empty_like(y)
-    call("avsep_nhwc_maxpool_bn_relu_bwd", *args, lib.ptr_cl(dy), ptr(ws), nbytes)
-    return dgamma, dbeta, dy
 
 
 class Cat:

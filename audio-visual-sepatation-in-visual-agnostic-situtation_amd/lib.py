@@ -63,15 +63,6 @@ SIGNATURES = {
     "avsep_bn_finalize": (C.c_int, [_P, _D, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "avsep_bn_bwd_coeffs": (C.c_int, [_P, _D, _P, _P, _P, _I, _P, _P, _P, _P]),
     "avsep_bn_bwd_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
-    "avsep_nhwc_stats_workspace_bytes": (C.c_size_t, [C.c_int64, _I]),
-    "avsep_nhwc_channel_stats": (C.c_int, [_P, C.c_int64, _I, _P, _P, _Z, _P]),
-    "avsep_nhwc_affine_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, C.c_int64, _I, _P, _P]),
-    "avsep_nhwc_bn_train_stats": (C.c_int, [_P, C.c_int64, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
-    "avsep_nhwc_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, C.c_int64, _I, _P, _P, _P, _P, _P,
-                                            _P, _P, _Z, _P]),
-    "avsep_nhwc_bn_bwd_apply": (C.c_int, [_P, _P, _P, C.c_int64, _I, _P, _P]),
-    "avsep_nhwc_maxpool_bn_relu_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
-    "avsep_nhwc_maxpool_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "avsep_affine_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "avsep_relu_up2x_fwd": (C.c_int, [_KD, _P, _P]),
@@ -131,14 +122,6 @@ def ptr(t):
     if t is None:
         return None
     assert t.is_contiguous(), "avsep kernels take dense tensors"
-    return t.data_ptr()
-
-
-def ptr_cl(t):
-    """Base pointer of a dense channels-last ([N,H,W,C] storage) tensor, for the avsep_nhwc_* entry points."""
-    if t is None:
-        return None
-    assert t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last), "expected a dense channels_last tensor"
     return t.data_ptr()
 
 

@@ -1,28 +1,21 @@
 """Per-frame visual encoder (reference: models/vision_net.py:20-147 + torchvision resnet18).
 
-Three backends for the ResNet-18 trunk + fc conv, selected by ``net.backend`` (default from the environment
-variable AVSEP_VISION_BACKEND, else "hip"), all over the same parameter tensors:
-  "hip"    : the whole trunk on libavsep_gfx950.so (models/vision_hip.py) — the default: the full-HIP path of
-             BASELINE.json configs[2], in fp32 or with bf16 conv operands (kernels.set_precision);
-  "hybrid" : MIOpen's NHWC convolutions (BASELINE.json configs[1]: "vision on PyTorch-ROCm") with everything between
-             them — BatchNorm statistics, normalise + residual + ReLU and their backward — on this library's
-             channels-last kernels, as one autograd node (models/vision_hybrid.py); in fp32 MIOpen's convolutions are
-             still ~25 % faster than this library's on the ResNet shapes, so it is kept for comparison runs;
-  "torch"  : the plain PyTorch-ROCm module graph (MIOpen convolutions and BatchNorm, ATen elementwise).
-The temporal mean that feeds the fusion is a HIP kernel in every case.
+The ResNet-18 trunk + fc conv run on libavsep_gfx950.so as ONE autograd node (models/vision_hip.py), in fp32 or with bf16
+conv operands (kernels.set_precision): the full-HIP path of BASELINE.json configs[2].  There is no other backend in the
+package; the MIOpen comparison runs of DESIGN.md live in tools/miopen_compare/ (they patch an instance, nothing here
+dispatches on an environment variable).
+The temporal mean that feeds the fusion is a HIP kernel.
 torchvision is not part of this image, so the standard ResNet-18 architecture is restated here
 with torchvision's child order, which keeps the reference's ``features.{0,1,4..7}.*`` /
 ``fc.*`` checkpoint keys.  ``pretrained=True`` (models/__init__.py:63) cannot be honoured
 offline: weights are PyTorch's default init unless a checkpoint is loaded.
 """
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import kernels as K
-from . import vision_hip, vision_hybrid
+from . import vision_hip
 
 
 class BasicBlock(nn.Module):
@@ -65,23 +58,14 @@ class _TemporalMean(torch.autograd.Function):
 
 
 class _VisualBase(nn.Module):
-    backend = os.environ.get("AVSEP_VISION_BACKEND", "hip")
+    backend = "hip"
 
     def _trunk(self, x):
         """fc(features(x)) for x [N,3,H,W]."""
-        if self.backend == "hip":
-            return vision_hip.run(self, x)
-        if self.backend == "hybrid":
-            return vision_hybrid.run(self, x)
-        if self.backend != "torch":
-            raise Exception("Unknown vision backend: " + str(self.backend))
-        return self.fc(self.features(self._nhwc(x)))
-
-    @staticmethod
-    def _nhwc(x):
-        # On the GPU the frames are handed to MIOpen channels-last: its fp32 implicit-GEMM solvers are NHWC and
-        # otherwise wrap every conv in transposes (measured -12 % on the visual step).  Values are unchanged.
-        return x.contiguous(memory_format=torch.channels_last) if x.is_cuda else x
+        if self.backend != "hip":
+            raise Exception("Unknown vision backend: " + str(self.backend) + " (the package has the HIP trunk only; "
+                            "MIOpen comparison runs: tools/miopen_compare)")
+        return vision_hip.run(self, x)
 
     def forward(self, x, pool=True):
         x = self._trunk(x)

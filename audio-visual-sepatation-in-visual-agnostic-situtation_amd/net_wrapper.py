@@ -179,11 +179,14 @@ class FlatSGD:
     ALIGN = 64      # elements: 256 bytes
 
     def __init__(self, groups, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1, overlap=None,
-                 require_gpu=True):
-        """`require_gpu=False` only skips the device check so that the bucket / all-reduce logic (`reduce_gradients`) can be
+                 require_gpu=True, force_collective=False):
+        """`force_collective`: issue the early + late all-reduce even at world size 1 (a 1-rank RCCL group on a one-GPU
+        box: the collectives, their stream order against the step's kernels and the hooks run exactly as on N ranks).
+        `require_gpu=False` only skips the device check so that the bucket / all-reduce logic (`reduce_gradients`) can be
         exercised on CPU tensors over gloo (tests/test_dp_gloo.py); `step()` itself has no CPU path."""
         self.momentum, self.weight_decay = momentum, weight_decay
         self.world_size, self.process_group = world_size, process_group
+        self._dist = world_size > 1 or bool(force_collective)
         # Data parallel: the first group's gradients (the U-Net: 130 MB of the 180 MB) are complete as soon as its
         # autograd node has run, i.e. BEFORE the visual trunk's backward (~30 ms) starts: their all-reduce is issued
         # right there (asynchronously, RCCL's own stream) and overlaps that backward; step() reduces the rest.
@@ -196,8 +199,7 @@ class FlatSGD:
         params = []
         for g in groups:
             ps = [p for p in g["params"] if p.requires_grad]
-            self.param_groups.append({"params": ps, "lr": g["lr"], "name": g.get("name", str(len(self.param_groups))),
-                                      "channels_last": bool(g.get("channels_last", False))})
+            self.param_groups.append({"params": ps, "lr": g["lr"], "name": g.get("name", str(len(self.param_groups)))})
             params += ps
         if not params:
             raise ValueError("no parameters")
@@ -218,25 +220,15 @@ class FlatSGD:
             g["range"] = [off, off]
             for p in g["params"]:
                 n = p.numel()
-                if g["channels_last"] and p.dim() == 4:
-                    # conv weights of a module that runs on MIOpen's NHWC kernels: keep them OHWI inside the flat
-                    # buffers (a channels_last-strided view), or MIOpen transposes every weight on every call
-                    O, I, KH, KW = p.shape
-                    view = lambda flat: flat[off:off + n].view(O, KH, KW, I).permute(0, 3, 1, 2)   # noqa: E731
-                    view(self.flat_param).copy_(p.data)
-                    p.data = view(self.flat_param)
-                    gv = view(self.flat_grad)
-                else:
-                    self.flat_param[off:off + n].copy_(p.data.reshape(-1))
-                    p.data = self.flat_param[off:off + n].view_as(p.data)
-                    gv = self.flat_grad[off:off + n].view_as(p.data)
+                self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[off:off + n].view_as(p.data)
+                gv = self.flat_grad[off:off + n].view_as(p.data)
                 p.grad = gv
                 self._views.append((p, gv))
-                if gv.is_contiguous():
-                    self._slot[p] = gv
+                self._slot[p] = gv
                 off += (n + A - 1) // A * A
             g["range"][1] = off
-        if self.world_size > 1 and self.overlap:
+        if self._dist and self.overlap:
             for p in self.param_groups[0]["params"]:
                 p.register_post_accumulate_grad_hook(self._on_first_group_grad)
 
@@ -322,7 +314,7 @@ class FlatSGD:
         autograd has been accumulated (AccumulateGrad runs once per leaf and backward, then the post-accumulate hook);
         parameters whose gradient the kernels placed directly (grad_dest) and no node returned need no hook.  Nodes that
         do not report (plain torch modules): the hooks alone count, as before."""
-        if self.world_size > 1 and self.overlap and accumulations > 0:
+        if self._dist and self.overlap and accumulations > 0:
             self._armed = True
             self._pending = set(self.param_groups[0]["params"])
             self._nodes_left = accumulations if self._reports else 0
@@ -339,42 +331,65 @@ class FlatSGD:
                 gv.copy_(p.grad)
             p.grad = gv
 
-    def _relayout(self, flat, to_logical):
-        """Copy of a flat buffer with every conv weight of the channels-last groups moved between the OHWI order it
-        has inside the flat buffers and the logical OIHW order (`to_logical`), or back."""
-        out = flat.clone()
-        off = 0
+    def _offsets(self, align):
+        """Start of every parameter inside a flat buffer whose tensors are padded to `align` elements."""
+        offs, off = [], 0
         for g in self.param_groups:
             for p in g["params"]:
-                n = p.numel()
-                if g["channels_last"] and p.dim() == 4:
-                    O, I, KH, KW = p.shape
-                    seg = flat[off:off + n]
-                    out[off:off + n] = (seg.view(O, KH, KW, I).permute(0, 3, 1, 2) if to_logical
-                                        else seg.view(O, I, KH, KW).permute(0, 2, 3, 1)).reshape(-1)
-                off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
-        return out
+                offs.append(off)
+                off += (p.numel() + align - 1) // align * align
+        return offs, off
 
     def state_dict(self):
-        """Momentum buffers + per-group lr / started flags (what torch.optim.SGD.state_dict carries, flat).  The
-        momentum is saved in LOGICAL (OIHW) order whatever layout the visual backend keeps inside the flat buffers,
-        so a run resumed under another AVSEP_VISION_BACKEND loads the right values."""
-        return {"momentum_buffer": self._relayout(self.flat_buf.detach(), True).cpu(), "layout": "oihw",
+        """What torch.optim.SGD.state_dict carries, independent of this class's buffer layout: one momentum tensor per
+        parameter in its logical shape (group order, then parameter order), plus per-group lr / started flags."""
+        offs, _ = self._offsets(self.ALIGN)
+        params = [p for g in self.param_groups for p in g["params"]]
+        buf = self.flat_buf.detach()
+        return {"format": 2,
+                "momentum": [buf[o:o + p.numel()].view(p.shape).cpu().clone() for o, p in zip(offs, params)],
                 "groups": [{"name": g["name"], "lr": g["lr"], "started": bool(g.get("started", False)),
-                            "range": list(g["range"])} for g in self.param_groups]}
+                            "numel": sum(p.numel() for p in g["params"])} for g in self.param_groups]}
 
     def load_state_dict(self, state):
-        if [g["range"] for g in state["groups"]] != [list(g["range"]) for g in self.param_groups]:
-            raise ValueError("optimizer state does not match the parameter groups")
-        buf = state["momentum_buffer"].to(self.flat_buf.device)
-        if state.get("layout") == "oihw":
-            buf = self._relayout(buf, False)
-        elif any(g["channels_last"] for g in self.param_groups):
-            raise ValueError("optimizer state without a layout tag (written before the layout was recorded) cannot be "
-                             "loaded into channels-last groups: resume with AVSEP_VISION_BACKEND=hip or retrain")
-        self.flat_buf.copy_(buf)
-        for g, s in zip(self.param_groups, state["groups"]):
-            g["lr"], g["started"] = s["lr"], s["started"]
+        """Accepts the per-parameter format above and the two flat layouts earlier builds wrote (`momentum_buffer` with
+        group `range`s: unpadded, or padded to 64 elements).  Returns True when the momentum was restored; on a blob
+        that matches neither (another architecture, another ALIGN) it warns, keeps zero momentum and restores only the
+        per-group lr / started flags where the group names agree — a history-only resume instead of a crash."""
+        import warnings
+        params = [p for g in self.param_groups for p in g["params"]]
+        offs, _ = self._offsets(self.ALIGN)
+        ok = False
+        if state.get("format") == 2:
+            mom = state["momentum"]
+            ok = len(mom) == len(params) and all(tuple(m.shape) == tuple(p.shape) for m, p in zip(mom, params))
+            if ok:
+                for o, p, m in zip(offs, params, mom):
+                    self.flat_buf[o:o + p.numel()].copy_(m.reshape(-1).to(self.flat_buf.device))
+        elif "momentum_buffer" in state:
+            flat = state["momentum_buffer"]
+            for align in (self.ALIGN, 1):
+                src, total = self._offsets(align)
+                ends, off = [], 0
+                for g in self.param_groups:
+                    beg = off
+                    off += sum((p.numel() + align - 1) // align * align for p in g["params"])
+                    ends.append([beg, off])
+                if flat.numel() == total and [list(g["range"]) for g in state["groups"]] == ends:
+                    for o, so, p in zip(offs, src, params):
+                        self.flat_buf[o:o + p.numel()].copy_(flat[so:so + p.numel()].to(self.flat_buf.device))
+                    ok = True
+                    break
+        if not ok:
+            warnings.warn("optimizer state does not match the parameter groups (written by another build or for another "
+                          "architecture): momentum starts from zero, learning rates are restored by group name")
+        by_name = {s["name"]: s for s in state.get("groups", [])}
+        for g in self.param_groups:
+            s = by_name.get(g["name"])
+            if s is not None:
+                g["lr"] = s["lr"]
+                g["started"] = bool(s["started"]) and ok
+        return ok
 
     def reduce_gradients(self, only=None):
         """The data-parallel half of step(): fold stray .grad tensors back into the flat buffer, wait for the early
@@ -384,7 +399,7 @@ class FlatSGD:
         active = [g for g in self.param_groups
                   if (only is None or g["name"] in only) and g["range"][1] > g["range"][0] and not g.get("no_grad")]
         scale = 1.0
-        if self.world_size > 1 and active:
+        if self._dist and active:
             import torch.distributed as dist
             rest = active
             if self._early is not None:                     # the first group is already being reduced
@@ -418,16 +433,16 @@ def attach_grad_sink(opt, *nets):
     return opt
 
 
-def create_optimizer(nets, args, process_group=None, world_size=1):
+def create_optimizer(nets, args, process_group=None, world_size=1, force_collective=False):
     (net_sound, net_frame) = nets
-    nhwc = getattr(net_frame, "backend", None) in ("torch", "hybrid")   # the MIOpen paths want OHWI conv weights
     groups = [{"params": list(net_sound.parameters()), "lr": args.lr_sound, "name": "sound"},
-              {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound, "name": "frame_fc", "channels_last": nhwc}]
+              {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound, "name": "frame_fc"}]
     if not args.fix_vis:
         groups.append({"params": list(net_frame.features.parameters()), "lr": args.lr_frame,
-                       "name": "frame_features", "channels_last": nhwc})
+                       "name": "frame_features"})
     return attach_grad_sink(FlatSGD(groups, momentum=args.beta1, weight_decay=args.weight_decay,
-                                    process_group=process_group, world_size=world_size), net_sound, net_frame)
+                                    process_group=process_group, world_size=world_size,
+                                    force_collective=force_collective), net_sound, net_frame)
 
 
 def adjust_learning_rate(optimizer, args):

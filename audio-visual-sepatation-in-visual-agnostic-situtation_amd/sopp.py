@@ -136,14 +136,12 @@ def create_optimizer(nets, args, process_group=None, world_size=1):
     """SoP++/main.py:593-606: SGD groups (sound, lr_sound), (synthesizer, lr_synthesizer), (attention module,
     lr_synthesizer) and, unless --fix_vis, (frame features, lr_frame), (frame fc, lr_sound) — as one FlatSGD."""
     net_sound, net_frame, net_synthesizer, net_pit = nets
-    nhwc = getattr(net_frame, "backend", None) in ("torch", "hybrid")
     groups = [{"params": list(net_sound.parameters()), "lr": args.lr_sound, "name": "sound"},
               {"params": list(net_synthesizer.parameters()), "lr": args.lr_synthesizer, "name": "synthesizer"},
               {"params": list(net_pit.parameters()), "lr": args.lr_synthesizer, "name": "pit"}]
     if not args.fix_vis:
-        groups += [{"params": list(net_frame.features.parameters()), "lr": args.lr_frame, "name": "frame_features",
-                    "channels_last": nhwc},
-                   {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound, "name": "frame_fc", "channels_last": nhwc}]
+        groups += [{"params": list(net_frame.features.parameters()), "lr": args.lr_frame, "name": "frame_features"},
+                   {"params": list(net_frame.fc.parameters()), "lr": args.lr_sound, "name": "frame_fc"}]
     groups = [g for g in groups if any(p.requires_grad for p in g["params"])]     # AttModel / Bias may hold no parameters
     return FlatSGD(groups, momentum=args.beta1, weight_decay=args.weight_decay, process_group=process_group,
                    world_size=world_size)

@@ -103,9 +103,15 @@ def main(args):
                                         extra_size=args.num_channels)
         net_syn = builder.build_synthesizer(arch=args.arch_synthesizer, fc_dim=args.num_channels, weights=args.weights_synthesizer)
         net_pit = get_attmodule(args)(att_type=args.att_type)
-        if getattr(args, "weights_net_pit", ""):
+        pit_path = getattr(args, "weights_net_pit", "")
+        if pit_path and not os.path.exists(pit_path) and pit_path.endswith("net_pit_best.pth"):
+            # a checkpoint directory written by the reference holds net_pit_latest.pth only (SoP++/main.py:630-631)
+            alt = pit_path[:-len("best.pth")] + "latest.pth"
+            pit_path = alt if os.path.exists(alt) else ""
+            print("net_pit_best.pth is missing: " + ("using net_pit_latest.pth" if pit_path else "attention module keeps its init"))
+        if pit_path:
             print("Loading weights for net_pit")
-            net_pit.load_state_dict(torch.load(args.weights_net_pit))
+            net_pit.load_state_dict(torch.load(pit_path, map_location="cpu"))
         nets = (net_sound.to(device), net_frame.to(device), net_syn.to(device), net_pit.to(device))
         wrapper = sopp.NetWrapper(nets, builder.build_criterion(arch=args.loss, use_pit=True), builder.build_criterion(arch=args.loss))
         optimizer = sopp.create_optimizer(nets, args, world_size=world)

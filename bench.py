@@ -11,7 +11,8 @@ main.py:557-569).  Inputs are resident in HBM before the timed region.  The refe
 the headline arithmetic; the same run then times, outside the headline's timed region and explicitly labelled:
   * "bf16": configs[2] as BASELINE.json names it — bf16 conv operands (rounded while they are staged into LDS), fp32
     accumulation / BatchNorm statistics / loss / master weights / SGD — with the loss difference to the fp32 path;
-  * "f32_miopen_hybrid": round 1's configs[1] path (visual convolutions on PyTorch-ROCm/MIOpen), for comparison only;
+  * with --compare-miopen only: "f32_miopen_hybrid", round 1's configs[1] path (visual convolutions on PyTorch-ROCm /
+    MIOpen through tools/miopen_compare, which patches the trunk of that one model instance), for comparison;
   * the audio-only step and the 1:1 AV/AO alternation the shipped flags produce.
 
 Launch: python bench.py --gpus N --steps K --warmup W.  With N > 1 and no WORLD_SIZE in the environment bench.py
@@ -63,7 +64,10 @@ def build(P, dev, seed, backend, config=3):
     frm = mb.build_frame(arch=a.arch_frame, fc_dim=a.vis_channels, pool_type=a.img_pool, weights="")
     crit_ao, crit_av = mb.build_criterion(a.loss, use_pit=True), mb.build_criterion(a.loss)
     snd, frm = snd.to(dev), frm.to(dev)
-    frm.backend = backend
+    if backend != "hip":                         # comparison runs only: the package itself has the HIP trunk and nothing else
+        sys.path.insert(0, os.path.join(ROOT, "tools", "miopen_compare"))
+        import backend as miopen_backend
+        miopen_backend.install(frm, backend)
     return a, snd, frm, P.NetWrapper((snd, frm), crit_ao, crit_av)
 
 
@@ -224,7 +228,9 @@ def self_launch(o):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    # dmabuf IPC: this pool's host driver supports no legacy IPC handles (the image exports the variable already; a
+    # launcher that builds its own env must keep it — cross-process RCCL cannot be exercised on a one-GPU box)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // o.gpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={o.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -275,12 +281,12 @@ def rehearse(o):
         dist.destroy_process_group()
 
 
-def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer=None, use_vis=True, config=3):
+def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer=None, use_vis=True, config=3, force=False):
     """Build the model from `seed`, run `warmup` untimed + `steps` timed train steps; returns the measurements."""
     import torch.distributed as dist
     P.kernels.set_precision(prec)
     a, snd, frm, wrap = build(P, dev, seed, backend, config)
-    opt = P.create_optimizer((snd, frm), a, world_size=world)
+    opt = P.create_optimizer((snd, frm), a, world_size=world, force_collective=force)
     raw = P.synth.make_batch(B, a.num_mix, a.num_frames, 224, a.audLen, seed=seed + 1 + rank, device=dev)
 
     def batch():
@@ -312,9 +318,17 @@ def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer
     dt = t.item()
     active = [g for g in opt.param_groups if use_vis or g["name"] == "sound"]
     res = {"value": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "loss": float(err),
-           "allreduce_bytes_per_step": 4 * sum(g["range"][1] - g["range"][0] for g in active) if world > 1 else 0,
+           "allreduce_bytes_per_step": 4 * sum(g["range"][1] - g["range"][0] for g in active) if (world > 1 or force) else 0,
+           "early_allreduces": opt.early_reductions,
            "match_loss": float(match) if match is not None else None,
            "first_step_loss": first[0] if first else None, "first_step_match_loss": first[1] if first else None}
+    if force:            # the step's one buffer through RCCL on its own (the collective's cost without overlap)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(opt.flat_grad)
+        sync()
+        res["allreduce_ms"] = (time.perf_counter() - t1) * 100.0
     del wrap, opt, snd, frm, raw
     gc.collect()
     torch.cuda.empty_cache()
@@ -394,7 +408,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (configs[2]: 64)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"], help="arithmetic of the HEADLINE run")
-    ap.add_argument("--backend", default="hip", choices=["hip", "hybrid", "torch"], help="visual trunk of the headline run")
+    ap.add_argument("--backend", default="hip", choices=["hip"], help="visual trunk of the headline run (this library)")
+    ap.add_argument("--compare-miopen", action="store_true", help="also time the step with the visual convolutions on MIOpen "
+                    "(tools/miopen_compare; comparison only, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--no-instrumented", action="store_true", help="profiling runs under rocprofv3: only the un-instrumented "
@@ -405,6 +421,8 @@ def main():
     ap.add_argument("--rehearse", action="store_true", help="launcher / rendezvous / all-reduce rehearsal without a train step "
                     "(runs on CPU ranks over gloo too); prints a line marked \"rehearsal\": true")
     ap.add_argument("--rehearse-elems", type=int, default=0, help="elements of the rehearsal's flat buffer (default: the step's)")
+    ap.add_argument("--force-collective", action="store_true", help="--gpus 1 only: create a 1-rank RCCL group and issue the "
+                    "step's early + late gradient all-reduce anyway; the line carries allreduce_ms and the no-collective time")
     o = ap.parse_args()
 
     if o.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -413,7 +431,10 @@ def main():
         return rehearse(o)
 
     import avsep_amd as P
-    rank, world, dev = P.dp.init_from_env()
+    if o.force_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+    rank, world, dev = P.dp.init_from_env(force=o.force_collective)
     if world != o.gpus:
         raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}")
     if dev.type != "cuda":
@@ -423,6 +444,21 @@ def main():
     seed, B = 1234, o.batch
     if o.config == 5:
         B = min(B, CONFIG5_BATCH)
+    if o.force_collective:
+        # RCCL readiness line (one GPU): the same step with and without the collectives of the N > 1 path
+        plain = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup, config=o.config)
+        forced = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup, config=o.config, force=True)
+        print(json.dumps({"metric": "mixtures/sec (train step, 2-src MUSIC shape)", "value": forced["value"], "unit": "mixtures/s",
+                          "n_gpus": 1, "steps": o.steps, "warmup": o.warmup, "ms_per_step": forced["ms_per_step"],
+                          "ms_per_step_no_collective": plain["ms_per_step"], "allreduce_ms": forced["allreduce_ms"],
+                          "allreduce_bytes_per_step": forced["allreduce_bytes_per_step"],
+                          "early_allreduces": forced["early_allreduces"], "backend": dist.get_backend(),
+                          "loss": forced["loss"], "loss_no_collective": plain["loss"], "dtype": o.precision,
+                          "config": {"workload": "headline step at batch %d with a 1-rank RCCL group: early U-Net all-reduce + late "
+                                                 "visual all-reduce forced (FlatSGD force_collective)" % B}}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # headline: un-instrumented.  Then the same configuration once more with HIP-event pairs around every conv launch
     head = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup, config=o.config)
     if o.no_instrumented:
@@ -459,9 +495,10 @@ def main():
                               "loss / master weights / SGD (BASELINE configs[2])" if other == "bf16" else "same step in fp32",
                   "by_kernel": {k: {"ms_per_step": round(v["ms_per_step"], 3), "tflops": round(v["tflops"], 1)} for k, v in k2.items()}})
         extras[other] = r
-        hyb = run_config(P, dev, world, seed, rank, "f32", "hybrid", B, max(3, o.steps // 2), 2, config=o.config)
-        extras["f32_miopen_hybrid"] = dict(hyb, workload="round-1 configs[1] path at the headline batch %d: visual convolutions on "
-                                           "PyTorch-ROCm/MIOpen, HIP BatchNorm glue; comparison only, not this build's kernels" % B)
+        if o.compare_miopen:
+            hyb = run_config(P, dev, world, seed, rank, "f32", "hybrid", B, max(3, o.steps // 2), 2, config=o.config)
+            extras["f32_miopen_hybrid"] = dict(hyb, workload="round-1 configs[1] path at the headline batch %d: visual convolutions "
+                                               "on PyTorch-ROCm/MIOpen, HIP BatchNorm glue; comparison only, not this build's kernels" % B)
         ao = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, max(3, o.steps // 2), 2, use_vis=False, config=o.config)
         extras["ao_step_mixtures_per_s"] = ao["value"]
         extras["av_ao_1to1_blend_mixtures_per_s"] = 2.0 / (1.0 / head["value"] + 1.0 / ao["value"])
@@ -471,9 +508,7 @@ def main():
     if rank == 0:
         roof, roof_step, hbm = roofline_of(kernels, o.precision, head["ms_per_step"], B)
         add_traffic(roof, o.precision, B)
-        vis = {"hip": "visual trunk on this library (no MIOpen kernel in the step)",
-               "hybrid": "visual convolutions on PyTorch-ROCm/MIOpen with HIP BatchNorm/ReLU glue",
-               "torch": "visual trunk on PyTorch-ROCm"}[o.backend]
+        vis = "visual trunk on this library (no MIOpen kernel in the step)"
         out = {
             "metric": "mixtures/sec (train step, 2-src MUSIC shape)", "value": head["value"],
             "unit": "mixtures/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,

@@ -387,6 +387,28 @@ def gen_step(ref_main):
                 out[f"final.{pre}.{k}.abs"] = p.double().abs().sum().reshape(1)
     out["final.sound.last_w"] = rs.state_dict()["unet_block.up_forward.2.weight"]
     out["final.frame.fc_b"] = rf.state_dict()["fc.bias"]
+    # The MixVis step (main.py:150-156 -> forward_avmiximg, :162-192) as SHIPPED: main.py:181 hands PitWrapper the
+    # un-stacked [B,1,F,T] weight.  Execute it through the reference's own NetWrapper.forward and record what happens,
+    # so that the oracle's repair (oracle/step.py forward_avmiximg: forward_ao's per-target stacking) rests on a fixture
+    # and not on a comment.
+    import models.audio_net as RA
+    torch.manual_seed(seed)
+    rs_mv = RA.Unet(fc_dim=2, num_downs=5, ngf=8, fusion_type="MixVis", att_type="sig")
+    O.wide_init(rs_mv, torch.Generator().manual_seed(seed))
+    margs = make_args(log_freq=0, fusion_type="MixVis")
+    ref_main.args = margs
+    rw_mv = ref_main.NetWrapper((rs_mv, rf), RC.PitWrapper(F.binary_cross_entropy), RC.BCELoss())
+    rw_mv.train()
+    exc = None
+    try:
+        rw_mv.forward(clone_batch(), margs, True)
+    except Exception as e:                              # noqa: BLE001 (whatever the reference raises is the datum)
+        exc = e
+    out["mixvis.raised"] = np.array([exc is not None])
+    out["mixvis.exc_type"] = np.frombuffer((type(exc).__name__ if exc is not None else "").encode(), dtype=np.uint8).copy()
+    out["mixvis.exc_msg"] = np.frombuffer((str(exc) if exc is not None else "").encode(), dtype=np.uint8).copy()
+    print("reference forward_avmiximg as shipped:", type(exc).__name__ if exc is not None else "ran", "-", str(exc)[:200])
+    ref_main.args = args
     save("step", out)
 
 

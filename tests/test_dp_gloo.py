@@ -144,3 +144,80 @@ def test_shard_range_errors():
         assert False
     except ValueError:
         pass
+
+
+def _reporting_worker(rank, world, port, out):
+    """Two gloo ranks driving FlatSGD the way the real networks do: ParamGrads nodes that PLACE gradients (grad_dest /
+    scratch_dest / finish -> node_finished) plus one parameter handed back to autograd, with arm_early_reduce(1 | 2)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import avsep_amd as P
+    from avsep_amd.net_wrapper import FlatSGD, attach_grad_sink
+    from avsep_amd.models.audio_net import ParamGrads
+    P.dp.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    snd = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1))
+    vis = torch.nn.Conv2d(3, 2, 1)
+    sp, vp = list(snd.parameters()), list(vis.parameters())
+    opt = FlatSGD([{"params": sp, "lr": 1e-3, "name": "sound"}, {"params": vp, "lr": 1e-3, "name": "frame_fc"}],
+                  world_size=world, overlap=True, require_gpu=False)
+    attach_grad_sink(opt, snd, vis)
+    assert opt._reports
+    gen = torch.Generator().manual_seed(100 + rank)
+    res = []
+
+    class Node(torch.autograd.Function):
+        """One autograd node owning `params`: backward places every gradient but `returned` (handed back to autograd)."""
+        @staticmethod
+        def forward(ctx, net, group, grads, returned, x, *params):
+            ctx.args = (net, group, grads, returned, params)
+            return x.sum() * 0.0 + sum((p * 0).sum() for p in params)
+
+        @staticmethod
+        def backward(ctx, dy):
+            net, group, grads, returned, params = ctx.args
+            pg = ParamGrads(net)
+            early_before = opt.early_reductions
+            for i, p in enumerate(params):
+                if i in returned:
+                    pg.d[p] = grads[i].clone()             # handed back: AccumulateGrad + the post-accumulate hook follow
+                else:
+                    pg.add(p, grads[i].clone())
+            out = pg.finish(list(params), group)
+            assert opt.early_reductions == early_before or group == "sound"
+            return (None, None, None, None, None, *out)
+    for nodes in (1, 2):
+        opt.zero_grad()
+        x = torch.zeros(1, requires_grad=True)
+        per_node = [[torch.randn(p.shape, generator=gen) for p in sp] for _ in range(nodes)]
+        gv = [torch.randn(p.shape, generator=gen) for p in vp]
+        loss = sum(Node.apply(snd, "sound", per_node[k], {1} if k == 0 else set(), x, *sp) for k in range(nodes))
+        loss = loss + Node.apply(vis, "frame_fc", gv, set(), x, *vp)
+        opt.arm_early_reduce(nodes)
+        before = opt.early_reductions
+        loss.backward()
+        started_early = opt.early_reductions - before
+        active, scale = opt.reduce_gradients(None)
+        local = [sum(per_node[k][i] for k in range(nodes)) for i in range(len(sp))] + gv
+        res.append({"early": started_early, "local": torch.cat([t.reshape(-1) for t in local]),
+                    "reduced": torch.cat([(g_ * scale).reshape(-1) for _, g_ in opt._views])})
+    torch.save(res, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_allreduce_with_reporting_nodes_over_two_gloo_ranks(tmp_path):
+    """FlatSGD.node_finished / _pending / _nodes_left with REPORTING nodes (attach_grad_sink: the networks' ParamGrads
+    place gradients themselves and report): with one and with two U-Net nodes per step, one parameter of the first node
+    handed back to autograd, the early all-reduce of the first group starts exactly once per step — after the LAST node
+    and after the handed-back gradient was accumulated — and every rank's flat gradient equals the mean over the ranks."""
+    sys.path.insert(0, ROOT)
+    port, out = _free_port(), str(tmp_path / "rep")
+    mp.spawn(_reporting_worker, args=(2, port, out), nprocs=2, join=True)
+    res = [torch.load(out + f".{r}") for r in range(2)]
+    for step in range(2):
+        mean = (res[0][step]["local"] + res[1][step]["local"]) / 2
+        for r in range(2):
+            assert res[r][step]["early"] == 1, (step, r, res[r][step]["early"])
+            assert torch.allclose(res[r][step]["reduced"], mean, atol=1e-6), (step, r)

@@ -3,6 +3,7 @@ reference (tests/golden/*.npz) and against the CPU oracle on seeded inputs.
 Tolerances (stated per assert) are fp32 summation-order noise through 10-14 conv layers with
 train-mode BatchNorm; the north-star bound is mask MSE <= 1e-4."""
 import argparse
+import math
 
 import pytest
 import torch
@@ -485,7 +486,7 @@ def test_shared_encoder_pair_equals_two_passes(dev, golden):
         assert_close(a["b"][k].double(), b["b"][k].double(), 1e-6, "buffer " + k)
 
 
-@pytest.mark.parametrize("log_freq,backend", [(1, "torch"), (1, "hybrid"), (1, "hip"), (0, "hip")])
+@pytest.mark.parametrize("log_freq,backend", [(1, "hip"), (0, "hip")])
 def test_config1_full_size_step_vs_oracle(dev, log_freq, backend):
     _full_size_step(dev, log_freq, backend, "f32", 1e-4)
 
@@ -608,7 +609,7 @@ def _full_size_step_body(dev, log_freq, backend, prec, err_tol, P, O, OS, OC, OS
         frm = mb.build_frame(arch=a.arch_frame, fc_dim=a.vis_channels, pool_type=a.img_pool)
         snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict())
         snd, frm = snd.to(dev), frm.to(dev)
-        frm.backend = backend
+        assert frm.backend == backend == "hip"
         wrap = P.NetWrapper((snd, frm), mb.build_criterion(a.loss, use_pit=True), mb.build_criterion(a.loss))
         opt = P.create_optimizer((snd, frm), a)
         owrap = OS.NetWrapper((osnd, ofrm), OC.build_criterion(a.loss, True), OC.build_criterion(a.loss))
@@ -699,13 +700,41 @@ def _oracle_full_size_b8(P, O, OS, OC, OST, np):
         osnd.levels()[-1].fusion.ao_draws = draws
         cb = {"mag_mix": mix.clone(), "mags": [m.clone() for m in mags], "frames": raw["frames"]}
         oerr, omatch, oouts = OS.train_step(owrap, cb, oopt, use_vis, a)
-        steps.append((oerr, omatch, [m.detach().clone() for m in oouts["pred_masks"]]))
+        # the gradients this step's SGD update consumed (train_step zeroes them at the START of a step): main.py:557-569
+        ograds = {("sound." + k): p.grad.detach().clone() for k, p in osnd.named_parameters() if p.grad is not None}
+        ograds.update({("frame." + k): p.grad.detach().clone() for k, p in ofrm.named_parameters() if p.grad is not None})
+        steps.append((oerr, omatch, [m.detach().clone() for m in oouts["pred_masks"]], ograds))
     _ORACLE_CACHE["r"] = (a, raw, init, draws, steps)
     return _ORACLE_CACHE["r"]
 
 
-@pytest.mark.parametrize("prec,err_tol", [("f32", 1e-4), ("bf16", 2e-3)])
-def test_benched_dispatch_full_size_step_vs_oracle(dev, prec, err_tol):
+def _check_flat_grads(prec, tag, nets, ograds, tol_rel):
+    """Every parameter gradient of the step (the views of FlatSGD.flat_grad the backward kernels wrote) against the CPU
+    oracle's .grad: || g_hip - g_oracle ||_2 <= tol_rel * || g_oracle ||_2 per tensor (a relative L2 bound: a weight
+    gradient is a sum over 10^5..10^7 products, its entries span orders of magnitude)."""
+    worst, n = ("", 0.0), 0
+    bad = []
+    for prefix, net in nets:
+        for k, p in net.named_parameters():
+            og = ograds.get(prefix + k)
+            if og is None:
+                continue
+            assert p.grad is not None, prefix + k
+            g = p.grad.detach().double().cpu()
+            ref = og.double()
+            rel = ((g - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+            n += 1
+            if rel > worst[1]:
+                worst = (prefix + k, rel)
+            if not rel <= tol_rel:
+                bad.append((prefix + k, rel, ref.norm().item()))
+    print(f"benched dispatch {prec} {tag}: {n} parameter gradients vs oracle, worst relative L2 error {worst[1]:.2e} ({worst[0]})")
+    assert not bad, f"{len(bad)} gradients off (bound {tol_rel}): {bad[:6]}"
+    return n
+
+
+@pytest.mark.parametrize("prec,err_tol,grad_tol", [("f32", 1e-4, 1e-3), ("bf16", 2e-3, 6e-2)])
+def test_benched_dispatch_full_size_step_vs_oracle(dev, prec, err_tol, grad_tol):
     """Full-size (256x256 tiles, 3x224^2 frames, unet7 + resnet18dilated) AV + AO train step on the kernel instantiations
     bench.py times at batch 64, against the CPU oracle: mask MSE <= 1e-4 (north star), loss |d| <= 1e-4 (fp32) /
     2e-3 (bf16 operands), and per layer launched variant == variant of the batch-64 descriptor."""
@@ -724,10 +753,9 @@ def test_benched_dispatch_full_size_step_vs_oracle(dev, prec, err_tol):
         frm = mb.build_frame(arch=a.arch_frame, fc_dim=a.vis_channels, pool_type=a.img_pool)
         snd.load_state_dict(init[0]); frm.load_state_dict(init[1])
         snd, frm = snd.to(dev), frm.to(dev)
-        frm.backend = "hip"
         wrap = P.NetWrapper((snd, frm), mb.build_criterion(a.loss, use_pit=True), mb.build_criterion(a.loss))
         opt = P.create_optimizer((snd, frm), a)
-        for (oerr, omatch, omasks), use_vis in zip(osteps, (True, False)):
+        for (oerr, omatch, omasks, ograds), use_vis in zip(osteps, (True, False)):
             snd.ao_draws = draws
             gb = {"audios": [w.to(dev) for w in raw["audios"]], "audio_mix": raw["audio_mix"].to(dev),
                   "frames": [f.to(dev) for f in raw["frames"]]}
@@ -739,6 +767,13 @@ def test_benched_dispatch_full_size_step_vs_oracle(dev, prec, err_tol):
             assert abs(err.item() - oerr) <= err_tol * max(1.0, abs(oerr)), (prec, use_vis, err.item(), oerr)
             if use_vis:
                 assert abs(match.item() - omatch) <= max(1e-4, err_tol)
+            # gradients: what the batch-64 instantiations of the data / weight gradient kernels wrote into the flat
+            # buffer (U-Net d1-d7, u1-u7, BatchNorm gamma / beta, trunk layer1-4 and fc), before the NEXT step zeroes it.
+            # The AO step runs from weights one SGD step away from the oracle's (lr 1e-3 * the AV gradient error): its
+            # bound is the same, the AV comparison is the sharp one.  bf16 bound: operands carry 2^-9 relative rounding
+            # each, a layer's gradient error grows with depth (measured: see the printed worst case)
+            n = _check_flat_grads(prec, "AV" if use_vis else "AO", (("sound.", snd), ("frame.", frm)), ograds, grad_tol)
+            assert n >= (95 if use_vis else 35), n
     finally:
         log.close()
         K.plan_batch_scale = 1
@@ -805,7 +840,7 @@ def test_eval_path_vs_oracle(dev):
                 assert abs(out[key][b, n].item() - ref[n]) < 0.05, (key, b, n, out[key][b, n].item(), ref[n])
 
 
-@pytest.mark.parametrize("backend", ["hip", "hybrid"])
+@pytest.mark.parametrize("backend", ["hip"])
 @pytest.mark.parametrize("B,T,HW,dilate,arch", [(2, 2, 64, 16, "resnet18dilated"), (1, 3, 224, 16, "resnet18dilated"),
                                                 (2, 1, 96, 8, "resnet18dilated"), (2, 1, 64, 16, "resnet18fc")])
 def test_visual_trunk_hip_backend(dev, B, T, HW, dilate, arch, backend):
@@ -829,7 +864,7 @@ def test_visual_trunk_hip_backend(dev, B, T, HW, dilate, arch, backend):
     assert list(net.state_dict().keys()) == list(onet.state_dict().keys())
     net.load_state_dict(onet.state_dict())
     net = net.to(dev)
-    net.backend = backend   # "hip": all on this library; "hybrid": MIOpen convolutions + channels-last HIP BatchNorm glue
+    assert net.backend == backend == "hip"      # the package has no other trunk (MIOpen comparison: tools/miopen_compare)
     gen = torch.Generator().manual_seed(9)
     x = torch.randn(B, 3, T, HW, HW, generator=gen)
     import copy
@@ -1107,6 +1142,90 @@ def test_data_parallel_two_ranks_early_allreduce(dev, tmp_path):
                     assert_close(got[lo:hi], want[lo:hi], 1e-5,
                                  f"all-reduced gradient vs mean of the shard gradients (overlap {overlap}, rank {rank}, "
                                  f"{'AV' if step == 0 else 'AO'} step, range {lo}:{hi})")
+
+
+
+def _rccl_worker(rank, port, out):
+    """Fresh process: a 1-rank `nccl` (= RCCL) group first, then the REAL full-size model with the collectives forced."""
+    import os
+    import sys
+    import time
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    import avsep_amd as P
+    r, w, dev = P.dp.init_from_env(backend="nccl", force=True)          # before any kernel of this library runs
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    a = P.arguments.train_music_args()
+    a.stft_pad_mode = "reflect"
+    raw = P.synth.make_batch(4, a.num_mix, a.num_frames, 224, a.audLen, seed=91, device=dev)
+    calls = []
+    orig_ar = dist.all_reduce
+
+    def spy(t, *args, **kw):
+        calls.append(t.numel())
+        return orig_ar(t, *args, **kw)
+    dist.all_reduce = spy
+    res = {}
+    for forced in (True, False):
+        torch.manual_seed(5)
+        mb = P.ModelBuilder()
+        snd = mb.build_sound(arch=a.arch_sound, fc_dim=a.num_channels, fusion_type=a.fusion_type, att_type=a.att_type)
+        frm = mb.build_frame(arch=a.arch_frame, fc_dim=a.vis_channels, pool_type=a.img_pool)
+        snd, frm = snd.to(dev), frm.to(dev)
+        wrap = P.NetWrapper((snd, frm), mb.build_criterion(a.loss, use_pit=True), mb.build_criterion(a.loss))
+        opt = P.create_optimizer((snd, frm), a, world_size=1, force_collective=forced)
+        losses = []
+        for use_vis in (True, True, False):
+            snd.ao_draws = torch.tensor([True, False, False, True])
+            gb = {"audios": list(raw["audios"]), "audio_mix": raw["audio_mix"], "frames": list(raw["frames"])}
+            err, _, _ = P.net_wrapper.train_step_async(wrap, gb, opt, use_vis, a)
+            losses.append(float(err))
+        res[forced] = {"losses": losses, "params": opt.flat_param.detach().cpu().clone(), "early": opt.early_reductions,
+                       "ranges": [list(g["range"]) for g in opt.param_groups]}
+        if forced:
+            res["calls"] = list(calls)
+            # the step's one buffer through RCCL, on its own: 10 all-reduces of the full flat gradient
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                orig_ar(opt.flat_grad)
+            torch.cuda.synchronize()
+            res["allreduce_ms"] = (time.perf_counter() - t0) * 100.0
+            res["bytes"] = opt.flat_grad.numel() * 4
+    dist.all_reduce = orig_ar
+    torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_group_carries_the_flat_gradient(dev, tmp_path):
+    """RCCL readiness on one GPU (main.py:660-662's replacement): a child process initialises a 1-rank `nccl` process
+    group before anything else, then runs two AV steps and one AO step of the REAL full-size model (unet7 + resnet18dilated,
+    256x256 tiles, 3x224^2 frames) with the collectives FORCED — FlatSGD issues the early all-reduce of the U-Net range from
+    the autograd node (overlapping the visual trunk's backward, RCCL's own stream against this library's 512-thread
+    workgroups) and the late one in step().  A 1-rank sum is the identity and scale = 1/world = 1, so the parameters must
+    equal BIT FOR BIT those of the same steps without any collective; the all-reduce sizes must be the U-Net range (early)
+    and the visual ranges (late) on AV steps, and only the U-Net range on the AO step."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
+    res = torch.load(out)
+    f, n = res[True], res[False]
+    assert f["early"] == 3 and n["early"] == 0, (f["early"], n["early"])
+    (a0, a1), rest = f["ranges"][0], f["ranges"][1:]
+    unet, vis = a1 - a0, max(r[1] for r in rest) - min(r[0] for r in rest)
+    assert res["calls"] == [unet, vis, unet, vis, unet], (res["calls"], unet, vis)
+    assert f["losses"] == n["losses"], (f["losses"], n["losses"])
+    assert torch.equal(f["params"], n["params"]), "parameters after 3 steps differ with the collectives in the step"
+    assert all(math.isfinite(x) for x in f["losses"])
+    print(f"RCCL 1-rank group: {res['bytes'] / 1e6:.1f} MB flat gradient, {res['allreduce_ms']:.3f} ms per all-reduce; "
+          f"early all-reduces {f['early']}, sizes {res['calls']}")
 
 
 @pytest.mark.parametrize("ftype,att,loss,binary,weighted,log_freq", [

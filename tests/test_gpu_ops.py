@@ -602,6 +602,52 @@ def test_fused_decoder_head_matches_unfused(dev, N, C0, C1, Hl, Wl, Cout, affine
     assert_close(acc, base + g0u, 5e-5, "g0 accumulate")
 
 
+
+def test_decoder_head_true_channels_vs_torch_autograd(dev):
+    """The decoder head at its TRUE operand widths (C0 = C1 = 64: the 128-channel contraction of audio_net.py:72-76 that the
+    batch-64 step launches), forward, weight gradient and the data gradients wrt both low-res sources against torch-CPU
+    autograd of  conv3x3(upsample_x2(relu(affine(cat)))) — the other head rows stop at 16 channels."""
+    import avsep_amd  # noqa: F401
+    from avsep_amd import kernels as K
+    from avsep_amd.lib import ACT_RELU
+    g = torch.Generator().manual_seed(4242)
+    N, C0, C1, Hl, Wl, Cout = 2, 64, 64, 64, 32, 2
+    x0 = torch.randn(N, C0, Hl, Wl, generator=g).requires_grad_(True)
+    x1 = torch.randn(N, C1, Hl, Wl, generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    dy = torch.randn(N, Cout, 2 * Hl, 2 * Wl, generator=g)
+    sc0, sh0 = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g) * 0.3
+    sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g) * 0.3
+    a0 = x0 * sc0.view(1, -1, 1, 1) + sh0.view(1, -1, 1, 1)
+    a1 = x1 * sc1.view(1, -1, 1, 1) + sh1.view(1, -1, 1, 1)
+    a0.retain_grad(); a1.retain_grad()
+    U = F.interpolate(torch.relu(torch.cat([a0, a1], 1)), scale_factor=2, mode="bilinear", align_corners=True)
+    y_ref = F.conv2d(U, w, b, padding=1)
+    y_ref.backward(dy)
+    d = lambda t: t.detach().to(dev)   # noqa: E731
+    cv = K.Conv(d(x0), Cout, 3, 1, 1, x1=d(x1), sc0=d(sc0), sh0=d(sh0), act0=ACT_RELU, sc1=d(sc1), sh1=d(sh1), act1=ACT_RELU,
+                up2x=True)
+    assert cv.head_applicable()
+    for mode, fam in (("fwd", "head_fwd_kernel"), ("dgrad", "head_dgrad_kernel"), ("wgrad", "head_wgrad_kernel")):
+        assert cv.kernel_name(mode, False) == fam, (mode, cv.kernel_name(mode, False))
+    y = cv.fwd(cv.pack(d(w), 0), d(b), None)
+    assert_close(y, y_ref, 2e-5, "head forward")
+    dw, db = cv.wgrad(d(dy), want_bias=True)
+    assert_close(dw, w.grad, 2e-5, "head dw")
+    assert_close(db, b.grad, 2e-5, "head db")
+    # the kernel returns the gradient wrt the activated-and-affine'd sources' PRE-ReLU value (dL/d a_i): a0.grad / a1.grad
+    mean1, invstd1 = d(torch.randn(C1, generator=g) * 0.1), d(torch.rand(C1, generator=g) + 0.5)
+    bst = K.zeros_stats(C1, d(x0))
+    g0, g1 = cv.dgrad_up2x(d(w), d(dy), mean1=mean1, invstd1=invstd1, bstats1=bst)
+    assert_close(g0, a0.grad, 2e-5, "head g0")
+    assert_close(g1, a1.grad, 2e-5, "head g1")
+    xh = (x1.detach().double() - mean1.cpu().double().view(1, -1, 1, 1)) * invstd1.cpu().double().view(1, -1, 1, 1)
+    gd = a1.grad.double()
+    st_ref = torch.cat([gd.sum((0, 2, 3)), (gd * xh).sum((0, 2, 3))])
+    assert_close(bst, st_ref, 1e-4, "head BatchNorm-backward sums")
+
+
 def test_down_conv_virtual_input(dev):
     """4x4 s2 halo-patch forward with the folded BatchNorm affine + LeakyReLU(0.2) of the previous encoder level
     (audio_net.py:57-58) and the BatchNorm statistics epilogue; dgrad / wgrad of the same descriptor."""
@@ -698,99 +744,6 @@ def test_bss_eval_vs_oracle(dev):
     assert abs(sir[0, 0].item() - 20.0) < 1.0 and abs(sdr[0, 1].item() - 40.0) < 1.0 and abs(sar[0, 1].item() - 40.0) < 1.0
     plain = 10 * np.log10((s[1, 0] ** 2).sum() / ((s[1, 0] - ests[1, 0]) ** 2).sum())
     assert sdr[1, 0].item() > 25 and plain < 3
-
-
-@pytest.mark.parametrize("N,C,H,W", [(4, 128, 8, 8), (3, 64, 9, 7), (2, 512, 4, 4), (5, 256, 6, 10), (2, 16, 5, 5),
-                                     (40, 64, 56, 56)])
-def test_channels_last_bn_pieces(dev, N, C, H, W):
-    """csrc/ops_nhwc.hip against torch: two-stage statistics, normalise + residual (with its own affine) + ReLU, its
-    backward with the BatchNorm-backward sums, and the folded BatchNorm gradient, on channels-last tensors."""
-    K = _pkg().kernels
-    g = torch.Generator().manual_seed(C + H)
-    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)   # noqa: E731
-    y, r, dz = (torch.randn(N, C, H, W, generator=g) for _ in range(3))
-    sc, sh, rs, rh = (torch.randn(C, generator=g) for _ in range(4))
-    mean, inv = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
-    st = torch.full((2 * C,), float("nan"), dtype=torch.float64, device=dev)          # overwritten, not accumulated
-    K.nhwc_channel_stats(cl(y), st)
-    assert_close(st, torch.cat([y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))]), 1e-5, "stats")
-    v = lambda t: t.view(1, -1, 1, 1)   # noqa: E731
-    for use_res, use_rs in ((False, False), (True, False), (True, True)):
-        pre = y * v(sc) + v(sh)
-        if use_res:
-            pre = pre + (r * v(rs) + v(rh) if use_rs else r)
-        gpre = dz * (pre > 0).float()
-        z = K.nhwc_affine_act(cl(y), sc.to(dev), sh.to(dev), cl(r) if use_res else None, 1,
-                              rs.to(dev) if use_rs else None, rh.to(dev) if use_rs else None)
-        assert_close(z, torch.relu(pre), 1e-6, "affine + residual + relu")
-        bst = torch.full((2 * C,), float("nan"), dtype=torch.float64, device=dev)
-        d = cl(dz).clone()
-        K.nhwc_affine_act_bwd_(d, cl(y), sc.to(dev), sh.to(dev), cl(r) if use_res else None, mean.to(dev), inv.to(dev), 1,
-                               bst, res_scale=rs.to(dev) if use_rs else None, res_shift=rh.to(dev) if use_rs else None)
-        assert_close(d, gpre, 1e-6, "masked gradient")
-        xhat = (y - v(mean)) * v(inv)
-        assert_close(bst, torch.cat([gpre.double().sum((0, 2, 3)), (gpre.double() * xhat.double()).sum((0, 2, 3))]), 1e-5,
-                     "BatchNorm-backward sums")
-        bst2 = torch.empty((2 * C,), dtype=torch.float64, device=dev)
-        d2 = cl(dz).clone()
-        K.nhwc_affine_act_bwd_(d2, cl(y), None, None, None, mean.to(dev), inv.to(dev), 0, bst2, stats_only=True)
-        assert torch.equal(d2, cl(dz))
-        assert_close(bst2, torch.cat([dz.double().sum((0, 2, 3)), (dz.double() * xhat.double()).sum((0, 2, 3))]), 1e-5,
-                     "statistics-only pass")
-        d3 = cl(dz).clone()                                  # residual join: the second gradient is summed on the fly
-        K.nhwc_affine_act_bwd_(d3, cl(y), sc.to(dev), sh.to(dev), cl(r) if use_res else None, mean.to(dev), inv.to(dev), 1,
-                               bst, res_scale=rs.to(dev) if use_rs else None, res_shift=rh.to(dev) if use_rs else None,
-                               dz2=cl(r))
-        assert_close(d3, (dz + r) * (pre > 0).float(), 1e-6, "masked sum of two gradients")
-    pqr = torch.randn(3, C, generator=g)
-    out = K.nhwc_bn_bwd_apply_(cl(dz).clone(), cl(y), pqr.to(dev))
-    assert_close(out, v(pqr[0]) * dz + v(pqr[1]) * y + v(pqr[2]), 1e-6, "folded BatchNorm gradient")
-    # second-stage tails: statistics + finalisation, and backward sums + coefficients, against the two-call forms
-    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
-    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-    rm2, rv2 = rm.clone(), rv.clone()
-    rows = K.nhwc_bn_train_stats(cl(y), gamma.to(dev), beta.to(dev), rm, rv, 0.1, 1e-5)
-    st2 = K.zeros_stats(C, y.to(dev))
-    K.channel_stats(y.to(dev), st2)
-    ref_rows = K.bn_finalize(st2, N * H * W, gamma.to(dev), beta.to(dev), rm2, rv2, 0.1, 1e-5, True, y.to(dev))
-    assert_close(rows, ref_rows, 1e-5, "statistics + finalisation")
-    assert_close(rm, rm2, 1e-6, "running mean")
-    assert_close(rv, rv2, 1e-6, "running var")
-    d = cl(dz).clone()
-    dgamma, dbeta, pq = K.nhwc_affine_act_bwd_(d, cl(y), rows[0], rows[1], None, rows[2], rows[3], 1, None,
-                                               gamma=gamma.to(dev), coeffs=True)
-    bst = K.zeros_stats(C, y.to(dev))
-    d_ref = K.affine_act_bwd_(dz.to(dev).clone(), y.to(dev), ref_rows[0], ref_rows[1], None, None, ref_rows[2], ref_rows[3],
-                              1, bst)
-    rg, rb, rpq = K.bn_bwd_coeffs(bst, N * H * W, gamma.to(dev), ref_rows[2], ref_rows[3])
-    assert_close(d, d_ref, 1e-6, "masked gradient (tail form)")
-    assert_close(dgamma, rg, 2e-5, "dgamma")
-    assert_close(dbeta, rb, 2e-5, "dbeta")
-    assert_close(pq, rpq, 2e-5, "pqr")
-
-
-@pytest.mark.parametrize("N,C,H,W", [(2, 64, 14, 18), (3, 16, 9, 11), (1, 64, 112, 112)])
-def test_channels_last_stem_tail(dev, N, C, H, W):
-    """maxpool(relu(bn(y))) fused forward (activated map never materialised) and its backward fused with the ReLU mask
-    and the train-mode BatchNorm backward, against torch autograd on the CPU."""
-    K = _pkg().kernels
-    g = torch.Generator().manual_seed(H)
-    y = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3
-    bn = torch.nn.BatchNorm2d(C)
-    bn.weight.data, bn.bias.data = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
-    yr = y.clone().requires_grad_(True)
-    p_ref = F.max_pool2d(torch.relu(bn(yr)), 3, 2, 1)
-    cot = torch.randn(p_ref.shape, generator=g)
-    (p_ref * cot).sum().backward()
-    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)   # noqa: E731
-    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-    rows = K.nhwc_bn_train_stats(cl(y), bn.weight.data.to(dev), bn.bias.data.to(dev), rm, rv, 0.1, 1e-5)
-    p, taps = K.nhwc_maxpool_bn_relu(cl(y), rows[0], rows[1])
-    assert_close(p, p_ref, 2e-6, "pooled activations")
-    dgamma, dbeta, dy = K.nhwc_maxpool_bn_relu_bwd(cl(cot), taps, cl(y), rows, bn.weight.data.to(dev))
-    assert_close(dy, yr.grad, 2e-5, "gradient wrt the conv output (through batch statistics)")
-    assert_close(dgamma, bn.weight.grad, 2e-5, "dgamma")
-    assert_close(dbeta, bn.bias.grad, 2e-5, "dbeta")
 
 
 @pytest.mark.parametrize("att", ["sig", "cos"])

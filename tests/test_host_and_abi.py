@@ -215,3 +215,94 @@ def test_pack_scope_and_plan_batch_are_scoped():
         assert K._pack_cache == {"x": 1}
     assert K._pack_cache is None
     assert P.lib.ConvDesc().plan_n == 0 and ctypes.sizeof(P.lib.ConvDesc) == 18 * 4 + 6 * 8
+
+
+def test_flat_sgd_state_dict_is_layout_independent_and_reads_older_blobs():
+    """FlatSGD.state_dict() carries one momentum tensor per parameter in its logical shape (no trace of ALIGN), and
+    load_state_dict() also accepts the two flat layouts earlier builds wrote into optim_latest.pth — unpadded offsets
+    (rounds 1-2) and offsets padded to 64 elements (round 3) — and degrades to a history-only resume (warning, zero
+    momentum, learning rates by group name) on a blob that matches nothing instead of raising."""
+    import warnings
+    P = _pkg()
+    FlatSGD = P.net_wrapper.FlatSGD
+    torch.manual_seed(1)
+
+    def nets():
+        torch.manual_seed(2)
+        return (torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5)), torch.nn.Conv2d(5, 7, 1))
+
+    def make():
+        a, b = nets()
+        return FlatSGD([{"params": list(a.parameters()), "lr": 0.1, "name": "sound"},
+                        {"params": list(b.parameters()), "lr": 0.01, "name": "frame_fc"}], require_gpu=False)
+    opt = make()
+    params = [p for g in opt.param_groups for p in g["params"]]
+    mom = [torch.randn_like(p) for p in params]
+    offs, total = opt._offsets(FlatSGD.ALIGN)
+    for o, m in zip(offs, mom):
+        opt.flat_buf[o:o + m.numel()] = m.reshape(-1)
+    opt.param_groups[0]["lr"], opt.param_groups[0]["started"] = 0.05, True
+    sd = opt.state_dict()
+    assert sd["format"] == 2 and [tuple(m.shape) for m in sd["momentum"]] == [tuple(p.shape) for p in params]
+    assert "range" not in sd["groups"][0]
+    fresh = make()
+    assert fresh.load_state_dict(sd) is True
+    assert torch.equal(fresh.flat_buf, opt.flat_buf) and fresh.param_groups[0]["lr"] == 0.05 and fresh.param_groups[0]["started"]
+    # older flat blobs: padded to 64 (round 3) and unpadded (rounds 1-2)
+    for align in (64, 1):
+        src, tot = opt._offsets(align)
+        flat = torch.zeros(tot)
+        for o, m in zip(src, mom):
+            flat[o:o + m.numel()] = m.reshape(-1)
+        ranges, off = [], 0
+        for g in opt.param_groups:
+            beg = off
+            off += sum((p.numel() + align - 1) // align * align for p in g["params"])
+            ranges.append([beg, off])
+        legacy = {"momentum_buffer": flat, "layout": "oihw",
+                  "groups": [{"name": g["name"], "lr": 0.5, "started": True, "range": r} for g, r in zip(opt.param_groups, ranges)]}
+        fresh = make()
+        assert fresh.load_state_dict(legacy) is True, align
+        assert torch.equal(fresh.flat_buf, opt.flat_buf), align
+        assert fresh.param_groups[1]["lr"] == 0.5
+    # a blob of another architecture: warning + history-only resume
+    bad = {"momentum_buffer": torch.zeros(17), "groups": [{"name": "sound", "lr": 0.3, "started": True, "range": [0, 17]}]}
+    fresh = make()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert fresh.load_state_dict(bad) is False
+    assert w and "momentum starts from zero" in str(w[0].message)
+    assert float(fresh.flat_buf.abs().sum()) == 0.0 and fresh.param_groups[0]["lr"] == 0.3 and not fresh.param_groups[0].get("started")
+
+
+def test_pack_scope_key_follows_in_place_weight_updates():
+    """kernels.pack_scope caches packed weight images per (weight, geometry); an in-place update of the weight inside a
+    scope bumps the tensor's version counter, which is part of the key, so the stale image is not reused (no GPU: the
+    packing call itself is replaced by a counter)."""
+    P = _pkg()
+    K = P.kernels
+    calls = []
+
+    class FakeLib:
+        def avsep_conv_packed_floats(self, ref, mode):
+            return 4
+    cv = K.Conv.__new__(K.Conv)
+    cv.d = P.lib.ConvDesc()
+    cv.ref = None
+    w = torch.zeros(4)
+    orig_load, orig_call, orig_f32 = K.lib.load, K.call, K._f32
+    K.lib.load = lambda: FakeLib()
+    K.call = lambda name, *a: calls.append(name)
+    K._f32 = lambda shape, like: torch.empty(shape)
+    orig_ptr = K.ptr
+    K.ptr = lambda t: 0
+    try:
+        with K.pack_scope():
+            a = cv.pack(w, 0)
+            assert cv.pack(w, 0) is a and len(calls) == 1
+            w.add_(1.0)                                     # e.g. an optimizer step / EMA / clamp inside the scope
+            b = cv.pack(w, 0)
+            assert b is not a and len(calls) == 2
+            assert cv.pack(w.detach(), 0) is b              # detach() shares the version counter
+    finally:
+        K.lib.load, K.call, K._f32, K.ptr = orig_load, orig_call, orig_f32, orig_ptr

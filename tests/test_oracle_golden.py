@@ -4,6 +4,7 @@ import argparse
 
 import numpy as np
 import torch
+import pytest
 import torch.nn.functional as F
 
 from conftest import assert_close
@@ -201,3 +202,25 @@ def test_train_steps(golden):
             assert abs(match - G[f"it{it}.match"].item()) < 2e-5
     assert_close(snd.state_dict()["unet_block.up_forward.2.weight"], G["final.sound.last_w"], 2e-4)
     assert_close(frm.state_dict()["fc.bias"], G["final.frame.fc_b"], 2e-4)
+
+
+def test_reference_mixvis_step_raises_as_shipped(golden):
+    """main.py:181 hands PitWrapper the un-stacked [B,1,F,T] weight: the reference's own forward_avmiximg, executed by
+    oracle/gen_golden.py through the reference's NetWrapper.forward, raises (recorded type + message).  The oracle's
+    forward_avmiximg (oracle/step.py) therefore carries a build-defined repair — forward_ao's per-target weight stacking
+    (main.py:103) — and with the ORIGINAL un-stacked weight the oracle's PitWrapper fails the same way."""
+    G = golden("step")
+    assert bool(G["mixvis.raised"][0])
+    typ = bytes(G["mixvis.exc_type"].numpy()).decode()
+    msg = bytes(G["mixvis.exc_msg"].numpy()).decode()
+    assert typ == "RuntimeError" and "must match the size of tensor" in msg, (typ, msg)
+    from oracle import criterion as OC
+    crit = OC.build_criterion("bce", True)
+    B, Fq, T = 2, 64, 64
+    g = torch.Generator().manual_seed(0)
+    pred, gt = torch.rand(B, Fq, T, 2, generator=g), (torch.rand(B, Fq, T, 2, generator=g) > 0.5).float()
+    weight = torch.rand(B, 1, Fq, T, generator=g)
+    with pytest.raises(RuntimeError, match="must match the size of tensor"):
+        crit(pred, gt, weight)                                   # what main.py:181 does
+    err, perms = crit(pred, gt, torch.stack([weight[:, 0]] * 2, -1))   # the repair
+    assert err.shape[0] == B and torch.isfinite(err).all()

@@ -1,10 +1,11 @@
 // BatchNorm / ReLU / residual pieces for channels-last ([N,H,W,C] = [M rows, C columns]) activations.
-// Used by the "hybrid" visual backend (models/vision_hybrid.py): the ResNet convolutions run on MIOpen's NHWC
+// Used by the "hybrid" visual backend (tools/miopen_compare/backend.py): the ResNet convolutions run on MIOpen's NHWC
 // implicit-GEMM kernels, everything between them on these kernels — train-mode BatchNorm2d statistics, the fused
 // normalise + residual + ReLU pass of a BasicBlock tail (torchvision resnet BasicBlock.forward), and the backward
 // with the BatchNorm gradient folded as dy = p*dz + q*y + r (same algebra as the NCHW kernels in ops.hip).
 // All are HBM-bound streaming kernels with 16-byte accesses; C % 4 == 0 and C/4 a divisor of 256.
 #include "common.h"
+#include "avsep_nhwc.h"
 
 // per-channel (sum a, sum a*b) of two [M, C] streams.  One thread owns one channel quad (column tid % C4) and every
 // (256/C4)-th row of the block's row range; LDS reduce -> one partial row [2*C] per block in the workspace, summed in
