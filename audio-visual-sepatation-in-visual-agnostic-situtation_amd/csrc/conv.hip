@@ -635,6 +635,13 @@ int bf_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
 int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, void* ws, size_t ws_bytes,
            hipStream_t st);
 int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
+bool bf_out_b16(const avsep_conv_desc* d, int mode);
+// wgrad_b16.hip: bf16 weight gradient over B16 images (transposed LDS reads)
+bool wbn_applicable(const avsep_conv_desc* d);
+size_t wbn_workspace_floats(const avsep_conv_desc* d);
+int wbn_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
+void wbn_variant(const avsep_conv_desc* d, char* buf, size_t cap);
+int b16_channel_sum(const void* x, int N, int C, int HW, double* acc, float* out, hipStream_t st);   // b16.hip
 // wgrad_bf16.hip
 bool wb_applicable(const avsep_conv_desc* d);
 size_t wb_workspace_floats(const avsep_conv_desc* d);
@@ -684,6 +691,25 @@ static inline int packed_rows(const avsep_conv_desc* d, int mode) {
   return mode == 0 ? roundup(d->Cin * d->KH * d->KW, 32) : roundup(d->KH * d->KW * d->Cout, 32);
 }
 static inline int packed_ld(const avsep_conv_desc* d, int mode) { return roundup(mode == 0 ? d->Cout : d->Cin, 128); }
+
+static bool wgrad_takes_b16(const avsep_conv_desc* d) {
+  return !smallco_applicable(d) && !head_applicable(d) && wbn_applicable(d);
+}
+extern "C" int avsep_conv_io_formats(const avsep_conv_desc* d, int32_t mode, int32_t* in_fmt, int32_t* out_b16) {
+  if (!in_fmt || !out_b16 || mode < 0 || mode > 2) return AVSEP_ERR_ARG;
+  int rc = check_desc(d, mode == 0);
+  if (rc) return rc;
+  *in_fmt = AVSEP_FMT_F32;
+  *out_b16 = 0;
+  if (mode == 0) {
+    if (!smallco_applicable(d) && !head_applicable(d) && bf_applicable(d, 0)) { *in_fmt = AVSEP_FMT_B16; *out_b16 = bf_out_b16(d, 0); }
+  } else if (mode == 1) {
+    if (!smallci_applicable(d) && !head_applicable(d) && bf_applicable(d, 1)) { *in_fmt = AVSEP_FMT_B16; *out_b16 = bf_out_b16(d, 1); }
+  } else if (wgrad_takes_b16(d)) {
+    *in_fmt = AVSEP_FMT_B16;
+  }
+  return AVSEP_OK;
+}
 
 extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
   if (!d || (mode != 0 && mode != 1)) return 0;
@@ -921,7 +947,7 @@ extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (check_desc(d)) return 0;
   if (smallco_applicable(d)) return smallco_wgrad_workspace_floats(d) * sizeof(float);
   if (head_applicable(d)) return head_wgrad_workspace_floats(d) * sizeof(float);
-  if (wb_applicable(d)) return wb_workspace_floats(d) * sizeof(float);
+  if (wbn_applicable(d)) return wbn_workspace_floats(d) * sizeof(float) + (size_t)2 * d->Cout * sizeof(double);
   if (w4b_applicable(d)) return w4b_workspace_floats(d) * sizeof(float);
   if (ww_applicable(d)) return ww_workspace_floats(d) * sizeof(float);
   if (w4d_applicable(d)) return w4d_workspace_floats(d) * sizeof(float);
@@ -942,6 +968,12 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
   if (need > workspace_bytes || (need && !workspace)) return AVSEP_ERR_WORKSPACE;
   if (smallco_applicable(d)) return smallco_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
   if (head_applicable(d)) return head_wgrad(d, dy, dw, dbias, (float*)workspace, (hipStream_t)stream);
+  if (wbn_applicable(d)) {
+    int rcw = wbn_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
+    if (rcw || !dbias) return rcw;
+    double* acc = reinterpret_cast<double*>((float*)workspace + wbn_workspace_floats(d));   // behind the slabs (8-byte aligned: slab sizes are multiples of 64*64)
+    return b16_channel_sum(dy, d->N, d->Cout, d->Ho * d->Wo, acc, dbias, (hipStream_t)stream);
+  }
   if (wb_applicable(d) || w4b_applicable(d) || ww_applicable(d) || w4d_applicable(d) || w3_applicable(d) || scw_applicable(d)) {
     int rc3 = wb_applicable(d) ? wb_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : w4b_applicable(d) ? w4b_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
@@ -1007,6 +1039,7 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
   }
   if (smallco_applicable(d)) return "smallco_wgrad";
   if (head_applicable(d)) return "head_wgrad_kernel";
+  if (wbn_applicable(d)) return "wgradb_kernel";
   if (wb_applicable(d)) return "wgradbf_kernel";
   if (w4b_applicable(d)) return "wgrad4bf_kernel";
   if (ww_applicable(d)) return "winow_kernel";
@@ -1026,6 +1059,7 @@ extern "C" int avsep_conv_kernel_variant(const avsep_conv_desc* d, int32_t mode,
   const char* fam = avsep_conv_kernel_name(d, mode, with_stats);
   char tail[64] = "";
   if (!strcmp(fam, "convbf_kernel")) bf_variant(d, mode, tail, sizeof(tail));
+  else if (!strcmp(fam, "wgradb_kernel")) wbn_variant(d, tail, sizeof(tail));
   else if (!strcmp(fam, "conv3x3_kernel")) {
     if (c3_applicable(d, mode)) c3_variant(d, mode, tail, sizeof(tail));
     else if (c4_applicable(d, mode)) c4_variant(d, mode, tail, sizeof(tail));

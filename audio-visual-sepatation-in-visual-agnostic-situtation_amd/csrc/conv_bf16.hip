@@ -112,6 +112,7 @@ static long long bf_flat_wgs(int M, long long P) {
   return (long long)gm * cdiv(P, big ? 256 : 128);
 }
 
+size_t bf_workspace_bytes(const avsep_conv_desc* d, int mode);
 bool bf_applicable(const avsep_conv_desc* d, int mode) {
   if (d->prec != AVSEP_PREC_BF16 || !bf_enabled()) return false;
   const int cls = bf_class(d);
@@ -119,14 +120,22 @@ bool bf_applicable(const avsep_conv_desc* d, int mode) {
   const int kc = mode == 0 ? d->Cin : d->Cout, m = mode == 0 ? d->Cout : d->Cin;
   if (kc % BF_CK != 0 || m < 32) return false;
   if (mode == 0 && d->scale0 && d->Cin > BF_AFF_MAX) return false;
-  // 32-bit element offsets inside the staged tensor; grid dimension
+  // 32-bit 16-byte-unit offsets inside the staged B16 image, int pixel indices; grid dimension
   const long long in_elems = mode == 0 ? (long long)d->N * d->Cin * d->H * d->W : (long long)d->N * d->Cout * d->Ho * d->Wo;
-  if (in_elems >= (1LL << 30) || d->N > 65535) return false;
+  if (in_elems >= (1LL << 33) || (long long)d->N * d->H * d->W >= (1LL << 31) || d->N > 65535) return false;
   if (cls == 3) return bf_flat(d) || (d->W >= 16 && d->H >= 4);
   if (cls == 6) return mode == 0 && d->Wo >= 16 && d->Ho >= 4;
   if (cls == 1) return d->Wo >= 8 && d->Ho >= 4 && (d->stride == 1 || mode == 0 || ((d->H & 1) == 0 && (d->W & 1) == 0));
   if (mode == 0) return d->Wo >= 8 && d->Ho >= 4;               // 8-wide outputs (U-Net d5) use half of a 16-wide tile
   return d->Wo >= 8 && d->Ho >= 4 && (d->H & 1) == 0 && (d->W & 1) == 0;
+}
+
+// may the output (y for mode 0, dx for mode 1) of this call be written as a B16 image?  Not through split-K slabs (their
+// combine writes fp32), and the output channels must come in whole 16-channel blocks
+bool bf_out_b16(const avsep_conv_desc* d, int mode) {
+  const int M = mode == 0 ? d->Cout : d->Cin;
+  if (M % 16 != 0) return false;
+  return bf_workspace_bytes(d, mode) == 0;
 }
 
 size_t bf_workspace_bytes(const avsep_conv_desc* d, int mode) {
@@ -269,6 +278,9 @@ int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
   a.C0 = d->Cin; a.C1 = 0; a.act0 = d->act0; a.Hs = d->H; a.Ws = d->W;
   a.x0 = d->x0; a.sc0 = d->scale0; a.sh0 = d->shift0;
   a.wp = wp; a.wp_ld = roundup(d->Cout, 128); a.out = y; a.bias = bias; a.stats = stats;
+  if (d->xfmt != AVSEP_FMT_B16) return AVSEP_ERR_ARG;               // the bf16 kernels stage B16 images only
+  a.out16 = d->yfmt == AVSEP_FMT_B16;
+  if (a.out16 && (d->Cout % 16 != 0 || !bf_out_b16(d, 0))) return AVSEP_ERR_ARG;
   if (bf_class(d) == 3) {
     int splits = 1;
     int rc = bf3_launch(a, d->dil, ws, ws_bytes, &splits, st);
@@ -285,11 +297,14 @@ int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
 }
 
 int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (d->dyfmt != AVSEP_FMT_B16) return AVSEP_ERR_ARG;
+  const int out16 = d->dxfmt == AVSEP_FMT_B16;
+  if (out16 && (d->Cin % 16 != 0 || !bf_out_b16(d, 1))) return AVSEP_ERR_ARG;
   if (bf_class(d) == 3) {
     C3Args a{};
     a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->H; a.Ws = d->W;
-    a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
+    a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx; a.out16 = out16;
     int splits = 1;
     int rc = bf3_launch(a, d->dil, ws, ws_bytes, &splits, st);
     if (rc || splits == 1) return rc;
@@ -301,9 +316,9 @@ int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
     C3Args a{};
     a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
-    a.x0 = dy; a.wp = wp; a.wp_ld = ld; a.out = dx;
+    a.x0 = dy; a.wp = wp; a.wp_ld = ld; a.out = dx; a.out16 = out16;
     a.Ho = d->Ho; a.Wo = d->Wo; a.padh = a.padw = 0; a.os = d->stride; a.ooh = a.oow = 0; a.OHs = d->H; a.OWs = d->W;
-    if (d->stride == 2 && hipMemsetAsync(dx, 0, (size_t)d->N * d->Cin * d->H * d->W * sizeof(float), st) != hipSuccess)
+    if (d->stride == 2 && hipMemsetAsync(dx, 0, (size_t)d->N * d->Cin * d->H * d->W * (out16 ? 2 : sizeof(float)), st) != hipSuccess)
       return AVSEP_ERR_LAUNCH;
     return bf_launch_rect<1, 1, 1, 1>(a, st);
   }
@@ -314,7 +329,7 @@ int bf_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
     C3Args a{};
     a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
-    a.x0 = dy; a.wp = wp + off; a.wp_ld = ld; a.out = dx;
+    a.x0 = dy; a.wp = wp + off; a.wp_ld = ld; a.out = dx; a.out16 = out16;
     a.Ho = d->H / 2; a.Wo = d->W / 2;
     a.os = 2; a.ooh = ph; a.oow = pw; a.OHs = d->H; a.OWs = d->W;
     int rc;

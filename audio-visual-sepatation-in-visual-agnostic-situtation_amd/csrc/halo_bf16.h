@@ -14,6 +14,13 @@
 //     the pack kernel, so it costs no registers, no VALU and no ds_write; only the patch goes through registers
 //     (8 fp32 loads -> affine/activation -> 4 packed converts -> one ds_write_b128).
 // Single source, no fused upsample (the U-Net decoder materialises relu+upsample, the fused head stays fp32).
+//
+// Round 4: the staged tensor lives in HBM as bf16 in the channel-blocked layout the patch already has,
+//   B16 = [N][C/16][H][W][16 ch]  (32 bytes per position and 16-channel block),
+// so a (position, 8-channel half) slot of the patch is ONE 16-byte load and, for an operand that needs no affine /
+// activation, one ds_write_b128 of the very same bits: no 8 strided fp32 loads, no converts.  The output is written either
+// fp32 NCHW or B16 (C3Args.out16): the packed bf16 quads of a lane pair are exchanged with v_permlane32_swap so that every
+// lane stores 16 contiguous bytes (8 channels of one position).  BatchNorm statistics are taken from the fp32 accumulators.
 #pragma once
 #include <type_traits>
 #include "common.h"
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
   const float slope = act_slope(a.act0);
 
   // ---- patch loader state: slot = (position, channel half g); 8 channels of one position per slot ----------------
-  unsigned p_off[PE];                       // element offset of the slot's first channel inside x0 (< 2^30: checked on the host)
+  unsigned p_off[PE];                       // 16-byte unit of the slot inside the B16 image of K-tile 0 (< 2^28: checked on the host)
   int p_lds[PE], p_g[PE];
   unsigned pok = 0;
 #pragma unroll
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
     }
     const bool ok = (PE * NTHR == NSLOT || tid + NTHR * e < NSLOT) && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
     const int ghc = min(max(gh, 0), a.H - 1), gwc = min(max(gw, 0), a.W - 1);
-    p_off[e] = (unsigned)(((long long)ne * a.C0 + 8 * g) * sHW + (long long)ghc * a.Ws + gwc);
+    p_off[e] = (unsigned)((((long long)ne * (a.C0 >> 4)) * sHW + (long long)ghc * a.Ws + gwc) * 2 + g);
     // stride 2: columns de-interleaved (even | odd) so that the 32 pixels of an MFMA column tile read consecutive positions
     const int lpos = (S == 2) ? r * PW + (col & 1) * PWH + (col >> 1) : pos;
     p_lds[e] = lpos * 32 + ((g ^ (lpos >> 3)) & 1) * 16;
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
   // converted into LDS.  With one set the loads of kt + 1 were issued at the top of iteration kt and consumed at its bottom:
   // one K-tile of MFMAs (18-36 x 32 cycles) is shorter than an HBM round trip under load, and the waves sat parked on
   // s_waitcnt for 38-50 % of their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r03_convbf_sq_before_prefetch2.txt)
-  float praw[2][PE][8];
+  u32x4 praw[2][PE];
   if (has_aff) {                            // scale / shift rows -> LDS once (kept out of the register pipeline)
     for (int c = tid; c < a.Cin; c += NTHR) {
       aff_sc[c] = a.sc0[c];
@@ -138,36 +145,37 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
   };
   auto issue_p = [&](int kt, auto set) __attribute__((always_inline)) {
     constexpr int R = decltype(set)::value;
-    const float* xk = a.x0 + (long long)kt * BF_CK * sHW;             // uniform: scalar base + 32-bit lane offset
+    const u32x4* xk = reinterpret_cast<const u32x4*>(a.x0) + (long long)kt * sHW * 2;   // uniform: scalar base + 32-bit lane offset
 #pragma unroll
-    for (int e = 0; e < PE; ++e) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) praw[R][e][j] = (xk + (long long)j * sHW)[p_off[e]];
-    }
+    for (int e = 0; e < PE; ++e) praw[R][e] = xk[p_off[e]];
   };
   auto finish = [&](int kt, int buf, auto set) __attribute__((always_inline)) {
     constexpr int R = decltype(set)::value;
 #pragma unroll
     for (int e = 0; e < PE; ++e) {
-      float v[8];
       const bool ok = (pok >> e) & 1u;
-      f32x4 sc[2], sh[2];
-      if (has_aff) {
-        const f32x4* sp = reinterpret_cast<const f32x4*>(aff_sc + kt * BF_CK + 8 * p_g[e]);
-        const f32x4* hp = reinterpret_cast<const f32x4*>(aff_sh + kt * BF_CK + 8 * p_g[e]);
-        sc[0] = sp[0]; sc[1] = sp[1]; sh[0] = hp[0]; sh[1] = hp[1];
-      }
+      u32x4 q = praw[R][e];
+      if constexpr (!RAW) {
+        f32x4 sc[2], sh[2];
+        if (has_aff) {
+          const f32x4* sp = reinterpret_cast<const f32x4*>(aff_sc + kt * BF_CK + 8 * p_g[e]);
+          const f32x4* hp = reinterpret_cast<const f32x4*>(aff_sh + kt * BF_CK + 8 * p_g[e]);
+          sc[0] = sp[0]; sc[1] = sp[1]; sh[0] = hp[0]; sh[1] = hp[1];
+        }
+        float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float x = praw[R][e][j];
-        if (has_aff) x = fmaf(x, sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
-        v[j] = RAW ? x : act_by_slope(x, slope);
+        for (int j = 0; j < 8; ++j) {
+          // bf16 -> f32 is a shift: element 2k sits in the low half of word k, element 2k + 1 in the high half
+          float x = __builtin_bit_cast(float, (j & 1) ? (q[j >> 1] & 0xffff0000u) : (q[j >> 1] << 16));
+          if (has_aff) x = fmaf(x, sc[j >> 2][j & 3], sh[j >> 2][j & 3]);
+          v[j] = act_by_slope(x, slope);
+        }
+        q = u32x4{bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
       }
       if (PE * NTHR == NSLOT || tid + NTHR * e < NSLOT) {
         // zero padding AFTER the activation, on the packed words (the 8 channels of a slot share one position)
-        u32x4 q = {ok ? bf_pack2(v[0], v[1]) : 0u, ok ? bf_pack2(v[2], v[3]) : 0u, ok ? bf_pack2(v[4], v[5]) : 0u,
-                   ok ? bf_pack2(v[6], v[7]) : 0u};
-        *reinterpret_cast<u32x4*>(Pb + buf * P_BYTES + p_lds[e]) = q;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(Pb + buf * P_BYTES + p_lds[e]) = ok ? q : z;
       }
     }
   };
@@ -243,10 +251,10 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
     // The barrier of the K-tile.  __syncthreads() is a workgroup-scope fence: on gfx9 loads and stores share vmcnt, so it
     // compiles to s_waitcnt vmcnt(0) and would drain the far patch loads issued just now.  What has to be complete here is
     // (a) this wave's LDS stores (lgkmcnt) and (b) its LDS-DMA pieces of the next weight tile, which are OLDER than the
-    // PE * 8 far loads: a counted vmcnt leaves exactly those in flight.
+    // PE far loads: a counted vmcnt leaves exactly those in flight.
     if (kt + 2 < nK) {
       issue_p(kt + 2, far);                                // `far` is the set the previous K-tile's finish() freed
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PE * 8) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PE) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -274,11 +282,26 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
     }
   }
   const bool want_stats = a.stats != nullptr && a.kts == 0;
+  const bool out16 = a.out16 && a.kts == 0;                  // split-K slabs stay fp32 (the combine decides the final format)
   float* const outp = a.out + (a.kts > 0 ? (long long)blockIdx.y * a.slab : 0);   // partial slab: bias / statistics in the combine
   float* s_sum = reinterpret_cast<float*>(Ab);               // [NWN][BM] per-wave-column partial sums (operands are dead)
   float* s_sq = s_sum + NWN * BM;
+  // B16 output: 32-byte unit index of (image, position) in the block-0 plane; + (row >> 4) * HW per 16-channel block
+  long long cb16[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = wn * 64 + j * 32 + li;
+    if constexpr (FLAT) {
+      const int pg = p0 + p;
+      cb16[j] = (long long)(pg / f_HW) * (a.Cout >> 4) * HW + pg % f_HW;
+    } else {
+      const int gh = h0 + p / TW, gw = w0 + p % TW;
+      cb16[j] = (long long)n * (a.Cout >> 4) * HW + (long long)(gh * a.os + a.ooh) * a.OWs + (gw * a.os + a.oow);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    float vv[16][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int lrow = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -289,8 +312,9 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float v = acc[i][j][r] + bias;
+        vv[r][j] = v;
         if (rok && cok[j]) {
-          outp[cbase[j] + (long long)row * HW] = v;
+          if (!out16) outp[cbase[j] + (long long)row * HW] = v;
           s += v;
           q += v * v;
         }
@@ -301,6 +325,28 @@ __global__ __launch_bounds__(128 * NWN) void convbf_kernel(C3Args a) {
         if (li == 31) {
           s_sum[wn * BM + lrow] = s;
           s_sq[wn * BM + lrow] = q;
+        }
+      }
+    }
+    if (out16) {
+      // rows of a 32-row block: lane half lk holds (r & 3) + 8 * (r >> 2) + 4 * lk, i.e. per 16-channel block hb the quads
+      // [4 lk .. 4 lk + 3] (r = 8 hb + 0..3) and [8 + 4 lk ..] (r = 8 hb + 4..7).  permlane32_swap(vdst = first quad,
+      // src = second quad) leaves lanes 0-31 with channels 0-7 and lanes 32-63 with channels 8-15 of the block: one
+      // 16-byte store per lane, 32 contiguous bytes per lane pair (cdna_hip_programming.md T21)
+      unsigned char* const ob = reinterpret_cast<unsigned char*>(a.out);
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const int row0 = m0 + wm * WTM + i * 32 + 16 * hb;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned a0 = bf_pack2(vv[8 * hb + 0][j], vv[8 * hb + 1][j]), a1 = bf_pack2(vv[8 * hb + 2][j], vv[8 * hb + 3][j]);
+          unsigned b0 = bf_pack2(vv[8 * hb + 4][j], vv[8 * hb + 5][j]), b1 = bf_pack2(vv[8 * hb + 6][j], vv[8 * hb + 7][j]);
+          auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          if (row0 < a.Cout && cok[j]) {
+            const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+            *reinterpret_cast<u32x4*>(ob + ((cb16[j] + (long long)(row0 >> 4) * HW) * 32 + lk * 16)) = o;
+          }
         }
       }
     }

@@ -23,6 +23,7 @@ struct C3Args {
   int kts;
   long long slab;
   int planN;             // host only: batch the tile-size heuristics are planned for (avsep_conv_desc.plan_n; 0 = N)
+  int out16;             // bf16 kernels: `out` is a B16 image ([N][Cout/16][OHs][OWs][16] bf16) instead of fp32 NCHW
 };
 static inline long long c3_plan_n(const C3Args& a) { return a.planN > 0 ? a.planN : a.N; }
 // 64-row instead of 128-row tiles (fp32 halo-patch kernels): small GEMM M, too few 128-row workgroups for the 256 CUs, or

@@ -16,6 +16,94 @@ def _f32(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+# ---- storage formats (include/avsep.h AVSEP_FMT_*) ------------------------------------------------------------------------
+# F32: dense fp32 [N,C,H,W].  B16: torch.bfloat16 of shape [N, C/16, H, W, 16] — the channel-blocked image the bf16 kernels
+# stage with one 16-byte load per (position, 8-channel half).  A tensor's dtype IS its format tag.
+FMT_F32, FMT_B16 = 0, 1
+
+
+def is_b16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def fmt_of(t):
+    return FMT_B16 if is_b16(t) else FMT_F32
+
+
+def dims(t):
+    """(N, C, H, W) of an activation tensor in either format."""
+    if is_b16(t):
+        N, CB, H, W, _ = t.shape
+        return N, CB * 16, H, W
+    return tuple(t.shape)
+
+
+def channels(t):
+    return t.shape[1] * 16 if is_b16(t) else t.shape[1]
+
+
+def per_channel(t):
+    """Elements per channel (the BatchNorm count N*H*W)."""
+    return t.numel() // channels(t)
+
+
+def _b16(shape_nchw, like):
+    N, Cc, H, W = shape_nchw
+    return torch.empty((N, Cc // 16, H, W, 16), dtype=torch.bfloat16, device=like.device)
+
+
+def empty_as(t):
+    return torch.empty_like(t)
+
+
+def to_b16(t):
+    """B16 image of an fp32 NCHW tensor (one HBM pass).  The converted twin is remembered on the tensor object, so an operand
+    that several kernels of a step need in the other format (the forward and the weight gradient of a conv) is converted once."""
+    if t is None or is_b16(t):
+        return t
+    twin = getattr(t, "_avsep_twin", None)
+    if twin is not None and twin[1] == t._version:
+        return twin[0]
+    N, Cc, H, W = t.shape
+    out = _b16((N, Cc, H, W), t)
+    call("avsep_f32_to_b16", ptr(t), N, Cc, H * W, ptr(out))
+    t._avsep_twin = (out, t._version)
+    out._avsep_twin = (t, out._version)
+    return out
+
+
+def to_f32(t):
+    if t is None or not is_b16(t):
+        return t
+    twin = getattr(t, "_avsep_twin", None)
+    if twin is not None and twin[1] == t._version:
+        return twin[0]
+    N, Cc, H, W = dims(t)
+    out = _f32((N, Cc, H, W), t)
+    call("avsep_b16_to_f32", ptr(t), N, Cc, H * W, ptr(out))
+    t._avsep_twin = (out, t._version)
+    out._avsep_twin = (t, out._version)
+    return out
+
+
+def as_fmt(t, fmt):
+    return to_b16(t) if fmt == FMT_B16 else to_f32(t)
+
+
+def b16_ok(c):
+    """May a [N,c,H,W] tensor be kept as a B16 image?"""
+    return c % 16 == 0
+
+
+# Activations between the bf16 kernels are kept as B16 images when the arithmetic mode is bf16 (set_precision) unless this
+# switch is off (A/B runs: AVSEP_BF16_ACTIVATIONS=0 keeps fp32 NCHW tensors and converts at every bf16 kernel's door).
+b16_activations = os.environ.get("AVSEP_BF16_ACTIVATIONS", "1") != "0"
+
+
+def want_b16(c=16):
+    return _precision == 1 and b16_activations and b16_ok(c)
+
+
 # Operand precision of the convolutions: "f32" (exact f32 MFMA, the reference's arithmetic) or "bf16" (operands rounded
 # to bf16 while they are staged, fp32 accumulation / BatchNorm statistics / outputs / master weights: BASELINE.json
 # configs[2]).  Geometries without a bf16 kernel run in f32 either way.
@@ -61,19 +149,23 @@ def out_size(h, k, s, p, d):
 
 
 class Conv:
-    """Geometry + virtual-input description of one convolution call (avsep_conv_desc)."""
+    """Geometry + virtual-input description of one convolution call (avsep_conv_desc).  Operands may be fp32 NCHW or B16
+    images; each call asks the library which format its kernel stages (avsep_conv_io_formats) and converts at the door
+    if the tensor it was given is in the other one."""
 
     def __init__(self, x0, cout, k, stride, pad, dil=1, x1=None, sc0=None, sh0=None, act0=0,
                  sc1=None, sh1=None, act1=0, up2x=False, prec=None):
         lib.require_gpu(x0)
-        N, C0, Hs, Ws = x0.shape
+        if x1 is not None:                       # two-source descriptors exist for the fp32 kernels only
+            x0, x1 = to_f32(x0), to_f32(x1)
+        N, C0, Hs, Ws = dims(x0)
         C1 = x1.shape[1] if x1 is not None else 0
         H, W = (2 * Hs, 2 * Ws) if up2x else (Hs, Ws)
         kh, kw = (k, k) if isinstance(k, int) else k
         self.N, self.Cin, self.H, self.W, self.Cout = N, C0 + C1, H, W, cout
         self.KH, self.KW = kh, kw
         self.Ho, self.Wo = out_size(H, kh, stride, pad, dil), out_size(W, kw, stride, pad, dil)
-        self.keep = (x0, x1, sc0, sh0, sc1, sh1)
+        self.keep = [x0, x1, sc0, sh0, sc1, sh1]
         d = ConvDesc()
         d.N, d.Cin, d.H, d.W, d.Cout, d.Ho, d.Wo = N, C0 + C1, H, W, cout, self.Ho, self.Wo
         d.KH, d.KW, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
@@ -81,10 +173,30 @@ class Conv:
         d.prec = _precision if prec is None else PREC_BY_NAME[prec]
         d.plan_n = N * plan_batch_scale if plan_batch_scale != 1 else 0
         d.x0, d.x1 = ptr(x0), ptr(x1)
+        d.xfmt = fmt_of(x0)
         d.scale0, d.shift0, d.scale1, d.shift1 = ptr(sc0), ptr(sh0), ptr(sc1), ptr(sh1)
         self.d = d
         self.ref = C.byref(d)
         self.like = x0
+
+    def io_formats(self, mode):
+        """(format the inputs of this call must have, may the output be B16) — mode 0 fwd, 1 dgrad, 2 wgrad."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        rc = lib.load().avsep_conv_io_formats(self.ref, mode, C.byref(a), C.byref(b))
+        if rc != 0:
+            raise lib.AvsepError(f"avsep_conv_io_formats failed ({rc})")
+        return a.value, bool(b.value)
+
+    def _x_as(self, fmt):
+        """Hand the kernel x0 in the format it stages."""
+        if self.d.xfmt != fmt:
+            x = as_fmt(self.keep[0], fmt)
+            self.keep.append(x)
+            self.d.x0, self.d.xfmt = ptr(x), fmt
+
+    def _out(self, shape_nchw, want, allowed):
+        b = bool(want) and allowed and b16_ok(shape_nchw[1])
+        return (_b16(shape_nchw, self.like) if b else _f32(shape_nchw, self.like)), (FMT_B16 if b else FMT_F32)
 
     def pack(self, w, mode):
         """Operand image of `w` for this call (mode 0 forward, 1 data gradient).  Inside a `pack_scope()` — one train step,
@@ -111,14 +223,23 @@ class Conv:
         ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=self.like.device) if nbytes else None
         return ws, nbytes
 
-    def fwd(self, w_packed, bias=None, stats=None):
-        y = _f32((self.N, self.Cout, self.Ho, self.Wo), self.like)
+    def fwd(self, w_packed, bias=None, stats=None, out_b16=None):
+        """`out_b16`: ask for the output as a B16 image (default: whenever the arithmetic mode keeps B16 activations);
+        granted when this call's kernel can write one, else the result is fp32 NCHW."""
+        need, allowed = self.io_formats(0)
+        self._x_as(need)
+        y, self.d.yfmt = self._out((self.N, self.Cout, self.Ho, self.Wo), want_b16(self.Cout) if out_b16 is None else out_b16,
+                                   allowed)
         ws, nbytes = self._ws("avsep_conv2d_fwd_workspace_bytes")
         call("avsep_conv2d_fwd", self.ref, ptr(w_packed), ptr(bias), ptr(y), ptr(stats), ptr(ws), nbytes)
         return y
 
-    def dgrad(self, w_packed_d, dy):
-        dx = _f32((self.N, self.Cin, self.H, self.W), self.like)
+    def dgrad(self, w_packed_d, dy, out_b16=None):
+        need, allowed = self.io_formats(1)
+        dy = as_fmt(dy, need)
+        self.d.dyfmt = need
+        dx, self.d.dxfmt = self._out((self.N, self.Cin, self.H, self.W), want_b16(self.Cin) if out_b16 is None else out_b16,
+                                     allowed)
         ws, nbytes = self._ws("avsep_conv2d_dgrad_workspace_bytes")
         call("avsep_conv2d_dgrad", self.ref, ptr(w_packed_d), ptr(dy), ptr(dx), ptr(ws), nbytes)
         return dx
@@ -150,7 +271,7 @@ class Conv:
         g0 = g0_acc if g0_acc is not None else torch.empty_like(x0)
         g1 = torch.empty_like(x1) if x1 is not None else None
         ws, nbytes = self._ws("avsep_conv2d_dgrad_up2x_workspace_bytes")
-        call("avsep_conv2d_dgrad_up2x", self.ref, ptr(w), ptr(dy), ptr(g0), ptr(g1), ptr(mean1), ptr(invstd1),
+        call("avsep_conv2d_dgrad_up2x", self.ref, ptr(w), ptr(to_f32(dy)), ptr(g0), ptr(g1), ptr(mean1), ptr(invstd1),
              ptr(bstats1), int(g0_acc is not None), ptr(ws), nbytes)
         return g0, g1
 
@@ -159,6 +280,10 @@ class Conv:
         shape = (self.Cout, self.Cin, self.KH, self.KW)
         if out is not None and (tuple(out.shape) != shape or not out.is_contiguous() or out.dtype != torch.float32):
             raise lib.AvsepError("wgrad destination must be a dense fp32 OIHW tensor")
+        need, _ = self.io_formats(2)
+        self._x_as(need)
+        dy = as_fmt(dy, need)
+        self.d.dyfmt = need
         dw = out if out is not None else _f32(shape, self.like)
         db = (out_bias if out_bias is not None else _f32((self.Cout,), self.like)) if want_bias else None
         nbytes = lib.load().avsep_conv2d_wgrad_workspace_bytes(self.ref)
@@ -206,6 +331,7 @@ def zeros_stats(c, like):
 
 
 def channel_stats(x, stats):
+    x = to_f32(x)
     N, Cc = x.shape[:2]
     call("avsep_channel_stats", ptr(x), N, Cc, x.numel() // (N * Cc), ptr(stats))
 
@@ -230,37 +356,83 @@ def bn_bwd_coeffs(bstats, count, gamma, mean, invstd, dgamma=None, dbeta=None):
     return dgamma, dbeta, pqr
 
 
-def bn_bwd_apply_(dz, y, pqr, out=None):
-    """dy = p*dz + q*y + r per channel; in place on dz unless `out` is given."""
-    N, Cc = y.shape[:2]
-    dst = dz if out is None else out
-    call("avsep_bn_bwd_apply", ptr(dz), ptr(y), ptr(pqr), N, Cc, y.numel() // (N * Cc), ptr(dst))
+def _drop_twin(t):
+    """`t` is about to be overwritten through a raw pointer: forget its converted twin (to_b16 / to_f32 cache)."""
+    if t is not None and hasattr(t, "_avsep_twin"):
+        other = t._avsep_twin[0]
+        if hasattr(other, "_avsep_twin") and other._avsep_twin[0] is t:
+            del other._avsep_twin
+        del t._avsep_twin
+
+
+def _same_fmt(main, *others):
+    """The elementwise kernels take all their tensor operands in ONE format: that of `main`."""
+    f = fmt_of(main)
+    return [as_fmt(o, f) for o in others]
+
+
+def bn_bwd_apply_(dz, y, pqr, out=None, fresh=False):
+    """dy = p*dz + q*y + r per channel, in y's storage format; in place on dz unless `out` is given or `fresh` asks for a
+    new tensor.  Returns the result tensor."""
+    N, Cc, H, W = dims(y)
+    (dz,) = _same_fmt(y, dz)
+    dst = torch.empty_like(y) if fresh else (dz if out is None else out)
+    _drop_twin(dst)
+    if is_b16(y):
+        call("avsep_b16_bn_bwd_apply", ptr(dz), ptr(y), ptr(pqr), N, Cc, H * W, ptr(dst))
+    else:
+        call("avsep_bn_bwd_apply", ptr(dz), ptr(y), ptr(pqr), N, Cc, H * W, ptr(dst))
     return dst
 
 
 def affine_act(y, scale, shift, residual, act, res_scale=None, res_shift=None):
-    N, Cc = y.shape[:2]
+    N, Cc, H, W = dims(y)
     z = torch.empty_like(y)
-    call("avsep_affine_act", ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift), act, N, Cc,
-         y.numel() // (N * Cc), ptr(z))
+    (residual,) = _same_fmt(y, residual)
+    if is_b16(y):
+        call("avsep_b16_affine_act", ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift), act, N, Cc,
+             H * W, ptr(z))
+    else:
+        call("avsep_affine_act", ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift), act, N, Cc,
+             H * W, ptr(z))
     return z
 
 
 def affine_act_bwd_(dz, y, scale, shift, residual, add, mean, invstd, act, bstats, res_scale=None, res_shift=None,
-                    out=None, dz2=None):
-    """dz <- act'(scale*y+shift[+res]) * (dz [+ dz2]) (+ add) (in place unless `out`); accumulates bstats."""
-    N, Cc = y.shape[:2]
+                    out=None, dz2=None, stats_only=False):
+    """dz <- act'(scale*y+shift[+res]) * (dz [+ dz2]) (+ add) (in place unless `out`); accumulates bstats.  All tensor
+    operands are brought to the format of `y`; the (possibly converted) result tensor is returned."""
+    N, Cc, H, W = dims(y)
+    dz, dz2, residual, add = _same_fmt(y, dz, dz2, residual, add)
     dst = dz if out is None else out
-    call("avsep_affine_act_bwd", ptr(dz), ptr(dz2), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift),
-         ptr(add), ptr(mean), ptr(invstd), act, N, Cc, y.numel() // (N * Cc), ptr(dst), ptr(bstats))
+    if stats_only and is_b16(y):       # the B16 kernel can skip the write (dz itself is the result: no activation, no add)
+        call("avsep_b16_affine_act_bwd", ptr(dz), ptr(dz2), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale),
+             ptr(res_shift), ptr(add), ptr(mean), ptr(invstd), act, N, Cc, H * W, None, ptr(bstats))
+        return dz
+    _drop_twin(dst)
+    if is_b16(y):
+        call("avsep_b16_affine_act_bwd", ptr(dz), ptr(dz2), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale),
+             ptr(res_shift), ptr(add), ptr(mean), ptr(invstd), act, N, Cc, H * W, ptr(dst), ptr(bstats))
+    else:
+        call("avsep_affine_act_bwd", ptr(dz), ptr(dz2), ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift),
+             ptr(add), ptr(mean), ptr(invstd), act, N, Cc, H * W, ptr(dst), ptr(bstats))
     return dst
 
 
 class Cat:
+    """relu(affine(cat(x0, x1))) -> bilinear x2 (the U-Net decoder's glue).  Two B16 sources (no broadcast vector) run the
+    B16 kernels and produce / consume B16 images; anything else runs the fp32 kernels on fp32 copies."""
+
     def __init__(self, x0, x1, sc0=None, sh0=None, sc1=None, sh1=None, bcast0=False, hw=None):
-        N, C0 = x0.shape[:2]
-        C1 = x1.shape[1] if x1 is not None else 0
-        H, W = hw if hw is not None else (x1.shape[2:] if x1 is not None else x0.shape[2:])
+        self.b16 = (not bcast0 and x1 is not None and (is_b16(x0) or is_b16(x1)) and b16_ok(channels(x0))
+                    and b16_ok(channels(x1)))
+        if self.b16:
+            x0, x1 = to_b16(x0), to_b16(x1)
+        else:
+            x0, x1 = to_f32(x0), to_f32(x1)
+        N, C0 = (x0.shape[0], x0.shape[1]) if bcast0 else dims(x0)[:2]
+        C1 = channels(x1) if x1 is not None else 0
+        H, W = hw if hw is not None else (dims(x1)[2:] if x1 is not None else dims(x0)[2:])
         self.shape = (N, C0, C1, H, W)
         self.keep = (x0, x1, sc0, sh0, sc1, sh1)
         d = CatDesc()
@@ -271,14 +443,32 @@ class Cat:
 
     def fwd(self):
         N, C0, C1, H, W = self.shape
+        x0, x1, sc0, sh0, sc1, sh1 = self.keep
+        if self.b16:
+            out = _b16((N, C0 + C1, 2 * H, 2 * W), self.like)
+            call("avsep_b16_relu_up2x_fwd", ptr(x0), ptr(x1), ptr(sc0), ptr(sh0), ptr(sc1), ptr(sh1), N, C0, C1, H, W, ptr(out))
+            return out
         out = _f32((N, C0 + C1, 2 * H, 2 * W), self.like)
         call("avsep_relu_up2x_fwd", self.ref, ptr(out))
         return out
 
     def bwd(self, dout, mean1=None, invstd1=None, bstats1=None, g0_acc=None):
-        """g0_acc: an existing source-0 gradient to accumulate into (shared-encoder AV step)."""
+        """g0_acc: an existing source-0 gradient to accumulate into (shared-encoder AV step; must be in this Cat's format)."""
         N, C0, C1, H, W = self.shape
+        x0, x1, sc0, sh0, sc1, sh1 = self.keep
+        if self.b16:
+            dout = to_b16(dout)
+            g0 = g0_acc if g0_acc is not None else _b16((N, C0, H, W), self.like)
+            assert is_b16(g0), "accumulating into an fp32 skip gradient from a B16 decoder level"
+            _drop_twin(g0)
+            g1 = _b16((N, C1, H, W), self.like)
+            call("avsep_b16_relu_up2x_bwd", ptr(x0), ptr(x1), ptr(sc0), ptr(sh0), ptr(sc1), ptr(sh1), N, C0, C1, H, W, ptr(dout),
+                 ptr(g0), ptr(g1), ptr(mean1), ptr(invstd1), ptr(bstats1), int(g0_acc is not None))
+            return g0, g1
+        dout = to_f32(dout)
         g0 = g0_acc if g0_acc is not None else _f32((N, C0) if self.bcast0 else (N, C0, H, W), self.like)
+        assert not is_b16(g0)
+        _drop_twin(g0)
         g1 = _f32((N, C1, H, W), self.like) if C1 else None
         call("avsep_relu_up2x_bwd", self.ref, ptr(dout), ptr(g0), ptr(g1), ptr(mean1), ptr(invstd1),
              ptr(bstats1), int(g0_acc is not None))
@@ -324,9 +514,15 @@ def temporal_mean_bwd(dy, B, T):
 
 
 def maxpool3x3s2(x, scale=None, shift=None, act=0):
-    """MaxPool2d(3,2,1) of act(scale*x+shift) (the stem's BN+ReLU folded into the pooling read)."""
-    N, Cc, H, W = x.shape
+    """MaxPool2d(3,2,1) of act(scale*x+shift) (the stem's BN+ReLU folded into the pooling read).  B16 in -> B16 out with a
+    one-byte winning-tap image; fp32 in -> fp32 out with int32 flat indices."""
+    N, Cc, H, W = dims(x)
     Ho, Wo = out_size(H, 3, 2, 1, 1), out_size(W, 3, 2, 1, 1)
+    if is_b16(x):
+        y = _b16((N, Cc, Ho, Wo), x)
+        idx = torch.empty((N, Cc // 16, Ho, Wo, 16), dtype=torch.uint8, device=x.device)
+        call("avsep_b16_maxpool3x3s2_fwd", ptr(x), ptr(scale), ptr(shift), act, N, Cc, H, W, ptr(y), ptr(idx))
+        return y, idx
     y = _f32((N, Cc, Ho, Wo), x)
     idx = torch.empty((N, Cc, Ho, Wo), dtype=torch.int32, device=x.device)
     call("avsep_maxpool3x3s2_fwd", ptr(x), ptr(scale), ptr(shift), act, Cc, N * Cc, H, W, ptr(y), ptr(idx))
@@ -340,26 +536,46 @@ def maxpool3x3s2_bwd(dy, idx, H, W):
     return dx
 
 
-def space_to_depth2(x, cp=16):
-    """[N,C,H,W] -> [N,cp,H/2+3,W/2+3]: the 2x2 phases of x as channels, zero border (2 before, 1 after): see avsep.h."""
+def space_to_depth2(x, cp=16, b16=None):
+    """[N,C,H,W] -> [N,cp,H/2+3,W/2+3]: the 2x2 phases of x as channels, zero border (2 before, 1 after): see avsep.h.
+    With `b16` (default: the arithmetic mode keeps B16 activations) the result is written as a one-block B16 image."""
     N, Cc, H, W = x.shape
+    if (want_b16(cp) if b16 is None else b16) and cp == 16:
+        xs = _b16((N, 16, H // 2 + 3, W // 2 + 3), x)
+        call("avsep_b16_space_to_depth2", ptr(x), N, Cc, H, W, ptr(xs))
+        return xs
     xs = _f32((N, cp, H // 2 + 3, W // 2 + 3), x)
     call("avsep_space_to_depth2", ptr(x), N, Cc, H, W, cp, ptr(xs))
     return xs
 
 
-def maxpool_bn_relu_bwd_stats(g, idx, y, bnrow, bstats):
-    """BatchNorm-backward sums of the stem tail taken over the pooled grid (see avsep.h); bstats is accumulated into."""
-    N, Cc, H, W = y.shape
-    call("avsep_maxpool_bn_relu_bwd_stats", ptr(g), ptr(idx), ptr(y), ptr(bnrow[0]), ptr(bnrow[1]), ptr(bnrow[2]), ptr(bnrow[3]),
+def maxpool_bn_relu_bwd_stats(g, idx, y, bnrow, bstats, g2=None):
+    """BatchNorm-backward sums of the stem tail taken over the pooled grid (see avsep.h); bstats is accumulated into.
+    `g2`: a second gradient of the pooled map, added on the fly (B16 images only; fp32 callers add it beforehand)."""
+    N, Cc, H, W = dims(y)
+    if is_b16(y):
+        g, g2 = to_b16(g), to_b16(g2)
+        call("avsep_b16_maxpool_bn_relu_bwd", ptr(g), ptr(g2), ptr(idx), ptr(y), ptr(bnrow[0]), ptr(bnrow[1]), ptr(bnrow[2]),
+             ptr(bnrow[3]), None, N, Cc, H, W, ptr(bstats), None, 0)
+        return
+    assert g2 is None
+    call("avsep_maxpool_bn_relu_bwd_stats", ptr(to_f32(g)), ptr(idx), ptr(y), ptr(bnrow[0]), ptr(bnrow[1]), ptr(bnrow[2]), ptr(bnrow[3]),
          N, Cc, H, W, ptr(bstats))
 
 
-def maxpool_bn_relu_bwd_apply(g, idx, y, bnrow, pqr):
-    """dL/d(raw stem conv output) from dL/d(pooled): max-pool backward + ReLU mask + folded BatchNorm backward in one pass."""
-    N, Cc, H, W = y.shape
+def maxpool_bn_relu_bwd_apply(g, idx, y, bnrow, pqr, g2=None, out_f32=False):
+    """dL/d(raw stem conv output) from dL/d(pooled): max-pool backward + ReLU mask + folded BatchNorm backward in one pass.
+    `out_f32` (B16 inputs): write the result as fp32 NCHW (its only consumer, the stem's weight gradient, is an fp32 kernel)."""
+    N, Cc, H, W = dims(y)
+    if is_b16(y):
+        g, g2 = to_b16(g), to_b16(g2)
+        dy = _f32((N, Cc, H, W), y) if out_f32 else torch.empty_like(y)
+        call("avsep_b16_maxpool_bn_relu_bwd", ptr(g), ptr(g2), ptr(idx), ptr(y), ptr(bnrow[0]), ptr(bnrow[1]), None, None, ptr(pqr),
+             N, Cc, H, W, None, ptr(dy), int(out_f32))
+        return dy
     dy = torch.empty_like(y)
-    call("avsep_maxpool_bn_relu_bwd_apply", ptr(g), ptr(idx), ptr(y), ptr(bnrow[0]), ptr(bnrow[1]), ptr(pqr), N, Cc, H, W, ptr(dy))
+    assert g2 is None
+    call("avsep_maxpool_bn_relu_bwd_apply", ptr(to_f32(g)), ptr(idx), ptr(y), ptr(bnrow[0]), ptr(bnrow[1]), ptr(pqr), N, Cc, H, W, ptr(dy))
     return dy
 
 

@@ -24,7 +24,7 @@ class AvsepError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                "N Cin H W Cout Ho Wo KH KW stride pad dil C0 act0 act1 up2x prec plan_n".split()] + \
+                "N Cin H W Cout Ho Wo KH KW stride pad dil C0 act0 act1 up2x prec plan_n xfmt yfmt dyfmt dxfmt".split()] + \
                [(n, C.c_void_p) for n in "x0 x1 scale0 shift0 scale1 shift1".split()]
 
 
@@ -43,6 +43,7 @@ SIGNATURES = {
     "avsep_strerror": (C.c_char_p, [C.c_int]),
     "avsep_conv_packed_floats": (_Z, [_CD, C.c_int]),
     "avsep_conv_pack_weights": (C.c_int, [_CD, _P, _P, C.c_int, _P]),
+    "avsep_conv_io_formats": (C.c_int, [_CD, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "avsep_conv2d_fwd_workspace_bytes": (_Z, [_CD]),
     "avsep_conv2d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _Z, _P]),
     "avsep_conv2d_dgrad_workspace_bytes": (_Z, [_CD]),
@@ -95,6 +96,16 @@ SIGNATURES = {
     "avsep_innerprod_nosum": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "avsep_innerprod_pixelwise": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_innerprod_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "avsep_f32_to_b16": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "avsep_b16_to_f32": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "avsep_b16_affine_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "avsep_b16_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_b16_bn_bwd_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "avsep_b16_relu_up2x_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "avsep_b16_relu_up2x_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "avsep_b16_maxpool3x3s2_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_b16_maxpool_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "avsep_b16_space_to_depth2": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "avsep_sdr_sums": (C.c_int, [_P, _P, _I, _I, C.c_int64, C.c_int64, _P, _P]),
 }
 

@@ -267,7 +267,7 @@ def _encode(net, x, training, repeat=1):
                     sh0=aff[1] if aff is not None else None, act0=act)
         st = K.zeros_stats(w.shape[0], x) if (l.down_bn is not None and training) else None
         y = cv.fwd(cv.pack(w, 0), None, st)
-        bn = _bn_run(l.down_bn, st, y.numel() // y.shape[1], training, x, repeat) if l.down_bn is not None else None
+        bn = _bn_run(l.down_bn, st, K.per_channel(y), training, x, repeat) if l.down_bn is not None else None
         E["dconv"].append(cv); E["yd"].append(y); E["dbn"].append(bn)
         src, aff, act = y, bn, ACT_LRELU02
     return E
@@ -277,7 +277,7 @@ def _decode(net, E, vs, draws, training):
     """Bottleneck fusion (or the SoP++ split) + the up path: ReLU + bilinear x2 + conv k3 p1 over concat(skip, inner)."""
     lv, x = E["lv"], E["x"]
     L = len(lv)
-    ybot = E["yd"][-1]
+    ybot = K.to_f32(E["yd"][-1])             # the fusion kernels and the SoP++ split read fp32
     extra = fus = feat_vec = None
     if net.extra_size is None:
         fus = net.fusion.run_forward(ybot, vs, draws)
@@ -309,8 +309,9 @@ def _decode(net, E, vs, draws, training):
             cv.head = False
         st = K.zeros_stats(w.shape[0], x) if (l.up_bn is not None and training) else None
         bias = l.up_conv.bias.detach() if l.up_conv.bias is not None else None
-        y = cv.fwd(cv.pack(w, 0), bias, st)
-        bn = _bn_run(l.up_bn, st, y.numel() // y.shape[1], training, x) if l.up_bn is not None else None
+        # the level below the fused head feeds fp32 kernels only (head forward / gradients, BatchNorm backward on fp32 dz)
+        y = cv.fwd(cv.pack(w, 0), bias, st, out_b16=False if (i == 1 and net.fuse_head) else None)
+        bn = _bn_run(l.up_bn, st, K.per_channel(y), training, x) if l.up_bn is not None else None
         D["uconv"][i], D["yu"][i], D["ubn"][i], D["cat"][i] = cv, y, bn, cat
     return D
 
@@ -331,9 +332,9 @@ def _decode_bwd(net, E, D, dlogits, dsecond, has_vis, grads, Gd):
             bst = K.zeros_stats(ubn.shape[1], x)
             Gd[i], dz = cv.dgrad_up2x(w, g, mean1=ubn[2], invstd1=ubn[3], bstats1=bst, g0_acc=Gd[i])
             yu = D["yu"][i + 1]
-            g = K.bn_bwd_apply_(dz, yu, _bn_back(grads, lv[i + 1].up_bn, ubn, bst, yu.numel() // yu.shape[1]))
+            g = K.bn_bwd_apply_(dz, yu, _bn_back(grads, lv[i + 1].up_bn, ubn, bst, K.per_channel(yu)))
             continue
-        dU = cv.dgrad(cv.pack(w, 1), g)                    # wrt the (virtual) upsampled input
+        dU = cv.dgrad(cv.pack(w, 1), g, out_b16=cat.b16)   # wrt the (virtual) upsampled input, in the format cat.bwd reads
         if i == L - 1:
             if net.extra_size is None:
                 dfeat, dbot = cat.bwd(dU)
@@ -345,7 +346,7 @@ def _decode_bwd(net, E, D, dlogits, dsecond, has_vis, grads, Gd):
             bst = K.zeros_stats(ubn.shape[1], x)
             Gd[i], dz = cat.bwd(dU, mean1=ubn[2], invstd1=ubn[3], bstats1=bst, g0_acc=Gd[i])
             yu = D["yu"][i + 1]
-            pqr = _bn_back(grads, lv[i + 1].up_bn, ubn, bst, yu.numel() // yu.shape[1])
+            pqr = _bn_back(grads, lv[i + 1].up_bn, ubn, bst, K.per_channel(yu))
             g = K.bn_bwd_apply_(dz, yu, pqr)
         del dU
     dvs = []
@@ -362,14 +363,15 @@ def _encode_bwd(net, E, dbot, Gd, grads):
         l, cv = lv[i], E["dconv"][i]
         w = l.down_conv.weight.detach()
         grads.wgrad(cv, l.down_conv.weight, g)
-        dS = cv.dgrad(cv.pack(w, 1), g)                   # wrt act(BN(prev)) (or BN0(x) for i == 0)
+        # wrt act(BN(prev)) (or BN0(x) for i == 0), in the storage format of the tensor whose mask / statistics come next
+        dS = cv.dgrad(cv.pack(w, 1), g, out_b16=K.is_b16(E["yd"][i - 1]) if i > 0 else False)
         if i > 0:
             yprev, bn = E["yd"][i - 1], E["dbn"][i - 1]
-            bst = K.zeros_stats(yprev.shape[1], x) if bn is not None else None
-            K.affine_act_bwd_(dS, yprev, bn[0] if bn is not None else None, bn[1] if bn is not None else None,
-                              None, Gd[i - 1], bn[2] if bn is not None else None,
-                              bn[3] if bn is not None else None, ACT_LRELU02, bst)
-            g = K.bn_bwd_apply_(dS, yprev, _bn_back(grads, lv[i - 1].down_bn, bn, bst, yprev.numel() // yprev.shape[1])) \
+            bst = K.zeros_stats(K.channels(yprev), x) if bn is not None else None
+            dS = K.affine_act_bwd_(dS, yprev, bn[0] if bn is not None else None, bn[1] if bn is not None else None,
+                                   None, Gd[i - 1], bn[2] if bn is not None else None,
+                                   bn[3] if bn is not None else None, ACT_LRELU02, bst)
+            g = K.bn_bwd_apply_(dS, yprev, _bn_back(grads, lv[i - 1].down_bn, bn, bst, K.per_channel(yprev))) \
                 if bn is not None else dS
         else:
             bn0 = E["bn0"]

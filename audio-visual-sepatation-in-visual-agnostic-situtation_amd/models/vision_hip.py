@@ -46,7 +46,7 @@ def _conv_bn(src, conv, bn, training, aff=None):
     cv = _conv(src, conv, aff)
     st = K.zeros_stats(conv.out_channels, src) if training else None
     y = cv.fwd(cv.pack(_w(conv), 0), None, st)
-    return cv, y, _bn_run(bn, st, y.numel() // y.shape[1], training, src)
+    return cv, y, _bn_run(bn, st, K.per_channel(y), training, src)
 
 
 def blocks_of(features):
@@ -95,7 +95,7 @@ def stem_forward(f, x, training):
         cs = K.Conv(K.space_to_depth2(x), f[0].out_channels, 4, 1, 0)
         st = K.zeros_stats(f[0].out_channels, x) if training else None
         S["y0"] = cs.fwd(cs.pack(_stem_s2d_weight(_w(f[0])), 0), None, st)
-        S["bn0"] = _bn_run(f[1], st, S["y0"].numel() // S["y0"].shape[1], training, x)
+        S["bn0"] = _bn_run(f[1], st, K.per_channel(S["y0"]), training, x)
     else:
         S["cv0"], S["y0"], S["bn0"] = _conv_bn(x, f[0], f[1], training)
     z, S["idx"] = K.maxpool3x3s2(S["y0"], S["bn0"][0], S["bn0"][1], ACT_RELU)
@@ -126,7 +126,7 @@ def block_forward(blk, z, training):
 def fc_forward(fc, z):
     cvf = _conv(z, fc)
     bias = fc.bias.detach() if fc.bias is not None else None
-    return cvf, cvf.fwd(cvf.pack(_w(fc), 0), bias, None)
+    return cvf, cvf.fwd(cvf.pack(_w(fc), 0), bias, None, out_b16=False)     # consumed by torch ops (temporal mean, activate)
 
 
 def trunk_forward(net, x, training):
@@ -140,11 +140,12 @@ def trunk_forward(net, x, training):
 
 
 def _relu_bn_back(grads, g, y, bnrow, bn_mod, res=None, rs=None, rh=None, g2=None):
-    """g <- relu'(bn(y) [+ residual]) * (g [+ g2]) in place; returns the folded BatchNorm-backward coefficients of bn(y)."""
-    bst = K.zeros_stats(y.shape[1], y)
-    K.affine_act_bwd_(g, y, bnrow[0], bnrow[1], res, None, bnrow[2], bnrow[3], ACT_RELU, bst, res_scale=rs, res_shift=rh,
-                      dz2=g2)
-    return _bn_back(grads, bn_mod, bnrow, bst, y.numel() // y.shape[1])
+    """g <- relu'(bn(y) [+ residual]) * (g [+ g2]) (in place when g already has y's storage format); returns (g, the folded
+    BatchNorm-backward coefficients of bn(y))."""
+    bst = K.zeros_stats(K.channels(y), y)
+    g = K.affine_act_bwd_(g, y, bnrow[0], bnrow[1], res, None, bnrow[2], bnrow[3], ACT_RELU, bst, res_scale=rs, res_shift=rh,
+                          dz2=g2)
+    return g, _bn_back(grads, bn_mod, bnrow, bst, K.per_channel(y))
 
 
 def fc_backward(fc, cvf, dout, grads):
@@ -159,22 +160,22 @@ def block_backward(R, g, grads, g2=None):
     blk = R["mod"]
     ds = blk.downsample is not None
     bnd = R.get("bnd")
-    pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
-                         rs=bnd[0] if ds else None, rh=bnd[1] if ds else None, g2=g2)   # g = dL/d(pre-ReLU sum)
-    dy2 = K.bn_bwd_apply_(g, R["y2"], pqr2, out=torch.empty_like(g))
+    g, pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
+                            rs=bnd[0] if ds else None, rh=bnd[1] if ds else None, g2=g2)   # g = dL/d(pre-ReLU sum)
+    dy2 = K.bn_bwd_apply_(g, R["y2"], pqr2, fresh=True)
     grads.wgrad(R["cv2"], blk.conv2.weight, dy2)
     da = R["cv2"].dgrad(R["cv2"].pack(_w(blk.conv2), 1), dy2)
     del dy2
-    pqr1 = _relu_bn_back(grads, da, R["y1"], R["bn1"], blk.bn1)
-    K.bn_bwd_apply_(da, R["y1"], pqr1)                              # da = dL/dy1
+    da, pqr1 = _relu_bn_back(grads, da, R["y1"], R["bn1"], blk.bn1)
+    da = K.bn_bwd_apply_(da, R["y1"], pqr1)                         # da = dL/dy1
     grads.wgrad(R["cv1"], blk.conv1.weight, da)
     dz = R["cv1"].dgrad(R["cv1"].pack(_w(blk.conv1), 1), da)
     del da
     if ds:
-        bst = K.zeros_stats(g.shape[1], g)                          # BNd statistics of g (values of g unchanged)
-        K.affine_act_bwd_(g, R["yd"], None, None, None, None, bnd[2], bnd[3], ACT_NONE, bst)
-        pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, g.numel() // g.shape[1])
-        K.bn_bwd_apply_(g, R["yd"], pqrd)                           # g = dL/dyd
+        bst = K.zeros_stats(K.channels(g), g)                       # BNd statistics of g (values of g unchanged)
+        g = K.affine_act_bwd_(g, R["yd"], None, None, None, None, bnd[2], bnd[3], ACT_NONE, bst, stats_only=True)
+        pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, K.per_channel(g))
+        g = K.bn_bwd_apply_(g, R["yd"], pqrd)                       # g = dL/dyd
         grads.wgrad(R["cvd"], blk.downsample[0].weight, g)
         return dz, R["cvd"].dgrad(R["cvd"].pack(_w(blk.downsample[0]), 1), g)
     return dz, g
@@ -183,12 +184,14 @@ def block_backward(R, g, grads, g2=None):
 def stem_backward(f, S, g, grads, g2=None):
     y0, bn0 = S["y0"], S["bn0"]
     g = g.contiguous()
-    if g2 is not None:
-        g.add_(g2)
-    bst = K.zeros_stats(y0.shape[1], y0)
-    K.maxpool_bn_relu_bwd_stats(g, S["idx"], y0, bn0, bst)          # sums over the pooled grid: dz is never written
-    pqr0 = _bn_back(grads, f[1], bn0, bst, y0.numel() // y0.shape[1])
-    dy0 = K.maxpool_bn_relu_bwd_apply(g, S["idx"], y0, bn0, pqr0)   # pool backward + ReLU mask + BatchNorm backward
+    if g2 is not None and not K.is_b16(y0):
+        g = K.to_f32(g).add_(K.to_f32(g2))
+        g2 = None                                                   # B16 images: the two kernels below add g2 on the fly
+    bst = K.zeros_stats(K.channels(y0), y0)
+    K.maxpool_bn_relu_bwd_stats(g, S["idx"], y0, bn0, bst, g2)      # sums over the pooled grid: dz is never written
+    pqr0 = _bn_back(grads, f[1], bn0, bst, K.per_channel(y0))
+    # pool backward + ReLU mask + BatchNorm backward; fp32 out: the stem's weight gradient (3 input channels) is an fp32 kernel
+    dy0 = K.maxpool_bn_relu_bwd_apply(g, S["idx"], y0, bn0, pqr0, g2, out_f32=True)
     grads.wgrad(S["cv0"], f[0].weight, dy0)                         # the frames need no gradient
 
 

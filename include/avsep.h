@@ -38,6 +38,15 @@ extern "C" {
 #define AVSEP_PREC_F32 0
 #define AVSEP_PREC_BF16 1
 
+/* Storage format of an activation / gradient tensor [N,C,H,W]:
+ *   AVSEP_FMT_F32: dense fp32 NCHW (the reference's tensors);
+ *   AVSEP_FMT_B16: bf16, channel-blocked  [N][C/16][H][W][16]  (C % 16 == 0): the 16 channels of a block at one position
+ *                  are 32 contiguous bytes — exactly one position of the bf16 kernels' LDS patch, so an operand is staged
+ *                  with one 16-byte load per (position, 8-channel half) and no conversion.  Used between the bf16 kernels
+ *                  (BASELINE.json configs[2]: half the HBM bytes of fp32 activations). */
+#define AVSEP_FMT_F32 0
+#define AVSEP_FMT_B16 1
+
 typedef void* avsep_stream_t;
 
 int avsep_version(void);
@@ -72,6 +81,9 @@ typedef struct avsep_conv_desc {
                                   call takes the decisions of the batch-64 call (grids and workspaces stay those of N).  The
                                   parity tests use it to run the benched dispatch at an oracle-sized batch; results never
                                   depend on it beyond the summation order of the chosen kernel. */
+  int32_t xfmt, yfmt;          /* AVSEP_FMT_* of x0 (forward / weight gradient) and of y as avsep_conv2d_fwd writes it */
+  int32_t dyfmt, dxfmt;        /* AVSEP_FMT_* of dy (data / weight gradient) and of dx as avsep_conv2d_dgrad writes it.
+                                  avsep_conv_io_formats tells which formats a call takes; B16 pointers are passed as float* */
   const float* x0;
   const float* x1;
   const float* scale0;         /* [C0] or NULL */
@@ -91,6 +103,11 @@ int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w, float* pac
  * per-channel sum and sum of squares of y, for the following BatchNorm.
  * workspace (avsep_conv2d_fwd_workspace_bytes; may be 0/NULL): split-K partial slabs for layers whose
  * output grid cannot fill the chip; without it the call falls back to an unsplit launch.        */
+/* Formats of a call (mode 0 forward, 1 data gradient, 2 weight gradient) under d->prec and the geometry:
+ * *in_fmt = the AVSEP_FMT_* its input tensors MUST have (x0 for mode 0; dy for mode 1; x0 and dy for mode 2),
+ * *out_b16 = 1 when the output (y / dx) may be requested as AVSEP_FMT_B16 through d->yfmt / d->dxfmt (fp32 always may).
+ * A call whose descriptor disagrees returns AVSEP_ERR_ARG. */
+int avsep_conv_io_formats(const avsep_conv_desc* d, int32_t mode, int32_t* in_fmt, int32_t* out_b16);
 size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d);
 int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed, const float* bias, float* y,
                      double* stats, void* workspace, size_t workspace_bytes, avsep_stream_t stream);
@@ -346,6 +363,49 @@ int avsep_innerprod_bwd(const float* img, const float* snd, const float* scale, 
  * sums[3r..] += (<est,ref>, <ref,ref>, <est,est>) over L samples; SI-SDR and SDR are ratios of them. */
 int avsep_sdr_sums(const float* est, const float* ref, int32_t R, int32_t L, int64_t est_stride,
                    int64_t ref_stride, double* sums, avsep_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * AVSEP_FMT_B16 images (bf16, [N][C/16][H][W][16]; csrc/b16.hip): what travels between the bf16 convolution kernels.
+ * HW = H*W positions; every entry point is one HBM pass with 16-byte accesses.  Statistics buffers are pre-zeroed doubles
+ * that are accumulated into, exactly as for the fp32 NCHW entry points of the same names below.
+ * ------------------------------------------------------------------------- */
+int avsep_f32_to_b16(const float* x, int32_t N, int32_t C, int32_t HW, void* out, avsep_stream_t stream);
+int avsep_b16_to_f32(const void* x, int32_t N, int32_t C, int32_t HW, float* out, avsep_stream_t stream);
+/* z = act(scale*y + shift [+ res_scale*residual + res_shift | + residual])   (BasicBlock tail; act NONE/RELU/LRELU02) */
+int avsep_b16_affine_act(const void* y, const float* scale, const float* shift, const void* residual,
+                         const float* res_scale, const float* res_shift, int32_t act, int32_t N, int32_t C, int32_t HW,
+                         void* z, avsep_stream_t stream);
+/* out = act'(scale*y + shift [+ residual term]) * (dz [+ dz2]) [+ add]  (out may alias dz; NULL = statistics only);
+ * bstats[2*C] += (sum out, sum out * (y - mean) * invstd) */
+int avsep_b16_affine_act_bwd(const void* dz, const void* dz2, const void* y, const float* scale, const float* shift,
+                             const void* residual, const float* res_scale, const float* res_shift, const void* add,
+                             const float* mean, const float* invstd, int32_t act, int32_t N, int32_t C, int32_t HW,
+                             void* out, double* bstats, avsep_stream_t stream);
+/* out = p*dz + q*y + r with pqr[3*C] from avsep_bn_bwd_coeffs (out may alias dz) */
+int avsep_b16_bn_bwd_apply(const void* dz, const void* y, const float* pqr, int32_t N, int32_t C, int32_t HW, void* out,
+                           avsep_stream_t stream);
+/* out [N][(C0+C1)/16][2H][2W][16] = bilinear x2 (align_corners) of relu(affine(cat(x0, x1)))   (audio_net.py:66-69,122) */
+int avsep_b16_relu_up2x_fwd(const void* x0, const void* x1, const float* sc0, const float* sh0, const float* sc1,
+                            const float* sh1, int32_t N, int32_t C0, int32_t C1, int32_t H, int32_t W, void* out,
+                            avsep_stream_t stream);
+/* its adjoint: g0 / g1 = gradient wrt the pre-ReLU affine values of the two low-res sources (acc0: add into g0);
+ * bstats1[2*C1] += BatchNorm-backward sums of source 1 (needs mean1 / invstd1) */
+int avsep_b16_relu_up2x_bwd(const void* x0, const void* x1, const float* sc0, const float* sh0, const float* sc1,
+                            const float* sh1, int32_t N, int32_t C0, int32_t C1, int32_t H, int32_t W, const void* dout,
+                            void* g0, void* g1, const float* mean1, const float* invstd1, double* bstats1, int32_t acc0,
+                            avsep_stream_t stream);
+/* z = MaxPool2d(3,2,1)(act(scale*y + shift)); idx: one byte per element (winning tap kh*3+kw), blocked like z */
+int avsep_b16_maxpool3x3s2_fwd(const void* y, const float* scale, const float* shift, int32_t act, int32_t N, int32_t C,
+                               int32_t H, int32_t W, void* z, void* idx, avsep_stream_t stream);
+/* fused stem-tail backward (avsep_maxpool_bn_relu_bwd_stats / _apply on B16 images): dy == NULL -> pass 1 (bstats),
+ * else pass 2 (dy = p*dz + q*y + r; dy_f32 != 0: dy is written as fp32 NCHW for the fp32 stem weight gradient);
+ * g2 (may be NULL) is added to g on the fly */
+int avsep_b16_maxpool_bn_relu_bwd(const void* g, const void* g2, const void* idx, const void* y, const float* scale,
+                                  const float* shift, const float* mean, const float* invstd, const float* pqr,
+                                  int32_t N, int32_t C, int32_t H, int32_t W, double* bstats, void* dy, int32_t dy_f32,
+                                  avsep_stream_t stream);
+/* avsep_space_to_depth2 written as a one-block B16 image [N][1][H/2+3][W/2+3][16] (4*C <= 16) */
+int avsep_b16_space_to_depth2(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, void* xs, avsep_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -174,10 +174,13 @@ BF16_CASES = [
 
 @pytest.mark.parametrize("case", BF16_CASES)
 def test_conv_bf16_operands(dev, case):
-    """avsep_conv_desc.prec = AVSEP_PREC_BF16: the kernel must equal a float64 convolution of the bf16-ROUNDED operands
-    (activation after the folded affine rounded to bf16, weights rounded to bf16) up to fp32 accumulation order; the
-    BatchNorm statistics are those of the fp32 result.  Against the unrounded float32 convolution the difference is the
-    bf16 operand rounding itself (2^-9 relative per operand): reported, bounded loosely."""
+    """avsep_conv_desc.prec = AVSEP_PREC_BF16.  The bf16 kernels stage B16 images (bf16, [N][C/16][H][W][16]): the input is
+    rounded to bf16 when it is stored, the folded affine + activation are applied in fp32 to the stored value (one fmaf)
+    and the result is rounded to bf16 again on its way into LDS; weights (and dY) are rounded once.  The kernel must equal a
+    float64 convolution of exactly those rounded operands up to fp32 accumulation order; the BatchNorm statistics are those
+    of the fp32 result.  A call without a bf16 kernel runs in exact f32 on the unrounded operands.  Outputs requested as
+    B16 images must be the bf16 rounding of the fp32 outputs, bit for bit.  Against the unrounded float32 convolution the
+    difference is the operand rounding itself (2^-9 relative per rounding): reported, bounded loosely."""
     K = _pkg().kernels
     N, Cin, H, W, Cout, k, s, p, d, aff = case
     g = torch.Generator().manual_seed(sum(case))
@@ -185,42 +188,163 @@ def test_conv_bf16_operands(dev, case):
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
     b = torch.randn(Cout, generator=g)
     sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
-    if aff:
+
+    def activated(x_):
+        if not aff:
+            return x_
         # the kernel folds the affine with ONE rounding (fmaf): float64 product + sum rounded once to float32 is the same
         # value; a separately rounded product would differ in the last float32 bit and flip bf16 roundings
-        v = (x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
-        v = F.relu(v) if aff == 1 else torch.where(v > 0, v, 0.2 * v)
-    else:
-        v = x
-    vr, wr = _bf16(v).requires_grad_(True), _bf16(w).requires_grad_(True)
+        v_ = (x_.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
+        return F.relu(v_) if aff == 1 else torch.where(v_ > 0, v_, 0.2 * v_)
+    v = activated(x)                                       # exact-f32 path
+    v16 = activated(x.to(torch.bfloat16).float())          # bf16 kernels: the stored image is rounded first
+    t = lambda z: z.to(dev)
+    cv = K.Conv(t(x), Cout, k, s, p, d, sc0=t(sc) if aff else None, sh0=t(sh) if aff else None, act0=aff, prec="bf16")
+    bf_fwd, bf_dgrad, bf_wgrad = (cv.kernel_name(m) in ("convbf_kernel", "wgradb_kernel") for m in ("fwd", "dgrad", "wgrad"))
+    assert bf_fwd, "every BF16_CASES geometry has a bf16 forward kernel"
+    vr, wr = _bf16(v16).requires_grad_(True), _bf16(w).requires_grad_(True)
     y_ref = F.conv2d(vr, wr, b.double(), s, p, d)
     dy = torch.randn(y_ref.shape, generator=g)
     # the data gradient rounds dY and the weights; the reference for it is the conv-transpose of the rounded dY
     dx_ref, dw_ref = torch.autograd.grad(y_ref, (vr, wr), _bf16(dy))
-    t = lambda z: z.to(dev)
-    cv = K.Conv(t(x), Cout, k, s, p, d, sc0=t(sc) if aff else None, sh0=t(sh) if aff else None, act0=aff, prec="bf16")
     st = K.zeros_stats(Cout, t(x))
     y = cv.fwd(cv.pack(t(w), 0), t(b), st)
+    assert y.dtype == torch.float32
     assert_close(y, y_ref, 2e-5, "fwd vs rounded operands")
     st_ref = torch.cat([y_ref.sum((0, 2, 3)), (y_ref ** 2).sum((0, 2, 3))])
     assert_close(st, st_ref, 1e-5, "stats")
+    need, b16_out = cv.io_formats(0)
+    assert need == K.FMT_B16
+    if b16_out and Cout % 16 == 0:                         # the same call writing a B16 image: bf16(fp32 result), exactly
+        y16 = cv.fwd(cv.pack(t(w), 0), t(b), None, out_b16=True)
+        assert K.is_b16(y16) and K.dims(y16) == tuple(y.shape)
+        assert torch.equal(K.to_f32(y16), y.to(torch.bfloat16).float()), "B16 forward output != bf16(fp32 output)"
     dx = cv.dgrad(cv.pack(t(w), 1), t(dy))
-    if Cout % 16 == 0 and Cin >= 32 and (s == 1 or (H % 2 == 0 and W % 2 == 0)):
+    if bf_dgrad:
+        assert Cout % 16 == 0
         assert_close(dx, dx_ref, 2e-5, "dgrad vs rounded operands")
+        if cv.io_formats(1)[1] and Cin % 16 == 0:
+            dx16 = cv.dgrad(cv.pack(t(w), 1), K.to_b16(t(dy)), out_b16=True)
+            assert K.is_b16(dx16)
+            assert torch.equal(K.to_f32(dx16), dx.to(torch.bfloat16).float()), "B16 data gradient != bf16(fp32 data gradient)"
     else:   # no bf16 data-gradient kernel for these channel counts: exact f32 arithmetic on the unrounded operands
         v32 = v.clone().requires_grad_(True)
         assert_close(dx, torch.autograd.grad(F.conv2d(v32, w, b, s, p, d), v32, dy)[0], 2e-5, "dgrad (f32 fallback)")
     v32, w32 = v.clone().requires_grad_(True), w.clone().requires_grad_(True)
     y32 = F.conv2d(v32, w32, b, s, p, d)
-    assert_close(y, y32, 2e-2, "fwd vs unrounded fp32 (bf16 operand rounding)")
+    assert_close(y, y32, 3e-2, "fwd vs unrounded fp32 (bf16 operand rounding)")
     # weight gradient: bf16 kernel (rounded dY and rounded activated input) where one exists, else exact f32
     dw, db = cv.wgrad(t(dy), want_bias=True)
     from conftest import rel_err
     e_bf, e_32 = rel_err(dw, dw_ref), rel_err(dw, torch.autograd.grad(y32, w32, dy)[0])
-    has_bf16_wgrad = (k == 3 and s == 1 and Cin >= 32 and Cout >= 32 and W >= 4 and W % 2 == 0) or \
-        (k in (3, 4) and s == 2 and Cin >= 32 and Cout >= 32 and W >= 32 and W % 8 == 0)
-    assert (e_bf if has_bf16_wgrad else e_32) <= 2e-5, (has_bf16_wgrad, e_bf, e_32)
-    assert_close(db, dy.sum((0, 2, 3)), 2e-5, "dbias")
+    assert (e_bf if bf_wgrad else e_32) <= 2e-5, (bf_wgrad, e_bf, e_32)
+    # the bias gradient of a bf16 weight-gradient call is summed from the B16 image of dY
+    assert_close(db, (_bf16(dy) if bf_wgrad else dy.double()).sum((0, 2, 3)), 2e-5, "dbias")
+
+
+def test_b16_conversions_and_elementwise(dev):
+    """csrc/b16.hip against torch on the unpacked values: f32 <-> B16 round trip (B16 = bf16 [N][C/16][H][W][16]); the
+    BasicBlock tail, its backward with the BatchNorm-backward sums, the folded BatchNorm backward; results are the bf16
+    rounding of the fp32 formula evaluated on the bf16-rounded inputs."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 3, 48, 9, 14
+    r16 = lambda z: z.to(torch.bfloat16).float()            # noqa: E731
+    x = torch.randn(N, C, H, W, generator=g)
+    X = K.to_b16(x.to(dev))
+    assert X.dtype == torch.bfloat16 and tuple(X.shape) == (N, C // 16, H, W, 16) and K.dims(X) == (N, C, H, W)
+    assert torch.equal(X.cpu().float(), r16(x).view(N, C // 16, 16, H, W).permute(0, 1, 3, 4, 2)), "blocked layout"
+    back = K.to_f32(K.to_b16(x.to(dev)).clone())
+    assert torch.equal(back.cpu(), r16(x)), "f32 -> B16 -> f32"
+    y, res, dz, dz2, add = (torch.randn(N, C, H, W, generator=g) for _ in range(5))
+    sc, sh, rs, rh = (torch.randn(C, generator=g) for _ in range(4))
+    mean, inv = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    B = lambda z: K.to_b16(z.to(dev)).clone()               # noqa: E731
+    v4 = lambda z: z.view(1, -1, 1, 1)                      # noqa: E731
+    for act, neg in ((1, 0.0), (2, 0.2), (0, 1.0)):
+        for use_res in (False, True):
+            pre = r16(y) * v4(sc) + v4(sh) + ((r16(res) * v4(rs) + v4(rh)) if use_res else 0)
+            z_ref = torch.where(pre > 0, pre, neg * pre)
+            z = K.affine_act(B(y), sc.to(dev), sh.to(dev), B(res) if use_res else None, act,
+                             rs.to(dev) if use_res else None, rh.to(dev) if use_res else None)
+            assert K.is_b16(z)
+            assert_close(K.to_f32(z), r16(z_ref), 4e-3, f"b16 affine_act act={act}")
+            gref = torch.where(pre > 0, 1.0, neg) * (r16(dz) + r16(dz2)) + r16(add)
+            bst = K.zeros_stats(C, X)
+            out = K.affine_act_bwd_(B(dz), B(y), sc.to(dev), sh.to(dev), B(res) if use_res else None, B(add), mean.to(dev),
+                                    inv.to(dev), act, bst, res_scale=rs.to(dev) if use_res else None,
+                                    res_shift=rh.to(dev) if use_res else None, dz2=B(dz2))
+            assert_close(K.to_f32(out), r16(gref), 4e-3, f"b16 affine_act_bwd act={act}")
+            xhat = (r16(y) - v4(mean)) * v4(inv)
+            st_ref = torch.cat([gref.double().sum((0, 2, 3)), (gref.double() * xhat.double()).sum((0, 2, 3))])
+            assert_close(bst, st_ref, 1e-4, "b16 BatchNorm-backward sums (taken on the fp32 values before rounding)")
+    pqr = torch.randn(3, C, generator=g)
+    o = K.bn_bwd_apply_(B(dz), B(y), pqr.to(dev), fresh=True)
+    assert_close(K.to_f32(o), r16(v4(pqr[0]) * r16(dz) + v4(pqr[1]) * r16(y) + v4(pqr[2])), 4e-3, "b16 bn_bwd_apply")
+    bst = K.zeros_stats(C, X)
+    same = B(dz)
+    ret = K.affine_act_bwd_(same, B(y), None, None, None, None, mean.to(dev), inv.to(dev), 0, bst, stats_only=True)
+    assert ret is same
+    st_ref = torch.cat([r16(dz).double().sum((0, 2, 3)), (r16(dz).double() * ((r16(y) - v4(mean)) * v4(inv)).double()).sum((0, 2, 3))])
+    assert_close(bst, st_ref, 1e-4, "statistics-only pass")
+
+
+@pytest.mark.parametrize("N,C0,C1,H,W", [(2, 32, 16, 9, 20), (3, 16, 48, 16, 16), (1, 16, 16, 33, 7)])
+def test_b16_relu_up2x_and_stem_tail(dev, N, C0, C1, H, W):
+    """The U-Net decoder glue and the stem tail on B16 images against the fp32 kernels of the same library run on the
+    bf16-rounded inputs: up2x(relu(affine(cat))) and its adjoint (both source gradients, accumulation, BatchNorm-backward
+    sums), MaxPool(3,2,1) over relu(bn(y)) with byte tap indices and the fused pool / ReLU / BatchNorm backward."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(N * 7 + H)
+    r16 = lambda z: z.to(torch.bfloat16).float()            # noqa: E731
+    x0, x1 = torch.randn(N, C0, H, W, generator=g), torch.randn(N, C1, H, W, generator=g)
+    sc0, sh0 = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g) * 0.3
+    sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g) * 0.3
+    d = lambda z: z.to(dev)                                 # noqa: E731
+    cat16 = K.Cat(K.to_b16(d(x0)).clone(), K.to_b16(d(x1)).clone(), sc0=d(sc0), sh0=d(sh0), sc1=d(sc1), sh1=d(sh1))
+    cat32 = K.Cat(d(r16(x0)), d(r16(x1)), sc0=d(sc0), sh0=d(sh0), sc1=d(sc1), sh1=d(sh1))
+    assert cat16.b16 and not cat32.b16
+    U16, U32 = cat16.fwd(), cat32.fwd()
+    assert K.is_b16(U16)
+    assert_close(K.to_f32(U16), U32, 4e-3, "b16 relu_up2x forward")
+    dU = torch.randn(N, C0 + C1, 2 * H, 2 * W, generator=g)
+    mean1, inv1 = d(torch.randn(C1, generator=g) * 0.1), d(torch.rand(C1, generator=g) + 0.5)
+    b16s, b32s = K.zeros_stats(C1, d(x0)), K.zeros_stats(C1, d(x0))
+    g0, g1 = cat16.bwd(K.to_b16(d(dU)).clone(), mean1=mean1, invstd1=inv1, bstats1=b16s)
+    h0, h1 = cat32.bwd(d(r16(dU)), mean1=mean1, invstd1=inv1, bstats1=b32s)
+    assert_close(K.to_f32(g0), h0, 4e-3, "b16 relu_up2x backward g0")
+    assert_close(K.to_f32(g1), h1, 4e-3, "b16 relu_up2x backward g1")
+    assert_close(b16s, b32s, 1e-4, "b16 relu_up2x backward sums")
+    base = torch.randn(N, C0, H, W, generator=g)
+    acc, _ = cat16.bwd(K.to_b16(d(dU)).clone(), g0_acc=K.to_b16(d(base)).clone())
+    assert_close(K.to_f32(acc), r16(base).to(dev) + h0, 8e-3, "b16 relu_up2x backward accumulate")
+    # stem tail
+    C = C0
+    y = torch.randn(N, C, H, W, generator=g)
+    rows = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1,
+                        torch.rand(C, generator=g) + 0.5]).to(dev)
+    Y16 = K.to_b16(d(y)).clone()
+    z16, idx16 = K.maxpool3x3s2(Y16, rows[0], rows[1], 1)
+    z32, idx32 = K.maxpool3x3s2(d(r16(y)), rows[0], rows[1], 1)
+    assert idx16.dtype == torch.uint8
+    assert_close(K.to_f32(z16), z32, 4e-3, "b16 maxpool forward")
+    Ho, Wo = z32.shape[2:]
+    gp, gp2 = torch.randn(N, C, Ho, Wo, generator=g), torch.randn(N, C, Ho, Wo, generator=g)
+    gsum = (r16(gp) + r16(gp2)).to(dev)
+    s16, s32 = K.zeros_stats(C, d(y)), K.zeros_stats(C, d(y))
+    K.maxpool_bn_relu_bwd_stats(K.to_b16(d(gp)).clone(), idx16, Y16, rows, s16, g2=K.to_b16(d(gp2)).clone())
+    K.maxpool_bn_relu_bwd_stats(gsum, idx32, d(r16(y)), rows, s32)
+    assert_close(s16, s32, 1e-4, "b16 stem-tail backward sums")
+    pqr = torch.randn(3, C, generator=g).to(dev)
+    for out_f32 in (False, True):
+        dy16 = K.maxpool_bn_relu_bwd_apply(K.to_b16(d(gp)).clone(), idx16, Y16, rows, pqr, g2=K.to_b16(d(gp2)).clone(), out_f32=out_f32)
+        dy32 = K.maxpool_bn_relu_bwd_apply(gsum, idx32, d(r16(y)), rows, pqr)
+        assert (dy16.dtype == torch.float32) == out_f32
+        assert_close(K.to_f32(dy16), dy32, 4e-3 if not out_f32 else 2e-5, f"b16 stem-tail backward apply (fp32 out {out_f32})")
+    # space-to-depth straight into a one-block B16 image
+    fr = torch.randn(2, 3, 12, 20, generator=g)
+    s2d16, s2d32 = K.space_to_depth2(d(fr), b16=True), K.space_to_depth2(d(fr), b16=False)
+    assert K.is_b16(s2d16) and torch.equal(K.to_f32(s2d16), s2d32.to(torch.bfloat16).float())
 
 
 def test_conv_virtual_input_winograd(dev):
