@@ -642,14 +642,6 @@ size_t wbn_workspace_floats(const avsep_conv_desc* d);
 int wbn_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 void wbn_variant(const avsep_conv_desc* d, char* buf, size_t cap);
 int b16_channel_sum(const void* x, int N, int C, int HW, double* acc, float* out, hipStream_t st);   // b16.hip
-// wgrad_bf16.hip
-bool wb_applicable(const avsep_conv_desc* d);
-size_t wb_workspace_floats(const avsep_conv_desc* d);
-int wb_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
-// wgrad4_bf16.hip
-bool w4b_applicable(const avsep_conv_desc* d);
-size_t w4b_workspace_floats(const avsep_conv_desc* d);
-int w4b_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
 // wgrad_smallci.hip
 bool scw_applicable(const avsep_conv_desc* d);
@@ -948,7 +940,6 @@ extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (smallco_applicable(d)) return smallco_wgrad_workspace_floats(d) * sizeof(float);
   if (head_applicable(d)) return head_wgrad_workspace_floats(d) * sizeof(float);
   if (wbn_applicable(d)) return wbn_workspace_floats(d) * sizeof(float) + (size_t)2 * d->Cout * sizeof(double);
-  if (w4b_applicable(d)) return w4b_workspace_floats(d) * sizeof(float);
   if (ww_applicable(d)) return ww_workspace_floats(d) * sizeof(float);
   if (w4d_applicable(d)) return w4d_workspace_floats(d) * sizeof(float);
   if (w3_applicable(d)) return w3_workspace_floats(d) * sizeof(float);
@@ -974,10 +965,8 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
     double* acc = reinterpret_cast<double*>((float*)workspace + wbn_workspace_floats(d));   // behind the slabs (8-byte aligned: slab sizes are multiples of 64*64)
     return b16_channel_sum(dy, d->N, d->Cout, d->Ho * d->Wo, acc, dbias, (hipStream_t)stream);
   }
-  if (wb_applicable(d) || w4b_applicable(d) || ww_applicable(d) || w4d_applicable(d) || w3_applicable(d) || scw_applicable(d)) {
-    int rc3 = wb_applicable(d) ? wb_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
-              : w4b_applicable(d) ? w4b_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
-              : ww_applicable(d) ? ww_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
+  if (ww_applicable(d) || w4d_applicable(d) || w3_applicable(d) || scw_applicable(d)) {
+    int rc3 = ww_applicable(d) ? ww_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : w4d_applicable(d) ? w4d_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : w3_applicable(d) ? w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
                                  : scw_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
@@ -1040,8 +1029,6 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
   if (smallco_applicable(d)) return "smallco_wgrad";
   if (head_applicable(d)) return "head_wgrad_kernel";
   if (wbn_applicable(d)) return "wgradb_kernel";
-  if (wb_applicable(d)) return "wgradbf_kernel";
-  if (w4b_applicable(d)) return "wgrad4bf_kernel";
   if (ww_applicable(d)) return "winow_kernel";
   if (w4d_applicable(d)) return "wgrad4d_kernel";
   if (w3_applicable(d)) return "wgrad3x3_kernel";

@@ -679,7 +679,26 @@ int ww_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
 }
 
 // ---- 4x4 / stride 2 ----
-int w4_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st);      // wgrad4_bf16.hip
+// dw[cc][tap] = sum_z ws[z][tap][cc], cc = co*Cin + ci (16 taps)
+__global__ void w4_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long P, int S) {
+  const long long cc = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cc >= P) return;
+  float s[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) s[t] = 0.f;
+#pragma unroll 2
+  for (int z = 0; z < S; ++z)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s[t] += ws[((long long)z * 16 + t) * P + cc];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    reinterpret_cast<float4*>(out + cc * 16)[t] = float4{s[4 * t], s[4 * t + 1], s[4 * t + 2], s[4 * t + 3]};
+}
+static int w4_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st) {
+  hipLaunchKernelGGL(w4_reduce_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, ws, dw, P, splits);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
 
 static WwPlan w4d_plan(const avsep_conv_desc* d) {
   avsep_conv_desc e = *d;                       // the chunk geometry of the 3x3 plan on the INPUT grid (tile = output pixel)
