@@ -331,7 +331,7 @@ extern "C" int avsep_b16_relu_up2x_fwd(const void* x0, const void* x1, const flo
 // BatchNorm-backward sums of source 1 (sum g1, sum g1 * xhat(x1)).
 // Workgroup = a TH x TW tile of low-res positions of ONE 16-channel block of one image; the (2TH+4) x (2TW+4) hi-res window
 // is staged in LDS (16-byte slots), then a thread = (position, half) gathers its 36 taps with ds_read_b128.
-constexpr int B16U_TH = 8, B16U_TW = 16, B16U_RH = 2 * B16U_TH + 4, B16U_RW = 2 * B16U_TW + 4;
+constexpr int B16U_TH = 8, B16U_TW = 16, B16U_RH = 2 * B16U_TH + 4, B16U_RW = 2 * B16U_TW + 4;   // 20 x 36 window (RW even)
 __device__ __forceinline__ void b16_taps6(int h, int Hin, float r, float (&wt)[6]) {     // = up2x_taps6 of ops.hip
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -353,7 +353,10 @@ __global__ __launch_bounds__(256) void b16_relu_up2x_bwd_kernel(const u32x4* __r
                                                                 const u32x4* __restrict__ dout, u32x4* g0, u32x4* g1,
                                                                 const float* __restrict__ mean1, const float* __restrict__ invstd1,
                                                                 double* bstats1, int acc0, int tilesX) {
-  __shared__ u32x4 tile[B16U_RH * B16U_RW * 2];
+  // hi-res window, even and odd columns in separate planes: the 32 lanes of a row read columns 2tx + x, i.e. CONSECUTIVE
+  // slots of one plane (conflict-free ds_read_b128; one interleaved image is a 2-way conflict on every tap)
+  constexpr int HWD = B16U_RW / 2, PLANE = B16U_RH * HWD * 2, SLOTS = B16U_RH * B16U_RW * 2, LE = (SLOTS + 255) / 256;
+  __shared__ u32x4 tile[2 * PLANE];
   const int CB0 = C0 >> 4, CB1 = C1 >> 4, cbo = blockIdx.y, half = threadIdx.x & 1, pos = threadIdx.x >> 1;
   const bool first = cbo < CB0;
   const int cbs = first ? cbo : cbo - CB0, CBs = first ? CB0 : CB1, c0 = cbs * 16 + half * 8;
@@ -372,19 +375,36 @@ __global__ __launch_bounds__(256) void b16_relu_up2x_bwd_kernel(const u32x4* __r
   b16_taps6(min(h, H - 1), H, rh, wh);
   b16_taps6(min(w, W - 1), W, rw, ww);
   const int Ho = 2 * H, Wo = 2 * W, r0 = 2 * h0 - 2, c0w = 2 * w0 - 2;
+  // staging slots of this thread: window position (rr, cc), half -> global offset inside an image plane (or -1) and LDS slot
+  int l_src[LE], l_dst[LE];
+#pragma unroll
+  for (int e = 0; e < LE; ++e) {
+    const int i = threadIdx.x + 256 * e;
+    const int hs = i & 1, pp = i >> 1, rr = pp / B16U_RW, cc = pp % B16U_RW;
+    const int ho = r0 + rr, wo = c0w + cc;
+    const bool ok = i < SLOTS && (unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo;
+    l_src[e] = ok ? (ho * Wo + wo) * 2 + hs : -1;
+    l_dst[e] = i < SLOTS ? (cc & 1) * PLANE + (rr * HWD + (cc >> 1)) * 2 + hs : -1;
+  }
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  const long long img = (long long)Ho * Wo * 2;
+  u32x4 stg[LE];
+  auto fetch = [&](int n) __attribute__((always_inline)) {
+    const u32x4* dp = dout + ((long long)n * (CB0 + CB1) + cbo) * img;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < LE; ++e) stg[e] = l_src[e] >= 0 ? dp[l_src[e]] : z;
+  };
+  if ((int)blockIdx.z < N) fetch(blockIdx.z);
   for (int n = blockIdx.z; n < N; n += gridDim.z) {
-    const u32x4* dp = dout + ((long long)n * (CB0 + CB1) + cbo) * Ho * Wo * 2;
     __syncthreads();
-    for (int i = threadIdx.x; i < B16U_RH * B16U_RW * 2; i += 256) {
-      const int hs = i & 1, pp = i >> 1, rr = pp / B16U_RW, cc = pp % B16U_RW;
-      const int ho = r0 + rr, wo = c0w + cc;
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      tile[i] = ((unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo) ? dp[((long long)ho * Wo + wo) * 2 + hs] : z;
-    }
+#pragma unroll
+    for (int e = 0; e < LE; ++e)
+      if (l_dst[e] >= 0) tile[l_dst[e]] = stg[e];
     __syncthreads();
+    if (n + (int)gridDim.z < N) fetch(n + gridDim.z);          // the next image's window is in flight during the gather
     if (inside) {
       const long long o = (((long long)n * CBs + cbs) * H * W + (long long)h * W + w) * 2 + half;
       float yv[8], tot[8];
@@ -399,7 +419,8 @@ __global__ __launch_bounds__(256) void b16_relu_up2x_bwd_kernel(const u32x4* __r
 #pragma unroll
         for (int x = 0; x < 6; ++x) {
           float t[8];
-          b16_unpack8(tile[((2 * ty + y) * B16U_RW + 2 * tx + x) * 2 + half], t);
+          // window column 2tx + x: plane x & 1, column tx + (x >> 1)
+          b16_unpack8(tile[(x & 1) * PLANE + ((2 * ty + y) * HWD + tx + (x >> 1)) * 2 + half], t);
 #pragma unroll
           for (int j = 0; j < 8; ++j) row[j] = fmaf(ww[x], t[j], row[j]);
         }

@@ -27,7 +27,7 @@ def per_kernel(directory):
 
 
 def family(name):
-    for key in ("winow_kernel", "wino_kernel", "convbf_kernel", "wgradbf_kernel", "wgrad4bf_kernel", "wgrad4d_kernel", "smallci_wgrad_kernel",
+    for key in ("winow_kernel", "wino_kernel", "convbf_kernel", "wgradb_reduce_kernel", "wgradb_kernel", "wgradbf_kernel", "wgrad4bf_kernel", "wgrad4d_kernel", "smallci_wgrad_kernel",
                 "conv3x3_kernel", "wgrad3x3_kernel", "head_fwd_kernel", "head_wgrad_kernel", "affine_act_kernel", "maxpool_fwd4_kernel",
                 "head_dgrad_kernel", "smallco_fwd", "smallco_wgrad", "smallci_dgrad", "relu_up2x_fwd",
                 "relu_up2x_bwd", "bn_bwd_apply_kernel", "affine_act_bwd_kernel", "sgd_kernel", "w3_reduce_kernel"):
@@ -35,7 +35,10 @@ def family(name):
             return key
     if "igemm_kernel<" in name:
         return "igemm_kernel<%s>" % {"0": "fwd", "1": "dgrad", "2": "wgrad"}[name.split("igemm_kernel<")[1][0]]
-    return None
+    # every other kernel of the step under its own base name (template arguments and parameter list stripped), so that the
+    # per-step total covers the WHOLE step (round 3's total only summed the families listed above)
+    base = name.replace("void ", "").split("<")[0].split("(")[0].strip()
+    return base or None
 
 
 def main():
@@ -62,6 +65,9 @@ def main():
                              "write_size_kib": sw / nw, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                              "traffic_bytes_per_launch": rd + wr,
                              "traffic_bytes_per_step": (rd + wr) * nf / steps if steps else None}
+    if steps:
+        out["total_traffic_bytes_per_step"] = sum(v["traffic_bytes_per_step"] for v in out["kernels"].values())
+        print("total_traffic_GB_per_step", out["total_traffic_bytes_per_step"] / 1e9)
     dst = sys.argv[6] if len(sys.argv) > 6 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
