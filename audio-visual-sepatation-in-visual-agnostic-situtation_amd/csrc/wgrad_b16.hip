@@ -20,6 +20,7 @@
 // [split][tap][co][ci] + a deterministic reduce that writes OIHW.
 // LDS plane strides are padded so that the two 16-lane groups of a 32-lane half hit disjoint banks (stride 1: planes 128 B
 // apart mod 256; stride 2: 32 B apart mod 64).
+#include <type_traits>
 #include "common.h"
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -54,21 +55,25 @@ __device__ __forceinline__ bf16x8 wb_tr8(const unsigned char* p, int off0, int o
   return __builtin_bit_cast(bf16x8, t);
 }
 
+// TG tap groups: the workgroup has TG x 4 waves; group tg multiplies taps [tg * NTW, (tg + 1) * NTW) of the same 64 x 64 tile out
+// of the same LDS images.  Two groups = two waves per SIMD at <= 256 registers: one wave's staging / LDS waits overlap the
+// other's MFMAs (one 4-wave workgroup per CU left the matrix pipe idle for ~60 % of a chunk: stage + barriers + issue).
 template <int KH, int KW, int S, int DIL, int TH, int TW, bool RAW>
-__global__ __launch_bounds__(256) void wgradb_kernel(WbArgs a) {
+__global__ __launch_bounds__(KH * KW > 1 ? 512 : 256) void wgradb_kernel(WbArgs a) {
   constexpr int NT = KH * KW, NPIX = TH * TW, KST = NPIX / 16;
+  constexpr int TG = NT > 1 ? 2 : 1, NTHR = 256 * TG, NTW = (NT + TG - 1) / TG;
   static_assert(TW % 16 == 0, "a k-step of 16 pixels stays inside one tile row");
   constexpr int PH = (TH - 1) * S + (KH - 1) * DIL + 1, PW = (TW - 1) * S + (KW - 1) * DIL + 1, PS = PH * PW;
   constexpr int XRES = S == 1 ? 128 : 32;
   constexpr int XPL = PS * 32 + ((XRES - (PS * 32) % 256) + 256) % 256;          // bytes per channel-block plane of the X patch
   constexpr int YPL = NPIX * 32 + ((128 - (NPIX * 32) % 256) + 256) % 256;       // ... of the dY tile
   constexpr int XSL = 4 * PS * 2, YSL = 4 * NPIX * 2;                            // 16-byte slots (4 channel blocks each)
-  constexpr int XE = (XSL + 255) / 256, YE = (YSL + 255) / 256;
+  constexpr int XE = (XSL + NTHR - 1) / NTHR, YE = (YSL + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * XPL + 4 * YPL];
   unsigned char* const Xs = smem;
   unsigned char* const Ys = smem + 4 * XPL;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
   const int cot = blockIdx.x / a.gridCi, cit = blockIdx.x % a.gridCi;
   const int CBi = a.Cin >> 4, CBo = a.Cout >> 4;
   const float slope = act_slope(a.act);
@@ -88,47 +93,46 @@ __global__ __launch_bounds__(256) void wgradb_kernel(WbArgs a) {
   int x_rc[XE], x_lds[XE], x_g[XE];        // (row << 16 | col) inside the patch; LDS byte; 16-byte unit inside one image (-1: no such channel block)
 #pragma unroll
   for (int e = 0; e < XE; ++e) {
-    const int i = min(tid + 256 * e, XSL - 1);
+    const int i = min(tid + NTHR * e, XSL - 1);
     const int cbx = i / (PS * 2), rem = i % (PS * 2), pos = rem >> 1, half = rem & 1;
     x_rc[e] = ((pos / PW) << 16) | (pos % PW);
     x_lds[e] = cbx * XPL + pos * 32 + half * 16;
     const int cb = cit * 4 + cbx;
-    x_g[e] = (cb < CBi && (XE * 256 == XSL || tid + 256 * e < XSL)) ? cb * a.H * a.W * 2 + half : -1;
+    x_g[e] = (cb < CBi && (XE * NTHR == XSL || tid + NTHR * e < XSL)) ? ((cb * a.H + pos / PW) * a.W + pos % PW) * 2 + half : -1;
   }
   int y_rc[YE], y_lds[YE], y_g[YE];
 #pragma unroll
   for (int e = 0; e < YE; ++e) {
-    const int i = min(tid + 256 * e, YSL - 1);
+    const int i = min(tid + NTHR * e, YSL - 1);
     const int cby = i / (NPIX * 2), rem = i % (NPIX * 2), pix = rem >> 1, half = rem & 1;
     y_rc[e] = ((pix / TW) << 16) | (pix % TW);
     y_lds[e] = cby * YPL + pix * 32 + half * 16;
     const int cb = cot * 4 + cby;
-    y_g[e] = (cb < CBo && (YE * 256 == YSL || tid + 256 * e < YSL)) ? cb * a.Ho * a.Wo * 2 + half : -1;
+    y_g[e] = (cb < CBo && (YE * NTHR == YSL || tid + NTHR * e < YSL)) ? ((cb * a.Ho + pix / TW) * a.Wo + pix % TW) * 2 + half : -1;
   }
 
   u32x4 xr[XE], yr[YE];
-  unsigned xok = 0, yok = 0;
+  unsigned xok = 0;
+  // per chunk and slot: one add per coordinate, two compares, one select, one add for the address (the slot's offset
+  // inside its image relative to the patch origin is a per-thread constant: x_g[e] already holds (cb*H + r)*W + c)
   auto issue = [&](int c) __attribute__((always_inline)) {
     const int tx = c % a.tilesX, t2 = c / a.tilesX, ty = t2 % a.tilesY, n = t2 / a.tilesY;
     const int gh0 = ty * TH * S - a.pad, gw0 = tx * TW * S - a.pad;
-    const u32x4* const xn = a.x + (long long)n * CBi * a.H * a.W * 2;       // uniform bases + 32-bit lane offsets
-    const u32x4* const yn = a.dy + (long long)n * CBo * a.Ho * a.Wo * 2;
-    xok = 0; yok = 0;
+    const u32x4* const xn = a.x + ((long long)n * CBi * a.H * a.W + (long long)gh0 * a.W + gw0) * 2;   // may point before the image: only valid slots load
+    const u32x4* const yn = a.dy + ((long long)n * CBo * a.Ho * a.Wo + (long long)(ty * TH) * a.Wo + tx * TW) * 2;
+    xok = 0;
 #pragma unroll
     for (int e = 0; e < XE; ++e) {
-      const int gh = gh0 + (x_rc[e] >> 16), gw = gw0 + (x_rc[e] & 0xffff);
-      const bool ok = x_g[e] >= 0 && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
-      const int ghc = min(max(gh, 0), a.H - 1), gwc = min(max(gw, 0), a.W - 1);
-      xr[e] = xn[max(x_g[e], 0) + (ghc * a.W + gwc) * 2];
+      const bool ok = x_g[e] >= 0 && (unsigned)(gh0 + (x_rc[e] >> 16)) < (unsigned)a.H && (unsigned)(gw0 + (x_rc[e] & 0xffff)) < (unsigned)a.W;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      xr[e] = ok ? xn[x_g[e]] : z;
       xok |= (unsigned)ok << e;
     }
 #pragma unroll
     for (int e = 0; e < YE; ++e) {
-      const int oh = ty * TH + (y_rc[e] >> 16), ow = tx * TW + (y_rc[e] & 0xffff);
-      const bool ok = y_g[e] >= 0 && oh < a.Ho && ow < a.Wo;
-      const int ohc = min(oh, a.Ho - 1), owc = min(ow, a.Wo - 1);
-      yr[e] = yn[max(y_g[e], 0) + (ohc * a.Wo + owc) * 2];
-      yok |= (unsigned)ok << e;
+      const bool ok = y_g[e] >= 0 && ty * TH + (y_rc[e] >> 16) < a.Ho && tx * TW + (y_rc[e] & 0xffff) < a.Wo;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      yr[e] = ok ? yn[y_g[e]] : z;
     }
   };
   auto stage = [&]() __attribute__((always_inline)) {
@@ -150,11 +154,11 @@ __global__ __launch_bounds__(256) void wgradb_kernel(WbArgs a) {
         }
         q = u32x4{wb_pack2(v[0], v[1]), wb_pack2(v[2], v[3]), wb_pack2(v[4], v[5]), wb_pack2(v[6], v[7])};
       }
-      if (XE * 256 == XSL || tid + 256 * e < XSL) *reinterpret_cast<u32x4*>(Xs + x_lds[e]) = ((xok >> e) & 1u) ? q : z;
+      if (XE * NTHR == XSL || tid + NTHR * e < XSL) *reinterpret_cast<u32x4*>(Xs + x_lds[e]) = (RAW || ((xok >> e) & 1u)) ? q : z;   // raw invalid slots loaded as 0
     }
 #pragma unroll
     for (int e = 0; e < YE; ++e)
-      if (YE * 256 == YSL || tid + 256 * e < YSL) *reinterpret_cast<u32x4*>(Ys + y_lds[e]) = ((yok >> e) & 1u) ? yr[e] : z;
+      if (YE * NTHR == YSL || tid + NTHR * e < YSL) *reinterpret_cast<u32x4*>(Ys + y_lds[e]) = yr[e];
   };
 
   // ---- operand addresses of the transposed reads: lane 4q + p of a 16-lane group supplies row q (a position), 8-byte column p --
@@ -162,9 +166,9 @@ __global__ __launch_bounds__(256) void wgradb_kernel(WbArgs a) {
   const unsigned char* const a_lane = Ys + (2 * wm + blk) * YPL + (8 * kg + q) * 32 + p * 8;
   const unsigned char* const b_lane = Xs + (2 * wn + blk) * XPL + (8 * kg + q) * S * 32 + p * 8;
 
-  f32x16 acc[NT];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NTW; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -175,18 +179,25 @@ __global__ __launch_bounds__(256) void wgradb_kernel(WbArgs a) {
     stage();
     __syncthreads();
     if (c + 1 < c_end) issue(c + 1);         // in flight while this chunk is multiplied
+    auto ksteps = [&](auto tgc) __attribute__((always_inline)) {
+      constexpr int T0 = decltype(tgc)::value * NTW;
 #pragma unroll
-    for (int ks = 0; ks < KST; ++ks) {
-      const int row = (ks * 16) / TW, col0 = (ks * 16) % TW;
-      const bf16x8 av = wb_tr8(a_lane, ks * 16 * 32, ks * 16 * 32 + 4 * 32);
+      for (int ks = 0; ks < KST; ++ks) {
+        const int row = (ks * 16) / TW, col0 = (ks * 16) % TW;
+        const bf16x8 av = wb_tr8(a_lane, ks * 16 * 32, ks * 16 * 32 + 4 * 32);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int kh = t / KW, kw = t % KW;
-        const int off = ((row * S + kh * DIL) * PW + col0 * S + kw * DIL) * 32;
-        const bf16x8 bv = wb_tr8(b_lane, off, off + 4 * S * 32);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+        for (int t = 0; t < NTW; ++t) {
+          if (T0 + t < NT) {
+            const int kh = (T0 + t) / KW, kw = (T0 + t) % KW;
+            const int off = ((row * S + kh * DIL) * PW + col0 * S + kw * DIL) * 32;
+            const bf16x8 bv = wb_tr8(b_lane, off, off + 4 * S * 32);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+          }
+        }
       }
-    }
+    };
+    if (TG == 1 || tg == 0) ksteps(std::integral_constant<int, 0>{});
+    else ksteps(std::integral_constant<int, TG - 1>{});
   }
 
   // ---- partial slab [tap][CoutP][CinP]: C/D map col = lane & 31 (ci), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (co) ----------
@@ -194,11 +205,13 @@ __global__ __launch_bounds__(256) void wgradb_kernel(WbArgs a) {
   const int li = lane & 31, lk = lane >> 5;
   const int ci = cit * 64 + wn * 32 + li;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NTW; ++t)
+    if (tg * NTW + t < NT) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cot * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      op[((long long)t * a.CoutP + co) * a.CinP + ci] = acc[t][r];
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        op[((long long)(tg * NTW + t) * a.CoutP + co) * a.CinP + ci] = acc[t][r];
+      }
     }
 }
 
@@ -249,7 +262,7 @@ static WbPlan wbn_plan(const avsep_conv_desc* d) {
   const bool s2 = cls == 3 || cls == 4 || cls == 6;
   p.wide = d->Wo > 16;
   p.tw = p.wide ? 32 : 16;
-  p.th = s2 ? (p.wide ? 2 : 4) : (p.wide ? 4 : 8);
+  p.th = cls == 3 ? (p.wide ? 2 : 4) : s2 ? (p.wide ? 4 : 8) : (p.wide ? 8 : 16);   // 16 taps (128 accumulator registers per wave): smaller chunks
   p.tilesX = cdiv(d->Wo, p.tw);
   p.tilesY = cdiv(d->Ho, p.th);
   p.gco = cdiv(d->Cout, 64);
@@ -280,11 +293,11 @@ void wbn_variant(const avsep_conv_desc* d, char* buf, size_t cap) {
 template <int KH, int KW, int S, int DIL>
 static int wbn_launch(WbArgs& a, const WbPlan& p, bool raw, hipStream_t st) {
   dim3 grid(p.gco * p.gci, 1, p.splits);
-  constexpr int THW = S == 2 ? 2 : 4, THN = S == 2 ? 4 : 8;
+  constexpr int THW = KH * KW == 16 ? 2 : S == 2 ? 4 : 8, THN = KH * KW == 16 ? 4 : S == 2 ? 8 : 16;
 #define WB_L(TH_, TW_)                                                                                                    \
   do {                                                                                                                    \
-    if (raw) hipLaunchKernelGGL((wgradb_kernel<KH, KW, S, DIL, TH_, TW_, true>), grid, dim3(256), 0, st, a);              \
-    else hipLaunchKernelGGL((wgradb_kernel<KH, KW, S, DIL, TH_, TW_, false>), grid, dim3(256), 0, st, a);                 \
+    if (raw) hipLaunchKernelGGL((wgradb_kernel<KH, KW, S, DIL, TH_, TW_, true>), grid, dim3(KH * KW > 1 ? 512 : 256), 0, st, a);  \
+    else hipLaunchKernelGGL((wgradb_kernel<KH, KW, S, DIL, TH_, TW_, false>), grid, dim3(KH * KW > 1 ? 512 : 256), 0, st, a);     \
   } while (0)
   if (p.wide) WB_L(THW, 32); else WB_L(THN, 16);
 #undef WB_L
