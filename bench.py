@@ -148,10 +148,13 @@ class KernelTimer:
         return out
 
 
-def pmc_traffic(family, prec="f32"):
+def pmc_traffic(family, prec="f32", config=3):
     """PMC-measured HBM traffic of one kernel family, from the committed summary of the rocprofv3 --pmc passes
     (counters cannot be read from inside the process; the summary is regenerated by profiles/summarise_pmc.py)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if prec == "f32" else "pmc_traffic_%s.json" % prec)
+    name = "pmc_traffic.json" if prec == "f32" else "pmc_traffic_%s.json" % prec
+    if config == 5:
+        name = name.replace(".json", "_config5.json")
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -346,6 +349,7 @@ def config5_line(P, dev, world, seed, rank, o, timer):
     r_inst = run_config(P, dev, world, seed, rank, o.precision, "hip", B5, steps, 1, timer, config=5)
     k5 = timer.summary(steps)
     roof5, step5, _ = roofline_of(k5, o.precision, r["ms_per_step"], B5)
+    add_traffic(roof5, o.precision, B5, config=5)
     r.update({"dtype": o.precision, "batch": B5, "roofline": roof5, "roofline_step": step5,
               "instrumented_ms_per_step": r_inst["ms_per_step"],
               "gflop_per_mixture_executed": step5["executed_gflop_per_step"] / B5,
@@ -358,8 +362,8 @@ def config5_line(P, dev, world, seed, rank, o, timer):
     return r
 
 
-def add_traffic(roof, prec, B):
-    traffic = pmc_traffic(roof["kernel"], prec)
+def add_traffic(roof, prec, B, config=3):
+    traffic = pmc_traffic(roof["kernel"], prec, config)
     if traffic and traffic["traffic_bytes_per_step"]:
         scale = B / float(traffic["batch"] or B)                   # PMC passes may run at another batch: bytes scale with it
         roof["traffic"] = traffic["traffic_bytes_per_step"] * scale / roof["launches_per_step"]

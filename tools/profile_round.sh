@@ -2,7 +2,7 @@
 # One call on the GPU box: kernel trace, the two PMC traffic passes and the SQ pass of the bench step, both precisions.
 #   bash tools/profile_round.sh r03        -> gpurun_out/ck/r03_* (copy what is to be judged into profiles/)
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ck
 FLAGS="--no-cpu-baseline --no-extra --no-instrumented"
@@ -18,3 +18,10 @@ for P in f32 bf16; do
   rm -rf gpurun_out/ck/tr_$P gpurun_out/ck/f_$P gpurun_out/ck/w_$P gpurun_out/ck/sq_$P
   echo done $P
 done
+# configs[4] (3 sources, 5 frames, 512x256, batch 32): the PMC traffic passes of its headline precision
+P=f32
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/ck/f5 -- python3 bench.py --config 5 --steps 2 --warmup 1 $FLAGS --precision $P > gpurun_out/ck/f5.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/ck/w5 -- python3 bench.py --config 5 --steps 2 --warmup 1 $FLAGS --precision $P > gpurun_out/ck/w5.log 2>&1
+python profiles/summarise_pmc.py gpurun_out/ck/f5 gpurun_out/ck/w5 "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --config 5 --steps 2 --warmup 1 $FLAGS --precision $P" 3 32 gpurun_out/ck/pmc_${P}_config5.json > gpurun_out/ck/pmc_config5.log
+rm -rf gpurun_out/ck/f5 gpurun_out/ck/w5
+echo done config5
