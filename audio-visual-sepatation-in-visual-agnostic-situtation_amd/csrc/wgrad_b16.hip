@@ -215,23 +215,143 @@ __global__ __launch_bounds__(KH * KW > 1 ? 512 : 256) void wgradb_kernel(WbArgs 
     }
 }
 
-// dW[co][ci][tap] = sum over splits of slab[s][tap][co][ci]; one thread per (co, ci), fixed summation order
+
+// ---- Cin == 16: the ResNet stem as a 4x4 / stride-1 conv over the space-to-depth frames (one 16-channel block) -----------------
+// With a single input block the 64 x 64 tile above would multiply 48 zero columns.  Here N = (tap, ci): a 32-column MFMA tile is
+// TWO taps x the 16 channels — the two 16-lane groups of a transposed read simply take different tap offsets — so all 16 taps
+// are 8 full tiles: 8 waves = 2 (co halves) x 4 (tap quads), two accumulator tiles per wave, every MFMA column useful.
+template <int KH, int KW, int TH, int TW>
+__global__ __launch_bounds__(512) void wgradb_ci16_kernel(WbArgs a) {
+  constexpr int NT = KH * KW, NPIX = TH * TW, KST = NPIX / 16, NTHR = 512;
+  static_assert(NT == 16 && TW % 16 == 0, "16 taps = 4 quads");
+  constexpr int PH = TH + KH - 1, PW = TW + KW - 1, PS = PH * PW;
+  constexpr int YPL = NPIX * 32 + ((128 - (NPIX * 32) % 256) + 256) % 256;
+  constexpr int XSL = PS * 2, YSL = 4 * NPIX * 2;
+  constexpr int XE = (XSL + NTHR - 1) / NTHR, YE = (YSL + NTHR - 1) / NTHR;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PS * 32 + 4 * YPL];
+  unsigned char* const Xs = smem;
+  unsigned char* const Ys = smem + PS * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tq = wave >> 1, wm = wave & 1;
+  const int cot = blockIdx.x, CBo = a.Cout >> 4;
+
+  int x_rc[XE], x_lds[XE], x_g[XE];
+#pragma unroll
+  for (int e = 0; e < XE; ++e) {
+    const int i = min(tid + NTHR * e, XSL - 1), pos = i >> 1, half = i & 1;
+    x_rc[e] = ((pos / PW) << 16) | (pos % PW);
+    x_lds[e] = pos * 32 + half * 16;
+    x_g[e] = (XE * NTHR == XSL || tid + NTHR * e < XSL) ? ((pos / PW) * a.W + pos % PW) * 2 + half : -1;
+  }
+  int y_rc[YE], y_lds[YE], y_g[YE];
+#pragma unroll
+  for (int e = 0; e < YE; ++e) {
+    const int i = min(tid + NTHR * e, YSL - 1);
+    const int cby = i / (NPIX * 2), rem = i % (NPIX * 2), pix = rem >> 1, half = rem & 1;
+    y_rc[e] = ((pix / TW) << 16) | (pix % TW);
+    y_lds[e] = cby * YPL + pix * 32 + half * 16;
+    const int cb = cot * 4 + cby;
+    y_g[e] = (cb < CBo && (YE * NTHR == YSL || tid + NTHR * e < YSL)) ? ((cb * a.Ho + pix / TW) * a.Wo + pix % TW) * 2 + half : -1;
+  }
+  u32x4 xr[XE], yr[YE];
+  auto issue = [&](int c) __attribute__((always_inline)) {
+    const int tx = c % a.tilesX, t2 = c / a.tilesX, ty = t2 % a.tilesY, n = t2 / a.tilesY;
+    const int gh0 = ty * TH - a.pad, gw0 = tx * TW - a.pad;
+    const u32x4* const xn = a.x + ((long long)n * a.H * a.W + (long long)gh0 * a.W + gw0) * 2;
+    const u32x4* const yn = a.dy + ((long long)n * CBo * a.Ho * a.Wo + (long long)(ty * TH) * a.Wo + tx * TW) * 2;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+      const bool ok = x_g[e] >= 0 && (unsigned)(gh0 + (x_rc[e] >> 16)) < (unsigned)a.H && (unsigned)(gw0 + (x_rc[e] & 0xffff)) < (unsigned)a.W;
+      xr[e] = ok ? xn[x_g[e]] : z;
+    }
+#pragma unroll
+    for (int e = 0; e < YE; ++e) {
+      const bool ok = y_g[e] >= 0 && ty * TH + (y_rc[e] >> 16) < a.Ho && tx * TW + (y_rc[e] & 0xffff) < a.Wo;
+      yr[e] = ok ? yn[y_g[e]] : z;
+    }
+  };
+  auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < XE; ++e)
+      if (XE * NTHR == XSL || tid + NTHR * e < XSL) *reinterpret_cast<u32x4*>(Xs + x_lds[e]) = xr[e];
+#pragma unroll
+    for (int e = 0; e < YE; ++e)
+      if (YE * NTHR == YSL || tid + NTHR * e < YSL) *reinterpret_cast<u32x4*>(Ys + y_lds[e]) = yr[e];
+  };
+  const int g16 = lane >> 4, blk = g16 & 1, kg = g16 >> 1, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* const a_lane = Ys + (2 * wm + blk) * YPL + (8 * kg + q) * 32 + p * 8;
+  const unsigned char* b_lane[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int tap = tq * 4 + 2 * j + blk;                       // this 16-lane group's tap of N-tile j
+    b_lane[j] = Xs + ((tap / KW) * PW + tap % KW + 8 * kg + q) * 32 + p * 8;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int c_beg = blockIdx.z * a.per_split, c_end = min(a.chunks, c_beg + a.per_split);
+  if (c_beg < c_end) issue(c_beg);
+  for (int c = c_beg; c < c_end; ++c) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (c + 1 < c_end) issue(c + 1);
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      const int off = (((ks * 16) / TW) * PW + (ks * 16) % TW) * 32;
+      const bf16x8 av = wb_tr8(a_lane, ks * 16 * 32, ks * 16 * 32 + 4 * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 bv = wb_tr8(b_lane[j], off, off + 4 * 32);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  float* const op = a.out + (long long)blockIdx.z * a.slab;
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int tap = tq * 4 + 2 * j + (li >> 4), ci = li & 15;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      op[((long long)tap * a.CoutP + co) * a.CinP + ci] = acc[j][r];
+    }
+  }
+}
+
+// dW[co][ci][tap] = sum over splits of slab[s][tap][co][ci].  Block = 4 split groups x 64 input channels of one output channel:
+// a thread sums every 4th split (two chains in flight), the four partial sums meet in LDS in a fixed order (deterministic).
+// One thread per (co, ci) walking all splits alone left 64-channel layers (256 splits, 64 active threads per block) latency-bound.
 template <int NT>
 __global__ __launch_bounds__(256) void wgradb_reduce_kernel(const float* __restrict__ ws, long long slab, int splits, int Cout,
                                                             int Cin, int CoutP, int CinP, float* __restrict__ dw) {
-  const int ci = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
-  if (ci >= Cin) return;
+  __shared__ float part[3][NT][64];
+  const int sg = threadIdx.x >> 6, ci = blockIdx.x * 64 + (threadIdx.x & 63), co = blockIdx.y;
+  const bool live = ci < Cin;
   float s[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) s[t] = 0.f;
-  for (int z = 0; z < splits; ++z) {
-    const float* p = ws + (long long)z * slab + (long long)co * CinP + ci;
+  if (live) {
+    const long long tap_stride = (long long)CoutP * CinP;
+    for (int z = sg; z < splits; z += 4) {
+      const float* p = ws + (long long)z * slab + (long long)co * CinP + ci;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) s[t] += p[(long long)t * CoutP * CinP];
+      for (int t = 0; t < NT; ++t) s[t] += p[(long long)t * tap_stride];
+    }
   }
-  float* o = dw + ((long long)co * Cin + ci) * NT;
+  if (sg > 0) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) o[t] = s[t];
+    for (int t = 0; t < NT; ++t) part[sg - 1][t][threadIdx.x & 63] = s[t];
+  }
+  __syncthreads();
+  if (sg == 0 && live) {
+    float* o = dw + ((long long)co * Cin + ci) * NT;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o[t] = (s[t] + part[0][t][threadIdx.x]) + (part[1][t][threadIdx.x] + part[2][t][threadIdx.x]);
+  }
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------------------
@@ -242,6 +362,8 @@ static int wbn_class(const avsep_conv_desc* d) {
   if (d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 && d->dil == 1) return 4;
   if (d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 1) return 5;
   if (d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 2) return 6;
+  if (d->KH == 4 && d->KW == 4 && d->stride == 1 && d->pad == 0 && d->dil == 1 && d->Cin == 16 && !d->scale0 && d->act0 == AVSEP_ACT_NONE)
+    return 7;                                              // the stem over space-to-depth frames (raw input)
   return 0;
 }
 static inline bool wbn_enabled() {
@@ -252,6 +374,7 @@ bool wbn_applicable(const avsep_conv_desc* d) {
   if (!wbn_enabled() || !wbn_class(d)) return false;
   if (d->Cin % 16 || d->Cout % 16 || d->Cin < 16 || d->Cout < 16) return false;
   if (d->Wo < 8 || d->Ho < 4 || d->N > 65535) return false;
+  if (wbn_class(d) == 7 && d->Wo <= 16) return false;          // the Cin == 16 form has the 8 x 32 chunk only
   if ((long long)d->N * d->Cin * d->H * d->W >= (1LL << 34) || (long long)d->N * d->Cout * d->Ho * d->Wo >= (1LL << 34)) return false;
   return true;
 }
@@ -317,6 +440,10 @@ int wbn_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, h
   const bool raw = d->scale0 == nullptr && d->act0 == AVSEP_ACT_NONE;
   int rc;
   switch (wbn_class(d)) {
+    case 7:
+      hipLaunchKernelGGL((wgradb_ci16_kernel<4, 4, 8, 32>), dim3(p.gco, 1, p.splits), dim3(512), 0, st, a);
+      rc = hipGetLastError() == hipSuccess ? AVSEP_OK : AVSEP_ERR_LAUNCH;
+      break;
     case 1: rc = wbn_launch<3, 3, 1, 1>(a, p, raw, st); break;
     case 2: rc = wbn_launch<3, 3, 1, 2>(a, p, raw, st); break;
     case 3: rc = wbn_launch<4, 4, 2, 1>(a, p, raw, st); break;
@@ -325,7 +452,7 @@ int wbn_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, h
     default: rc = wbn_launch<1, 1, 2, 1>(a, p, raw, st); break;
   }
   if (rc) return rc;
-  dim3 rg(cdiv(d->Cin, 256), d->Cout);
+  dim3 rg(cdiv(d->Cin, 64), d->Cout);
   switch (d->KH * d->KW) {
     case 9: hipLaunchKernelGGL(wgradb_reduce_kernel<9>, rg, dim3(256), 0, st, ws, a.slab, p.splits, d->Cout, d->Cin, p.CoutP, p.CinP, dw); break;
     case 16: hipLaunchKernelGGL(wgradb_reduce_kernel<16>, rg, dim3(256), 0, st, ws, a.slab, p.splits, d->Cout, d->Cin, p.CoutP, p.CinP, dw); break;

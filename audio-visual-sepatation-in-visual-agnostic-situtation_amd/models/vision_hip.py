@@ -80,6 +80,24 @@ def _stem_s2d_weight(w):
     return (w.reshape(Co, -1)[:, idx].reshape(Co, 16, 4, 4) * ok).contiguous()
 
 
+def _stem_s2d_weight_grad(dw2, Cc):
+    """The adjoint of _stem_s2d_weight: dw' [Co,16,4,4] (gradient of the stride-1 form) -> dw [Co,C,7,7].  Every 7x7 tap sits at
+    exactly one (phase channel, a, b) position, so this is a gather."""
+    Co = dw2.shape[0]
+    key = ("inv", Cc, dw2.device)
+    if key not in _S2D_INDEX:
+        inv = torch.zeros((Cc, 7, 7), dtype=torch.long)
+        for q in range(4 * Cc):
+            c, dy, dx = q % Cc, (q // Cc) >> 1, (q // Cc) & 1
+            for a in range(4):
+                for b in range(4):
+                    kh, kw = 2 * a + dy - 1, 2 * b + dx - 1
+                    if 0 <= kh <= 6 and 0 <= kw <= 6:
+                        inv[c, kh, kw] = (q * 4 + a) * 4 + b
+        _S2D_INDEX[key] = inv.to(dw2.device).reshape(-1)
+    return dw2.reshape(Co, -1)[:, _S2D_INDEX[key]].reshape(Co, Cc, 7, 7)
+
+
 def _stem_is_s2d(conv, x):
     return (conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1)
             and conv.in_channels <= 4 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
@@ -93,6 +111,7 @@ def stem_forward(f, x, training):
     if _stem_is_s2d(f[0], x):
         S["cv0"] = _conv(x, f[0])                       # descriptor of the original conv: the weight gradient uses it
         cs = K.Conv(K.space_to_depth2(x), f[0].out_channels, 4, 1, 0)
+        S["cs"] = cs
         st = K.zeros_stats(f[0].out_channels, x) if training else None
         S["y0"] = cs.fwd(cs.pack(_stem_s2d_weight(_w(f[0])), 0), None, st)
         S["bn0"] = _bn_run(f[1], st, K.per_channel(S["y0"]), training, x)
@@ -190,7 +209,15 @@ def stem_backward(f, S, g, grads, g2=None):
     bst = K.zeros_stats(K.channels(y0), y0)
     K.maxpool_bn_relu_bwd_stats(g, S["idx"], y0, bn0, bst, g2)      # sums over the pooled grid: dz is never written
     pqr0 = _bn_back(grads, f[1], bn0, bst, K.per_channel(y0))
-    # pool backward + ReLU mask + BatchNorm backward; fp32 out: the stem's weight gradient (3 input channels) is an fp32 kernel
+    cs = S.get("cs")
+    if cs is not None and K.is_b16(y0) and cs.io_formats(2)[0] == K.FMT_B16:
+        # bf16 mode: the weight gradient in the conv's stride-1 form over the space-to-depth frames (one 16-channel B16 block:
+        # csrc/wgrad_b16.hip wgradb_ci16_kernel), mapped back to the 7x7 taps by a gather; dy0 stays a B16 image
+        dy0 = K.maxpool_bn_relu_bwd_apply(g, S["idx"], y0, bn0, pqr0, g2)
+        dw2, _ = cs.wgrad(dy0)
+        grads.add(f[0].weight, _stem_s2d_weight_grad(dw2, f[0].in_channels))
+        return
+    # pool backward + ReLU mask + BatchNorm backward; fp32 out: the 7x7/s2 weight gradient over 3 channels is an fp32 kernel
     dy0 = K.maxpool_bn_relu_bwd_apply(g, S["idx"], y0, bn0, pqr0, g2, out_f32=True)
     grads.wgrad(S["cv0"], f[0].weight, dy0)                         # the frames need no gradient
 

@@ -242,6 +242,29 @@ def test_conv_bf16_operands(dev, case):
     assert_close(db, (_bf16(dy) if bf_wgrad else dy.double()).sum((0, 2, 3)), 2e-5, "dbias")
 
 
+def test_stem_weight_gradient_over_space_to_depth_b16(dev):
+    """The ResNet stem's weight gradient in bf16 mode (vision_net.py:84-89 conv1): the 7x7/s2 conv runs as a 4x4/s1 conv over
+    the space-to-depth frames (ONE 16-channel B16 block); csrc/wgrad_b16.hip wgradb_ci16_kernel makes (tap, ci) the GEMM's N
+    dimension.  Against float64 on the bf16-rounded operands, in the 4x4 form and mapped back to the 7x7 taps."""
+    K = _pkg().kernels
+    from avsep_amd.models import vision_hip as VH
+    g = torch.Generator().manual_seed(31)
+    N, H, W, Co = 5, 64, 96, 64
+    x = torch.randn(N, 3, H, W, generator=g)
+    xs = K.space_to_depth2(x.to(dev), b16=True)
+    cs = K.Conv(xs, Co, 4, 1, 0, prec="bf16")
+    assert cs.kernel_name("wgrad") == "wgradb_kernel" and cs.io_formats(2)[0] == K.FMT_B16
+    dy = torch.randn(N, Co, H // 2, W // 2, generator=g)
+    dw2, _ = cs.wgrad(K.to_b16(dy.to(dev)))
+    xs64 = K.to_f32(xs).double().cpu().requires_grad_(False)
+    w2 = torch.zeros(Co, 16, 4, 4, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xs64, w2).backward(_bf16(dy))
+    assert_close(dw2, w2.grad, 2e-5, "stem weight gradient, 4x4 form over the space-to-depth frames")
+    w7 = torch.zeros(Co, 3, 7, 7, dtype=torch.float64, requires_grad=True)
+    F.conv2d(_bf16(x), w7, None, 2, 3).backward(_bf16(dy))
+    assert_close(VH._stem_s2d_weight_grad(dw2, 3), w7.grad, 2e-5, "mapped back to the 7x7 / stride 2 taps")
+
+
 def test_b16_conversions_and_elementwise(dev):
     """csrc/b16.hip against torch on the unpacked values: f32 <-> B16 round trip (B16 = bf16 [N][C/16][H][W][16]); the
     BasicBlock tail, its backward with the BatchNorm-backward sums, the folded BatchNorm backward; results are the bf16
