@@ -95,9 +95,9 @@ def b16_ok(c):
     return c % 16 == 0
 
 
-# Activations between the bf16 kernels are kept as B16 images when the arithmetic mode is bf16 (set_precision) unless this
-# switch is off (A/B runs: AVSEP_BF16_ACTIVATIONS=0 keeps fp32 NCHW tensors and converts at every bf16 kernel's door).
-b16_activations = os.environ.get("AVSEP_BF16_ACTIVATIONS", "1") != "0"
+# Activations between the bf16 kernels are kept as B16 images when the arithmetic mode is bf16 (set_precision).  The module
+# attribute exists for A/B measurements from a script (False: fp32 NCHW tensors, converted at every bf16 kernel's door).
+b16_activations = True
 
 
 def want_b16(c=16):
