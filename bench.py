@@ -9,8 +9,9 @@ tiles, 3 RGB frames at 224^2 per source; one step = zero_grad + NetWrapper.forwa
 frames, TWO U-Net passes over a shared encoder, fusion, BCE) + backward + SGD(momentum, wd) (reference
 main.py:557-569).  Inputs are resident in HBM before the timed region.  The reference computes in fp32, so fp32 is
 the headline arithmetic; the same run then times, outside the headline's timed region and explicitly labelled:
-  * "bf16": configs[2] as BASELINE.json names it — bf16 conv operands (rounded while they are staged into LDS), fp32
-    accumulation / BatchNorm statistics / loss / master weights / SGD — with the loss difference to the fp32 path;
+  * "bf16": configs[2] as BASELINE.json names it — bf16 conv operands AND bf16 channel-blocked activation / gradient images
+    in HBM (AVSEP_FMT_B16), fp32 accumulation / BatchNorm statistics / loss / master weights / SGD — with the loss
+    difference to the fp32 path;
   * with --compare-miopen only: "f32_miopen_hybrid", round 1's configs[1] path (visual convolutions on PyTorch-ROCm /
     MIOpen through tools/miopen_compare, which patches the trunk of that one model instance), for comparison;
   * the audio-only step and the 1:1 AV/AO alternation the shipped flags produce.
@@ -495,8 +496,9 @@ def main():
         add_traffic(roof2, other, B)
         r.update({"dtype": other, "roofline": roof2, "roofline_step": step2, "instrumented_ms_per_step": r_inst["ms_per_step"],
                   "first_step_loss_abs_diff_vs_headline": abs(r["first_step_loss"] - head["first_step_loss"]),
-                  "workload": "same step, conv operands rounded to bf16 while staged, fp32 accumulate / BatchNorm statistics / "
-                              "loss / master weights / SGD (BASELINE configs[2])" if other == "bf16" else "same step in fp32",
+                  "workload": "same step in bf16 mode: bf16 conv operands and bf16 channel-blocked activation / gradient images in HBM, "
+                              "fp32 accumulate / BatchNorm statistics / loss / master weights / SGD (BASELINE configs[2])"
+                              if other == "bf16" else "same step in fp32",
                   "by_kernel": {k: {"ms_per_step": round(v["ms_per_step"], 3), "tflops": round(v["tflops"], 1)} for k, v in k2.items()}})
         extras[other] = r
         if o.compare_miopen:
