@@ -374,6 +374,14 @@ __global__ __launch_bounds__(256) void b16_relu_up2x_bwd_kernel(const u32x4* __r
   float wh[6], ww[6];
   b16_taps6(min(h, H - 1), H, rh, wh);
   b16_taps6(min(w, W - 1), W, rw, ww);
+  // a bilinear x2 source position receives from 4-5 of the 6 window rows / columns; which ones drifts slowly with the position,
+  // so most waves skip a third of the taps in each direction: wave-uniform masks of the taps ANY lane needs
+  unsigned ymask = 0, xmask = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    ymask |= (__builtin_amdgcn_ballot_w64(wh[k] != 0.f) != 0ull ? 1u : 0u) << k;
+    xmask |= (__builtin_amdgcn_ballot_w64(ww[k] != 0.f) != 0ull ? 1u : 0u) << k;
+  }
   const int Ho = 2 * H, Wo = 2 * W, r0 = 2 * h0 - 2, c0w = 2 * w0 - 2;
   // staging slots of this thread: window position (rr, cc), half -> global offset inside an image plane (or -1) and LDS slot
   int l_src[LE], l_dst[LE];
@@ -413,11 +421,13 @@ __global__ __launch_bounds__(256) void b16_relu_up2x_bwd_kernel(const u32x4* __r
       for (int j = 0; j < 8; ++j) tot[j] = 0.f;
 #pragma unroll
       for (int y = 0; y < 6; ++y) {
+        if (!((ymask >> y) & 1u)) continue;                  // wave-uniform: no lane of this wave has a weight on window row y
         float row[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) row[j] = 0.f;
 #pragma unroll
         for (int x = 0; x < 6; ++x) {
+          if (!((xmask >> x) & 1u)) continue;
           float t[8];
           // window column 2tx + x: plane x & 1, column tx + (x >> 1)
           b16_unpack8(tile[(x & 1) * PLANE + ((2 * ty + y) * HWD + tx + (x >> 1)) * 2 + half], t);

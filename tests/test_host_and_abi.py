@@ -306,3 +306,40 @@ def test_pack_scope_key_follows_in_place_weight_updates():
             assert cv.pack(w.detach(), 0) is b              # detach() shares the version counter
     finally:
         K.lib.load, K.call, K._f32, K.ptr = orig_load, orig_call, orig_f32, orig_ptr
+
+
+def test_storage_format_helpers_and_conversion_cache_host_logic():
+    """kernels.py's format layer without a GPU (the conversion launches are stood in for by torch ops): a B16 image is a
+    torch.bfloat16 tensor [N, C/16, H, W, 16] whose dtype is the format tag; dims / channels / per_channel agree for both
+    formats; to_b16 / to_f32 remember the converted twin on the tensor, hand the ORIGINAL back when asked to convert the twin
+    again, and forget it when an in-place kernel is about to overwrite either side (_drop_twin)."""
+    P = _pkg()
+    K = P.kernels
+    calls = []
+
+    def fake_call(name, *a):
+        calls.append(name)
+    orig_call, orig_ptr = K.call, K.ptr
+    K.call, K.ptr = fake_call, (lambda t: 0)
+    try:
+        x = torch.randn(2, 32, 5, 7)
+        assert K.dims(x) == (2, 32, 5, 7) and K.channels(x) == 32 and K.per_channel(x) == 70 and K.fmt_of(x) == K.FMT_F32
+        b = K.to_b16(x)
+        assert calls == ["avsep_f32_to_b16"] and b.dtype == torch.bfloat16 and tuple(b.shape) == (2, 2, 5, 7, 16)
+        assert K.is_b16(b) and K.dims(b) == (2, 32, 5, 7) and K.channels(b) == 32 and K.per_channel(b) == 70
+        assert K.to_b16(x) is b and K.to_f32(b) is x and calls == ["avsep_f32_to_b16"], "twin cache, both directions"
+        assert K.as_fmt(x, K.FMT_B16) is b and K.as_fmt(b, K.FMT_F32) is x and K.as_fmt(None, K.FMT_B16) is None
+        K._drop_twin(b)                                   # b is about to be overwritten in place
+        assert not hasattr(x, "_avsep_twin") and not hasattr(b, "_avsep_twin")
+        assert K.to_f32(b) is not x and calls[-1] == "avsep_b16_to_f32"
+        x.add_(1.0)                                       # a torch in-place op bumps the version: the twin is stale
+        b2 = K.to_b16(x)
+        assert b2 is not b and calls[-1] == "avsep_f32_to_b16"
+        assert K.b16_ok(64) and not K.b16_ok(170)
+        K.set_precision("bf16")
+        assert K.want_b16(64) and not K.want_b16(170)
+        K.set_precision("f32")
+        assert not K.want_b16(64)
+    finally:
+        K.call, K.ptr = orig_call, orig_ptr
+        K.set_precision("f32")
