@@ -996,6 +996,74 @@ def test_inference_wrapper_vs_oracle(dev, ftype):
         cmp(out, OI.forward((osnd, ofrm), (mag, phase), duet, args, True), ["maps", "match_loss"])
 
 
+def test_bf16_mode_eval_and_audio_only_on_b16_images(dev):
+    """bf16 mode OUTSIDE the benched AV train step, at channel widths that really take the B16 kernels (unet5 with ngf 32:
+    32 ... 256 channels on 128x128 tiles; ResNet trunk 64 ... 512): a train-mode AO step (PIT, LeakyReLU / skip-gradient
+    path of the encoder backward on B16 images), then eval-mode AV and AO forwards of the inference wrapper (running
+    statistics instead of batch statistics through the same folded-affine staging) against the fp32 CPU oracle: mask MSE
+    <= 1e-4 (the north-star bound), and the B16 kernel families are asserted to have been launched."""
+    P = _pkg()
+    from oracle import nets as O, step as OS, criterion as OC, inference as OI
+    K = P.kernels
+    torch.manual_seed(4)
+    gen = torch.Generator().manual_seed(4)
+    osnd = O.Unet(fc_dim=2, num_downs=5, ngf=32, fusion_type="hidsep", att_type="sig")
+    O.wide_init(osnd, gen)
+    ofrm = O.VisualNet(fc_dim=128, pool_type="maxpool", dilate_scale=16)
+    snd = P.models.Unet(fc_dim=2, num_downs=5, ngf=32, fusion_type="hidsep", att_type="sig")
+    frm = P.models.ResnetDilated(None, fc_dim=128, pool_type="maxpool")
+    snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict())
+    snd, frm = snd.to(dev), frm.to(dev)
+    args = _args(fusion_type="hidsep")
+    B = 4
+    srcs = [torch.rand(B, 1, 128, 128, generator=gen) ** 2 for _ in range(2)]
+    frames = [torch.randn(B, 3, 2, 96, 96, generator=gen) for _ in range(2)]
+    mb = P.ModelBuilder()
+    wrap = P.NetWrapper((snd, frm), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
+    opt = P.create_optimizer((snd, frm), args)
+    owrap = OS.NetWrapper((osnd, ofrm), OC.build_criterion("bce", True), OC.build_criterion("bce"))
+    oopt = OS.create_optimizer((osnd, ofrm), args)
+    seen = set()
+    orig = {n: getattr(K.Conv, n) for n in ("fwd", "dgrad", "wgrad")}
+
+    def spy(name):
+        def f(cv, *a, **kw):
+            seen.add(cv.kernel_name(name, True))
+            return orig[name](cv, *a, **kw)
+        return f
+    K.set_precision("bf16")
+    for n in orig:
+        setattr(K.Conv, n, spy(n))
+    try:
+        for use_vis in (True, False):
+            draws = torch.tensor([True, False, False, True])
+            snd.ao_draws = draws
+            osnd.levels()[-1].fusion.ao_draws = draws
+            gb = {"mag_mix": (srcs[0] + srcs[1]).to(dev), "mags": [x.clone().to(dev) for x in srcs], "frames": [f.to(dev) for f in frames]}
+            cb = {"mag_mix": srcs[0] + srcs[1], "mags": [x.clone() for x in srcs], "frames": frames}
+            err, _, outs = P.net_wrapper.train_step_async(wrap, gb, opt, use_vis, args)
+            oerr, _, oouts = OS.train_step(owrap, cb, oopt, use_vis, args)
+            mse = max(((a.detach().cpu() - b.detach()) ** 2).mean().item() for a, b in zip(outs["pred_masks"], oouts["pred_masks"]))
+            print(f"bf16 / B16 mid-size {'AV' if use_vis else 'AO'} train step: err hip={err.item():.6f} oracle={oerr:.6f} mask-MSE={mse:.2e}")
+            assert mse <= 1e-4 and abs(err.item() - oerr) <= 5e-3 * max(1.0, abs(oerr))
+        assert {"convbf_kernel", "wgradb_kernel"} <= seen, seen
+        snd.eval(); frm.eval(); osnd.eval(); ofrm.eval()
+        iw = P.inference.NetWrapper((snd, frm))
+        mag, phase = srcs[0] + srcs[1], torch.rand(B, 1, 128, 128, generator=gen)
+        with torch.no_grad():
+            for use_vis in (False, True):
+                clips = [f.clone() for f in frames] if use_vis else None
+                out = iw((mag.to(dev), phase.to(dev)), [c.to(dev) for c in clips] if use_vis else None, args, use_vis)
+                ref = OI.forward((osnd, ofrm), (mag, phase), clips, args, use_vis)
+                mse = max(((out["pred_masks"][n].cpu() - ref["pred_masks"][n]) ** 2).mean().item() for n in range(2))
+                print(f"bf16 / B16 eval-mode {'AV' if use_vis else 'AO'} forward: mask-MSE={mse:.2e}")
+                assert mse <= 1e-4
+    finally:
+        for n, f in orig.items():
+            setattr(K.Conv, n, f)
+        K.set_precision("f32")
+
+
 def test_checkpoint_resume_on_gpu(dev, tmp_path):
     """checkpoint() -> rebuild through ModelBuilder(weights=...) + optimizer state: the resumed run takes the same
     next step as the uninterrupted one (the reference drops the momentum; optim_latest.pth is this build's extra)."""
