@@ -499,7 +499,8 @@ def test_config2_bf16_full_hip_step_vs_oracle(dev):
     _full_size_step(dev, 1, "hip", "bf16", 2e-3)
 
 
-def test_config5_three_sources_five_frames_step_vs_oracle(dev):
+@pytest.mark.parametrize("prec,err_tol", [("f32", 1e-4), ("bf16", 3e-3)])
+def test_config5_three_sources_five_frames_step_vs_oracle(dev, prec, err_tol):
     """BASELINE.json configs[4]: 3-source mix, 512x256 STFT tiles (log_freq 0), 5 frames per source.  The reference
     hard-codes two sources (fusion_net.py:35,43-46; main.py:103,109); the N-source generalisation is build-defined
     (DESIGN.md §9), restated in the oracle (Fusion._coloc_n, ao_permute_n, per-target PIT weights) and pinned to the
@@ -538,10 +539,12 @@ def test_config5_three_sources_five_frames_step_vs_oracle(dev):
     FN, launched = P.models.fusion_net, []
     orig_call = FN.call
     FN.call = lambda name, *args: (launched.append(name), orig_call(name, *args))[1]     # which fusion entry points run
+    P.kernels.set_precision(prec)         # bf16: 512x256 (non-square) tiles and 15 frames per mixture on B16 images
     try:
-        _config5_steps(P, OS, dev, a, raw, mix, mags, snd, osnd, wrap, owrap, opt, oopt)
+        _config5_steps(P, OS, dev, a, raw, mix, mags, snd, osnd, wrap, owrap, opt, oopt, err_tol)
     finally:
         FN.call = orig_call
+        P.kernels.set_precision("f32")
     # the N-source fusion is the HIP kernel pair of csrc/fusion_n.hip (two AV passes + one AO pass, forward and backward),
     # and the two AV passes share one encoder (one U-Net autograd node)
     assert launched.count("avsep_fusion_n_av_fwd") == 2 and launched.count("avsep_fusion_n_av_bwd") == 2, launched
@@ -549,7 +552,7 @@ def test_config5_three_sources_five_frames_step_vs_oracle(dev):
     assert not [n for n in launched if not n.startswith("avsep_fusion_n_")], launched
 
 
-def _config5_steps(P, OS, dev, a, raw, mix, mags, snd, osnd, wrap, owrap, opt, oopt):
+def _config5_steps(P, OS, dev, a, raw, mix, mags, snd, osnd, wrap, owrap, opt, oopt, err_tol=1e-4):
     for use_vis in (True, False):
         draws = torch.tensor([4, 1])                              # permutation indices (itertools order) of the AO step
         snd.ao_draws = draws
@@ -564,9 +567,10 @@ def _config5_steps(P, OS, dev, a, raw, mix, mags, snd, osnd, wrap, owrap, opt, o
                   for x, y in zip(outs["pred_masks"], oouts["pred_masks"]))
         print(f"configs[4] 3 sources {'AV' if use_vis else 'AO'}: err hip={err.item():.6f} oracle={oerr:.6f} mask-MSE={mse:.2e}")
         assert mse <= 1e-4, mse
-        assert abs(err.item() - oerr) <= 1e-4 * max(1.0, abs(oerr)), (use_vis, err.item(), oerr)
+        assert abs(err.item() - oerr) <= err_tol * max(1.0, abs(oerr)), (use_vis, err.item(), oerr)
         if use_vis:
-            assert abs(match.item() - omatch) <= 1e-4
+            # the match term is a sum over 3! permutation scores of 3 attention-map maxima each (|.| ~ 2): bf16 bound 5e-3 of it
+            assert abs(match.item() - omatch) <= (1e-4 if err_tol <= 1e-4 else 5e-3 * max(1.0, abs(omatch))), (match.item(), omatch)
         else:
             assert list(oouts["perms"]) == list(wrap._last_perms), "PIT must pick the same permutation of the 3 sources"
         if use_vis:
