@@ -105,11 +105,23 @@ static BfSplit bf_split_plan(long long wgs, int nK) {
   if (p.splits < 2) { p.splits = 1; p.kts = 0; }
   return p;
 }
+// tile decisions of the flat launches, shared by the launch, the workspace query and avsep_conv_kernel_variant.
+// Measured on one box (round 4, `tools/conv_bench.py --prec bf16`): 256 -> 256 @ 14x14 (294 pixel tiles of 256) ran 30 % faster
+// on 64-row tiles x 512 threads than on 128-row tiles x 256 threads (0.086 -> 0.060 ms forward and data gradient): when
+// 128-row tiles cannot fill two rounds of 512-thread workgroups, halve the rows instead of the pixels.
+struct BfFlat { bool m64, big; int gm; };
+static BfFlat bf_flat_plan(int M, long long planP) {
+  BfFlat f;
+  const long long t256 = cdiv(planP, 256);
+  f.m64 = M <= 64 || (long long)cdiv(M, 128) * t256 < 512;
+  f.gm = cdiv(M, f.m64 ? 64 : 128);
+  f.big = (long long)f.gm * t256 >= 512;
+  return f;
+}
 // workgroups of the unsplit flat launch (mirrors bf_launch_flat)
 static long long bf_flat_wgs(int M, long long P) {
-  const int gm = cdiv(M, M <= 64 ? 64 : 128);
-  const bool big = (long long)gm * cdiv(P, 256) >= 512;
-  return (long long)gm * cdiv(P, big ? 256 : 128);
+  const BfFlat f = bf_flat_plan(M, P);
+  return (long long)f.gm * cdiv(P, f.big ? 256 : 128);
 }
 
 size_t bf_workspace_bytes(const avsep_conv_desc* d, int mode);
@@ -164,14 +176,18 @@ int bf_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
 
 // tile decisions shared by the launches below and avsep_conv_kernel_variant
 struct BfRect { bool wide, m64, big; int gm; };
-static BfRect bf_rect_plan(int M, int Ho, int Wo, int taps, long long planN) {
+// nK = 16-channel K-tiles of the call.  Round-4 measurements behind the two rules (one box, conv_bench): (1) short-K calls
+// (<= 8 K-tiles: the data gradients of u2 / u3, 256 <- 64 @ 128x128 and 512 <- 128 @ 64x64) gain 7 % on 64-row tiles — twice
+// the workgroups hide each other's prologue and epilogue — while long-K calls lose 5 %; (2) 1024 -> 512 @ 16x16 forward
+// (256 workgroups of 256 pixels) runs 0.189 -> 0.140 ms on the 512-thread tiles: one full round of them is enough.
+static BfRect bf_rect_plan(int M, int Ho, int Wo, int taps, long long planN, int nK) {
   BfRect r;
   r.wide = Wo >= 32;
   // 16-tap weight tiles of 128 rows (2 x 64 KB) would not fit beside the stride-2 patch: 64-row tiles there
-  r.m64 = M <= 64 || taps > 9;
+  r.m64 = M <= 64 || taps > 9 || nK <= 8;
   r.gm = cdiv(M, r.m64 ? 64 : 128);
   const long long wg256 = (long long)r.gm * cdiv(Wo, r.wide ? 32 : 16) * cdiv(Ho, r.wide ? 8 : 16) * planN;
-  r.big = wg256 >= 512 && Ho >= (r.wide ? 8 : 16);
+  r.big = wg256 >= 256 && Ho >= (r.wide ? 8 : 16);
   return r;
 }
 void bf_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
@@ -180,9 +196,8 @@ void bf_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
   const long long pn = plan_batch(d);
   if (cls == 3 && bf_flat(d)) {
     const long long planP = pn * d->H * d->W;
-    const int gm = cdiv(M, M <= 64 ? 64 : 128);
-    const bool big = (long long)gm * cdiv(planP, 256) >= 512;
-    snprintf(buf, cap, "flat%d,%dx%d,split%d", bf_flat_w(d->H, d->W, d->dil), M <= 64 ? 64 : 128, big ? 256 : 128,
+    const BfFlat f = bf_flat_plan(M, planP);
+    snprintf(buf, cap, "flat%d,%dx%d,split%d", bf_flat_w(d->H, d->W, d->dil), f.m64 ? 64 : 128, f.big ? 256 : 128,
              bf_split_plan(bf_flat_wgs(M, planP), kc / BF_CK).splits);
     return;
   }
@@ -190,7 +205,7 @@ void bf_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
   if (mode == 1 && cls == 3) { Ho = d->H; Wo = d->W; }
   else if (mode == 1 && cls == 1) taps = 1;
   else if (mode == 1) { Ho = d->H / 2; Wo = d->W / 2; taps = 4; }     // stride-2 data gradient: the (2x2-tap) parity classes
-  const BfRect r = bf_rect_plan(M, Ho, Wo, taps, pn);
+  const BfRect r = bf_rect_plan(M, Ho, Wo, taps, pn, kc / BF_CK);
   snprintf(buf, cap, "%s,%dx%d", r.wide ? (r.big ? "8x32" : "4x32") : (r.big ? "16x16" : "8x16"), r.m64 ? 64 : 128, r.big ? 256 : 128);
 }
 
@@ -200,7 +215,7 @@ void bf_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
 template <int KH_, int KW_, int S_, int DIL_>
 static int bf_launch_rect(C3Args& a, hipStream_t st) {
   constexpr bool ONLY64 = KH_ * KW_ > 9;
-  const BfRect r = bf_rect_plan(a.Cout, a.Ho, a.Wo, KH_ * KW_, c3_plan_n(a));
+  const BfRect r = bf_rect_plan(a.Cout, a.Ho, a.Wo, KH_ * KW_, c3_plan_n(a), a.Cin / BF_CK);
   const bool wide = r.wide, m64 = r.m64, big = r.big;
   a.gridM = r.gm;
   a.tilesX = cdiv(a.Wo, wide ? 32 : 16);
@@ -227,9 +242,9 @@ static int bf_launch_rect(C3Args& a, hipStream_t st) {
 template <int FW_, int DIL_>
 static int bf_launch_flat(C3Args& a, int splits, hipStream_t st) {
   const long long P = (long long)a.N * a.H * a.W, planP = c3_plan_n(a) * a.H * a.W;
-  const bool m64 = a.Cout <= 64;
-  a.gridM = cdiv(a.Cout, m64 ? 64 : 128);
-  const bool big = (long long)a.gridM * cdiv(planP, 256) >= 512;
+  const BfFlat f = bf_flat_plan(a.Cout, planP);
+  const bool m64 = f.m64, big = f.big;
+  a.gridM = f.gm;
   a.tilesX = cdiv(P, big ? 256 : 128);
   a.tilesY = 1;
   dim3 grid((unsigned)((long long)a.gridM * a.tilesX), splits);
