@@ -184,10 +184,14 @@ static BfRect bf_rect_plan(int M, int Ho, int Wo, int taps, long long planN, int
   BfRect r;
   r.wide = Wo >= 32;
   // 16-tap weight tiles of 128 rows (2 x 64 KB) would not fit beside the stride-2 patch: 64-row tiles there
-  r.m64 = M <= 64 || taps > 9 || nK <= 8;
+  // short reductions (K-tiles x taps <= 72): 64-row tiles when there are several M tiles anyway (M >= 256) or the taps are few
+  // (the 1 / 2 / 4-tap parity classes of the stride-2 data gradients: 128 <- 256 @ 28x28 0.090 -> 0.077 ms); a single
+  // 128-row tile stays (64 -> 128 3x3/s2 forward: 0.066 on 64 rows, 0.056 on 128)
+  r.m64 = M <= 64 || taps > 9 || (nK * taps <= 72 && (M >= 256 || taps <= 4));
   r.gm = cdiv(M, r.m64 ? 64 : 128);
   const long long wg256 = (long long)r.gm * cdiv(Wo, r.wide ? 32 : 16) * cdiv(Ho, r.wide ? 8 : 16) * planN;
-  r.big = wg256 >= 256 && Ho >= (r.wide ? 8 : 16);
+  // 512-thread tiles from one full round; a 16-row tile also pays on 9..15-row maps (128 -> 256 3x3/s2 @ 14x14: 0.075 -> 0.048 ms)
+  r.big = wg256 >= 256 && Ho > 8;
   return r;
 }
 void bf_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
