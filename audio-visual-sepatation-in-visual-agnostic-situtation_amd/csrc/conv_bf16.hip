@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "halo_bf16.h"
+#include "res_bf16.h"
 
 // mode 0: forward  M = Cout, k-channel = ci, value w[m][c][tap]
 // mode 1: dgrad    M = Cin,  k-channel = co, value w[c][m][flip(tap)]           (KH x KW taps, stride 1)
@@ -194,6 +195,7 @@ static BfRect bf_rect_plan(int M, int Ho, int Wo, int taps, long long planN, int
   r.big = wg256 >= 256 && Ho > 8;
   return r;
 }
+static bool bf_res_ok(int taps_h, int taps_w, int Kc, int M, int W, int dil, bool flat);
 void bf_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
   const int cls = bf_class(d);
   const int M = mode == 0 ? d->Cout : d->Cin, kc = mode == 0 ? d->Cin : d->Cout;
@@ -205,12 +207,37 @@ void bf_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
              bf_split_plan(bf_flat_wgs(M, planP), kc / BF_CK).splits);
     return;
   }
+  if ((cls == 3 || (cls == 6 && mode == 0)) && bf_res_ok(d->KH, d->KW, kc, M, mode == 0 ? d->Wo : d->W, d->dil, false)) {
+    snprintf(buf, cap, "res8x32,64x256");
+    return;
+  }
   int Ho = d->Ho, Wo = d->Wo, taps = d->KH * d->KW;
   if (mode == 1 && cls == 3) { Ho = d->H; Wo = d->W; }
   else if (mode == 1 && cls == 1) taps = 1;
   else if (mode == 1) { Ho = d->H / 2; Wo = d->W / 2; taps = 4; }     // stride-2 data gradient: the (2x2-tap) parity classes
   const BfRect r = bf_rect_plan(M, Ho, Wo, taps, pn, kc / BF_CK);
   snprintf(buf, cap, "%s,%dx%d", r.wide ? (r.big ? "8x32" : "4x32") : (r.big ? "16x16" : "8x16"), r.m64 ? 64 : 128, r.big ? 256 : 128);
+}
+
+// ---- resident-weights persistent form (res_bf16.h): short reductions with <= 64 output rows --------------------------------
+// 3x3 / s1 / dil 1 with exactly 64 reduction channels on maps >= 32 wide (ResNet layer1, forward and data gradient), and the
+// stem's 4x4 / s1 form over the 16-channel space-to-depth frames
+static bool bf_res_ok(int taps_h, int taps_w, int Kc, int M, int W, int dil, bool flat) {
+  if (flat || dil != 1 || M > 64 || W < 32) return false;
+  return (taps_h == 3 && taps_w == 3 && Kc == 64) || (taps_h == 4 && taps_w == 4 && Kc == 16);
+}
+template <int KH_, int KW_, int NKT>
+static int bf_launch_res(C3Args& a, hipStream_t st) {
+  a.gridM = 1;
+  a.tilesX = cdiv(a.Wo, 32);
+  a.tilesY = cdiv(a.Ho, 8);
+  const long long T = (long long)a.N * a.tilesX * a.tilesY;
+  dim3 grid((unsigned)(T < cu_count() ? T : cu_count()));
+  const bool raw = a.sc0 == nullptr && a.act0 == AVSEP_ACT_NONE;
+  if (raw) hipLaunchKernelGGL((convbf_res_kernel<8, 32, KH_, KW_, NKT, true>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((convbf_res_kernel<8, 32, KH_, KW_, NKT, false>), grid, dim3(512), 0, st, a);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
 }
 
 // ---- launch: tile choice ------------------------------------------------------------------------------------------
@@ -284,6 +311,7 @@ static int bf3_launch(C3Args& a, int dil, void* ws, size_t ws_bytes, int* splits
     if (fw == 8) return bf_launch_flat<8, 1>(a, sp.splits, st);
     return bf_launch_flat<4, 1>(a, sp.splits, st);
   }
+  if (bf_res_ok(3, 3, a.Cin, a.Cout, a.W, dil, false)) return bf_launch_res<3, 3, 4>(a, st);
   return dil == 1 ? bf_launch_rect<3, 3, 1, 1>(a, st) : bf_launch_rect<3, 3, 1, 2>(a, st);
 }
 int splitk_combine(const float* ws, long long slab, int S, const avsep_conv_desc* d, const float* bias, float* y, double* stats,
@@ -310,7 +338,7 @@ int bf_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
   switch (bf_class(d)) {
     case 4: return bf_launch_rect<4, 4, 2, 1>(a, st);
     case 5: return bf_launch_rect<3, 3, 2, 1>(a, st);
-    case 6: return bf_launch_rect<4, 4, 1, 1>(a, st);
+    case 6: return bf_res_ok(4, 4, a.Cin, a.Cout, a.Wo, 1, false) ? bf_launch_res<4, 4, 1>(a, st) : bf_launch_rect<4, 4, 1, 1>(a, st);
     default: return d->stride == 1 ? bf_launch_rect<1, 1, 1, 1>(a, st) : bf_launch_rect<1, 1, 2, 1>(a, st);
   }
 }

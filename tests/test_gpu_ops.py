@@ -169,6 +169,10 @@ BF16_CASES = [
     (2, 64, 30, 28, 144, 3, 2, 1, 1, 0),     # same, 14-wide outputs (layer3.0): forward + dgrad in bf16, weight gradient in f32
     (3, 64, 14, 14, 144, 1, 1, 0, 1, 1),     # 1x1 (layer4.0 downsample): forward + dgrad
     (2, 32, 28, 28, 48, 1, 2, 0, 1, 0),      # 1x1 / stride 2 (layer2.0 / layer3.0 downsample): dgrad zero-fills the skipped pixels
+    (7, 64, 24, 40, 64, 3, 1, 1, 1, 1),      # resident-weights persistent form (ResNet layer1): 64 -> 64, folded affine + ReLU, ragged tiles
+    (40, 64, 16, 64, 48, 3, 1, 1, 1, 0),     # same, raw input, 48 output rows
+    (150, 64, 24, 40, 64, 3, 1, 1, 1, 1),    # same, 900 ragged tiles on 256 persistent workgroups: several tiles per workgroup
+    (6, 16, 27, 43, 64, 4, 1, 0, 1, 0),      # the stem's 4x4 / stride-1 form over 16 space-to-depth channels (resident weights; Cin = 16 wgrad)
 ]
 
 
