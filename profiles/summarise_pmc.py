@@ -27,6 +27,8 @@ def per_kernel(directory):
 
 
 def family(name):
+    if "convbf_res_kernel" in name:          # the resident-weights form is reported under its family (avsep_conv_kernel_name: convbf_kernel)
+        return "convbf_kernel"
     for key in ("winow_kernel", "wino_kernel", "convbf_kernel", "wgradb_reduce_kernel", "wgradb_kernel", "wgradbf_kernel", "wgrad4bf_kernel", "wgrad4d_kernel", "smallci_wgrad_kernel",
                 "conv3x3_kernel", "wgrad3x3_kernel", "head_fwd_kernel", "head_wgrad_kernel", "affine_act_kernel", "maxpool_fwd4_kernel",
                 "head_dgrad_kernel", "smallco_fwd", "smallco_wgrad", "smallci_dgrad", "relu_up2x_fwd",
