@@ -13,11 +13,11 @@
 // A tap (kh, kw) is a constant byte offset on the X read, a stride-2 conv doubles the position step: every geometry is
 // address arithmetic folded into the `offset:` immediates of fully unrolled reads — no shifted copies, no v_alignbit.
 //
-// Workgroup = 64 co x 64 ci x all taps, 4 waves as 2 (co) x 2 (ci), NT accumulator tiles of 16 registers per wave; it walks
-// its share of pixel chunks (TH x TW output pixels of one image; TW % 16 == 0 so that a k-step of 16 pixels stays in one
-// row; columns past the map are zero dY); the next chunk's slots are in flight in registers while the current one is
-// multiplied out of LDS; two workgroups per CU overlap each other's staging.  K-split over chunks -> tap-major slabs
-// [split][tap][co][ci] + a deterministic reduce that writes OIHW.
+// Workgroup = 64 co x 64 ci x all taps, 8 waves as 2 (co) x 2 (ci) x 2 tap groups (4 waves for 1x1), <= 5 accumulator tiles
+// of 16 registers per wave, two waves per SIMD; it walks its share of pixel chunks (TH x TW output pixels of one image;
+// TW % 16 == 0 so that a k-step of 16 pixels stays in one row; columns past the map are zero dY); the next chunk's slots are
+// in flight in registers while the current one is multiplied out of LDS.  K-split over chunks (one workgroup per CU, one
+// round) -> tap-major slabs [split][tap][co][ci] + a split-parallel deterministic reduce that writes OIHW.
 // LDS plane strides are padded so that the two 16-lane groups of a 32-lane half hit disjoint banks (stride 1: planes 128 B
 // apart mod 256; stride 2: 32 B apart mod 64).
 #include <type_traits>
@@ -394,7 +394,7 @@ static WbPlan wbn_plan(const avsep_conv_desc* d) {
   p.CinP = p.gci * 64;
   p.chunks = d->N * p.tilesX * p.tilesY;
   const long long plan_chunks = (long long)plan_batch(d) * p.tilesX * p.tilesY;
-  int s = cdiv(cu_count(), p.gco * p.gci);            // one workgroup per CU (4 waves x up to 512 registers), one round
+  int s = cdiv(cu_count(), p.gco * p.gci);            // one 512-thread workgroup per CU, one round
   if (s > plan_chunks) s = (int)plan_chunks;
   if (s < 1) s = 1;
   p.plan_splits = s;
