@@ -91,6 +91,34 @@ __global__ __launch_bounds__(256) void b16_to_f32_kernel(const u32x4* __restrict
     }
   }
 }
+// dy = p*dz + q*y + r on fp32 NCHW inputs, written as a B16 image: the BatchNorm backward at the fp32 -> B16 boundary below the
+// fused decoder head (its fp32 result was written, read back and converted: two full passes more)
+__global__ __launch_bounds__(256) void f32_bn_bwd_apply_to_b16_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                                      const float* __restrict__ pqr, int C, int HW,
+                                                                      u32x4* __restrict__ out) {
+  const int cb = blockIdx.y, CB = C >> 4, n = blockIdx.z;
+  const long long base = ((long long)n * C + cb * 16) * HW;
+  u32x4* op = out + ((long long)n * CB + cb) * HW * 2;
+  float cp[16], cq[16], cr[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { cp[j] = pqr[cb * 16 + j]; cq[j] = pqr[C + cb * 16 + j]; cr[j] = pqr[2 * C + cb * 16 + j]; }
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = fmaf(cp[j], dz[base + (long long)j * HW + p], fmaf(cq[j], y[base + (long long)j * HW + p], cr[j]));
+    op[2 * p] = u32x4{b16_pack2(v[0], v[1]), b16_pack2(v[2], v[3]), b16_pack2(v[4], v[5]), b16_pack2(v[6], v[7])};
+    op[2 * p + 1] = u32x4{b16_pack2(v[8], v[9]), b16_pack2(v[10], v[11]), b16_pack2(v[12], v[13]), b16_pack2(v[14], v[15])};
+  }
+}
+static bool b16_dims_ok(int N, int C, long long HW);
+extern "C" int avsep_bn_bwd_apply_to_b16(const float* dz, const float* y, const float* pqr, int32_t N, int32_t C, int32_t HW, void* out,
+                                         avsep_stream_t stream) {
+  if (!dz || !y || !pqr || !out || !b16_dims_ok(N, C, HW)) return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(f32_bn_bwd_apply_to_b16_kernel, dim3(min(cdiv(HW, 256), 64), C / 16, N), dim3(256), 0, (hipStream_t)stream, dz, y,
+                     pqr, C, HW, (u32x4*)out);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
 static bool b16_dims_ok(int N, int C, long long HW) {
   return N > 0 && N <= 65535 && C > 0 && C % 16 == 0 && C / 16 <= 65535 && HW > 0 && HW < (1LL << 30);
 }

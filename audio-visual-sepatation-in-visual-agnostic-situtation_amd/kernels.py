@@ -371,10 +371,15 @@ def _same_fmt(main, *others):
     return [as_fmt(o, f) for o in others]
 
 
-def bn_bwd_apply_(dz, y, pqr, out=None, fresh=False):
+def bn_bwd_apply_(dz, y, pqr, out=None, fresh=False, to_b16_out=False):
     """dy = p*dz + q*y + r per channel, in y's storage format; in place on dz unless `out` is given or `fresh` asks for a
-    new tensor.  Returns the result tensor."""
+    new tensor.  `to_b16_out` (fp32 dz and y, C % 16 == 0): write the result as a B16 image in the same pass — its consumers
+    are bf16 kernels.  Returns the result tensor."""
     N, Cc, H, W = dims(y)
+    if to_b16_out and not is_b16(y) and not is_b16(dz) and b16_ok(Cc):
+        dst = _b16((N, Cc, H, W), y)
+        call("avsep_bn_bwd_apply_to_b16", ptr(dz), ptr(y), ptr(pqr), N, Cc, H * W, ptr(dst))
+        return dst
     (dz,) = _same_fmt(y, dz)
     dst = torch.empty_like(y) if fresh else (dz if out is None else out)
     _drop_twin(dst)

@@ -332,7 +332,9 @@ def _decode_bwd(net, E, D, dlogits, dsecond, has_vis, grads, Gd):
             bst = K.zeros_stats(ubn.shape[1], x)
             Gd[i], dz = cv.dgrad_up2x(w, g, mean1=ubn[2], invstd1=ubn[3], bstats1=bst, g0_acc=Gd[i])
             yu = D["yu"][i + 1]
-            g = K.bn_bwd_apply_(dz, yu, _bn_back(grads, lv[i + 1].up_bn, ubn, bst, K.per_channel(yu)))
+            # the consumers of g (level i + 1's weight / data gradient) are bf16 kernels in bf16 mode: write the B16 image directly
+            g = K.bn_bwd_apply_(dz, yu, _bn_back(grads, lv[i + 1].up_bn, ubn, bst, K.per_channel(yu)),
+                                to_b16_out=K.want_b16(K.channels(yu)))
             continue
         dU = cv.dgrad(cv.pack(w, 1), g, out_b16=cat.b16)   # wrt the (virtual) upsampled input, in the format cat.bwd reads
         if i == L - 1:

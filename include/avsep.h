@@ -384,6 +384,10 @@ int avsep_b16_affine_act_bwd(const void* dz, const void* dz2, const void* y, con
 /* out = p*dz + q*y + r with pqr[3*C] from avsep_bn_bwd_coeffs (out may alias dz) */
 int avsep_b16_bn_bwd_apply(const void* dz, const void* y, const float* pqr, int32_t N, int32_t C, int32_t HW, void* out,
                            avsep_stream_t stream);
+/* out (B16) = p*dz + q*y + r with dz, y fp32 NCHW: avsep_bn_bwd_apply + avsep_f32_to_b16 in one pass (the fp32 -> B16 boundary
+ * below the fused decoder head) */
+int avsep_bn_bwd_apply_to_b16(const float* dz, const float* y, const float* pqr, int32_t N, int32_t C, int32_t HW, void* out,
+                              avsep_stream_t stream);
 /* out [N][(C0+C1)/16][2H][2W][16] = bilinear x2 (align_corners) of relu(affine(cat(x0, x1)))   (audio_net.py:66-69,122) */
 int avsep_b16_relu_up2x_fwd(const void* x0, const void* x1, const float* sc0, const float* sh0, const float* sc1,
                             const float* sh1, int32_t N, int32_t C0, int32_t C1, int32_t H, int32_t W, void* out,

@@ -306,6 +306,9 @@ def test_b16_conversions_and_elementwise(dev):
             st_ref = torch.cat([gref.double().sum((0, 2, 3)), (gref.double() * xhat.double()).sum((0, 2, 3))])
             assert_close(bst, st_ref, 1e-4, "b16 BatchNorm-backward sums (taken on the fp32 values before rounding)")
     pqr = torch.randn(3, C, generator=g)
+    fused = K.bn_bwd_apply_(dz.to(dev), y.to(dev), pqr.to(dev), to_b16_out=True)       # fp32 in, B16 out in one pass
+    assert K.is_b16(fused)
+    assert_close(K.to_f32(fused), r16(v4(pqr[0]) * dz + v4(pqr[1]) * y + v4(pqr[2])), 4e-3, "fp32 bn_bwd_apply written as B16")
     o = K.bn_bwd_apply_(B(dz), B(y), pqr.to(dev), fresh=True)
     assert_close(K.to_f32(o), r16(v4(pqr[0]) * r16(dz) + v4(pqr[1]) * r16(y) + v4(pqr[2])), 4e-3, "b16 bn_bwd_apply")
     bst = K.zeros_stats(C, X)
