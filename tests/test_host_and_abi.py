@@ -30,6 +30,37 @@ def test_library_exports_every_declared_symbol():
     assert L.avsep_strerror(-1).startswith(b"invalid argument")
 
 
+def test_every_entry_point_rejects_null_and_zero_arguments():
+    """Error behaviour at the boundary: an int-returning entry point handed null pointers, empty descriptors and zero sizes
+    returns AVSEP_ERR_ARG before anything is launched (this runs without a GPU)."""
+    import ctypes as C
+    P = _pkg()
+    L = P.lib.load()
+    probed = 0
+    for name, (res, args) in sorted(P.lib.SIGNATURES.items()):
+        if res is not C.c_int or not args or name in ("avsep_strerror", "avsep_conv2d_head_applicable"):
+            continue
+        vals = []
+        for a in args:
+            if a is C.c_void_p or a is C.c_char_p:
+                vals.append(None)
+            elif a is P.lib._CD:
+                vals.append(C.byref(P.lib.ConvDesc()))
+            elif a is P.lib._KD:
+                vals.append(C.byref(P.lib.CatDesc()))
+            elif a in (C.c_float, C.c_double):
+                vals.append(0.0)
+            elif a.__name__.startswith("LP_"):
+                vals.append(None)
+            else:
+                vals.append(0)
+        assert getattr(L, name)(*vals) == -1, name
+        probed += 1
+    assert probed >= 55
+    assert L.avsep_conv2d_head_applicable(C.byref(P.lib.ConvDesc())) == 0
+    assert L.avsep_conv_packed_floats(C.byref(P.lib.ConvDesc()), 0) == 0
+
+
 def test_no_cpu_fallback():
     P = _pkg()
     net = P.ModelBuilder().build_sound(arch="unet5", fc_dim=2, fusion_type="hidsep", att_type="sig")
