@@ -15,6 +15,7 @@ for P in f32 bf16; do
   python profiles/summarise_pmc.py gpurun_out/ck/f_$P gpurun_out/ck/w_$P "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 $FLAGS --precision $P" 3 64 gpurun_out/ck/pmc_$P.json > gpurun_out/ck/pmc_$P.log
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/ck/sq_$P -- python3 bench.py --steps 1 --warmup 1 $FLAGS --precision $P > gpurun_out/ck/sq_$P.log 2>&1
   python profiles/summarise_sq.py gpurun_out/ck/sq_$P "rocprofv3 --pmc SQ_* --kernel-trace -- python3 bench.py --steps 1 --warmup 1 $FLAGS --precision $P (full-HIP AV step, batch 64)" > gpurun_out/ck/${TAG}_sq_counters_$P.txt
+  python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extra --precision $P --layers gpurun_out/ck/${TAG}_layers_$P.txt > gpurun_out/ck/layers_$P.log 2>&1
   rm -rf gpurun_out/ck/tr_$P gpurun_out/ck/f_$P gpurun_out/ck/w_$P gpurun_out/ck/sq_$P
   echo done $P
 done
