@@ -690,3 +690,93 @@ extern "C" int avsep_b16_space_to_depth2(const float* x, int32_t N, int32_t C, i
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
+
+// ---- grid image of a batch of small maps -----------------------------------------------------------------------------------------
+// The deep U-Net levels run on 2x2 ... 8x8 maps: a 256-pixel chunk of wgradb_kernel (a tile of ONE image) would be 6-25 % full.
+// Here the N images of the batch are laid side by side in ONE image [1][C/16][HG][WG][16], image n at (n / GX * PY, n % GX * PX),
+// everything else zero, with the conv's folded affine + activation applied on the way (so that the separators are true zeros).
+// With the right pitch the separator rows / columns are the zero padding of every image at once, and wherever one
+// operand of the weight gradient is zero the product vanishes: dW over the grid images of X and dY IS the batch's dW
+// (3x3 / pad 1: pitch H + 1 for both; 4x4 / stride 2 / pad 1: pitch H + 2 for X, H/2 + 1 for dY).
+__global__ __launch_bounds__(256) void b16_grid_pack_kernel(const void* __restrict__ x, int xf32, int N, int C, int H, int W, int GX,
+                                                            int PY, int PX, int HG, int WG, const float* __restrict__ sc,
+                                                            const float* __restrict__ sh, int act, u32x4* __restrict__ out) {
+  const int cb = blockIdx.y, CB = C >> 4;
+  const float slope = act_slope(act);
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= HG * WG * 2) return;
+  const int half = slot & 1, pos = slot >> 1, Y = pos / WG, X = pos % WG;
+  const int gy = Y / PY, r = Y % PY, gx = X / PX, c = X % PX, n = gy * GX + gx, c0 = cb * 16 + half * 8;
+  u32x4 q = {0u, 0u, 0u, 0u};
+  if (r < H && c < W && gx < GX && n < N) {
+    float v[8];
+    if (xf32) {
+      const float* xp = reinterpret_cast<const float*>(x) + (((long long)n * C + c0) * H + r) * W + c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)(__bf16)xp[(long long)j * H * W];   // as stored in a B16 image: rounded before the affine
+    } else {
+      b16_unpack8(reinterpret_cast<const u32x4*>(x)[((((long long)n * CB + cb) * H + r) * W + c) * 2 + half], v);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (sc) v[j] = fmaf(v[j], sc[c0 + j], sh[c0 + j]);
+      v[j] = act_by_slope(v[j], slope);
+    }
+    q = b16_pack8(v);
+  }
+  out[((long long)cb * HG * WG + pos) * 2 + half] = q;
+}
+extern "C" int avsep_b16_grid_pack(const void* x, int32_t xfmt, int32_t N, int32_t C, int32_t H, int32_t W, int32_t GX, int32_t PY,
+                                   int32_t PX, int32_t HG, int32_t WG, const float* scale, const float* shift, int32_t act, void* out,
+                                   avsep_stream_t stream) {
+  if (!x || !out || (xfmt != AVSEP_FMT_F32 && xfmt != AVSEP_FMT_B16) || N <= 0 || C <= 0 || C % 16 || H <= 0 || W <= 0 || GX <= 0 ||
+      PY < H || PX < W || HG <= 0 || WG <= 0 || HG % PY || WG != GX * PX || (long long)(HG / PY) * GX < N ||
+      (long long)HG * WG >= (1LL << 27) || (scale == nullptr) != (shift == nullptr) || act < 0 || act > 2)
+    return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(b16_grid_pack_kernel, dim3(cdiv(HG * WG * 2, 256), C / 16), dim3(256), 0, (hipStream_t)stream, x,
+                     (int)(xfmt == AVSEP_FMT_F32), N, C, H, W, GX, PY, PX, HG, WG, scale, shift, act, (u32x4*)out);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}
+
+// the inverse for a forward result: the real positions of an fp32 grid image [1][C][HG][WG] -> the batch's output (B16 image or
+// fp32 NCHW) with the BatchNorm sums (sum y, sum y^2) of the fp32 values, as the conv epilogues take them
+__global__ __launch_bounds__(256) void grid_unpack_kernel(const float* __restrict__ grid, int N, int C, int H, int W, int GX, int PY,
+                                                          int PX, int HG, int WG, void* __restrict__ out, int of32,
+                                                          double* __restrict__ stats) {
+  const int cb = blockIdx.y, CB = C >> 4;
+  const int slot = blockIdx.x * 256 + threadIdx.x, half = threadIdx.x & 1, c0 = cb * 16 + half * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (slot < N * H * W * 2) {
+    const int pos = slot >> 1, n = pos / (H * W), r = (pos % (H * W)) / W, c = pos % W;
+    const float* gp = grid + ((long long)c0 * HG + (n / GX) * PY + r) * WG + (n % GX) * PX + c;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = gp[(long long)j * HG * WG];
+      s1[j] = v[j];
+      s2[j] = v[j] * v[j];
+    }
+    if (of32) {
+      float* op = reinterpret_cast<float*>(out) + (((long long)n * C + c0) * H + r) * W + c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) op[(long long)j * H * W] = v[j];
+    } else {
+      reinterpret_cast<u32x4*>(out)[((((long long)n * CB + cb) * H + r) * W + c) * 2 + half] = b16_pack8(v);
+    }
+  }
+  if (stats) b16_block_stats(s1, s2, cb, C, stats);
+}
+extern "C" int avsep_grid_unpack(const float* grid, int32_t N, int32_t C, int32_t H, int32_t W, int32_t GX, int32_t PY, int32_t PX,
+                                 int32_t HG, int32_t WG, void* out, int32_t ofmt, double* stats, avsep_stream_t stream) {
+  if (!grid || !out || (ofmt != AVSEP_FMT_F32 && ofmt != AVSEP_FMT_B16) || N <= 0 || C <= 0 || C % 16 || H <= 0 || W <= 0 || GX <= 0 ||
+      PY < H || PX < W || HG <= 0 || WG <= 0 || HG % PY || WG != GX * PX || (long long)(HG / PY) * GX < N ||
+      (long long)HG * WG >= (1LL << 27) || (long long)N * H * W >= (1LL << 27))
+    return AVSEP_ERR_ARG;
+  hipLaunchKernelGGL(grid_unpack_kernel, dim3(cdiv(N * H * W * 2, 256), C / 16), dim3(256), 0, (hipStream_t)stream, grid, N, C, H, W, GX,
+                     PY, PX, HG, WG, out, (int)(ofmt == AVSEP_FMT_F32), stats);
+  AVSEP_LAUNCH_CHECK();
+  return AVSEP_OK;
+}

@@ -104,6 +104,19 @@ def want_b16(c=16):
     return _precision == 1 and b16_activations and b16_ok(c)
 
 
+# bf16 mode: weight gradients of the <= 8x8 maps (the deep U-Net levels) run over ONE grid image of the whole batch instead of
+# one mostly empty 256-pixel chunk per image (csrc/b16.hip: avsep_b16_grid_pack)
+grid_small_maps = os.environ.get("AVSEP_GRID_SMALL_MAPS", "1") != "0"
+
+
+def grid_pack(x, n, c, h, w, gx, gy, py, px, sc=None, sh=None, act=0):
+    """B16 grid image [1, c/16, gy*py, gx*px, 16] of the n small maps of x (fp32 NCHW or B16), act(affine(.)) applied, zeros
+    everywhere else."""
+    out = _b16((1, c, gy * py, gx * px), x)
+    call("avsep_b16_grid_pack", ptr(x), fmt_of(x), n, c, h, w, gx, py, px, gy * py, gx * px, ptr(sc), ptr(sh), act, ptr(out))
+    return out
+
+
 # Operand precision of the convolutions: "f32" (exact f32 MFMA, the reference's arithmetic) or "bf16" (operands rounded
 # to bf16 while they are staged, fp32 accumulation / BatchNorm statistics / outputs / master weights: BASELINE.json
 # configs[2]).  Geometries without a bf16 kernel run in f32 either way.
@@ -178,6 +191,7 @@ class Conv:
         self.d = d
         self.ref = C.byref(d)
         self.like = x0
+        self._grid_xg = None
 
     def io_formats(self, mode):
         """(format the inputs of this call must have, may the output be B16) — mode 0 fwd, 1 dgrad, 2 wgrad."""
@@ -203,7 +217,9 @@ class Conv:
         during which the weights do not change — the image of a (weight, geometry, mode) is built once and shared: the
         second decoder pass of an AV step and the visual trunk's second source used to repack every weight (56 of the
         114 pack launches of a step)."""
-        d = self.d
+        g = self._grid_geometry(0) if mode == 0 else None
+        d = self._grid_desc(g) if g is not None else self.d      # a grid forward multiplies by the N = 1 conv's weight image
+        ref = C.byref(d)
         key = None
         if _pack_cache is not None:
             key = (w.data_ptr(), w._version, mode, d.N, d.Cin, d.H, d.W, d.Cout, d.KH, d.KW, d.stride, d.pad, d.dil, d.C0, d.up2x, d.prec,
@@ -211,12 +227,74 @@ class Conv:
             hit = _pack_cache.get(key)
             if hit is not None:
                 return hit[0]
-        n = lib.load().avsep_conv_packed_floats(self.ref, mode)
+        n = lib.load().avsep_conv_packed_floats(ref, mode)
         out = _f32((n,), w)
-        call("avsep_conv_pack_weights", self.ref, ptr(w), ptr(out), mode)
+        call("avsep_conv_pack_weights", ref, ptr(w), ptr(out), mode)
         if key is not None:
             _pack_cache[key] = (out, w)      # holding `w` keeps a temporary weight tensor's address from being reused
         return out
+
+    def _grid_geometry(self, mode=2):
+        """(images per grid row, grid rows, input pitch, output pitch) when this call runs over a grid image of the batch
+        (bf16 mode, one source, maps of at most 8x8, avsep_b16_grid_pack): the weight gradient (mode 2) of 3x3 / pad 1 and
+        4x4 / stride 2 / pad 1, the forward (mode 0) of 4x4 / stride 2 / pad 1.  None otherwise."""
+        if mode not in (0, 2):
+            return None
+        key = (mode, grid_small_maps, b16_activations)
+        memo = self.__dict__.setdefault("_grid_memo", {})
+        hit = memo.get(key, 0)
+        if hit != 0:
+            return hit
+        memo[key] = g = self._grid_geometry_of(mode)
+        return g
+
+    def _grid_geometry_of(self, mode):
+        d = self.d
+        if not (grid_small_maps and d.prec == 1 and b16_activations and self.keep[1] is None and not d.up2x and d.dil == 1 and
+                self.N >= 2 and b16_ok(self.Cin) and b16_ok(self.Cout) and max(self.H, self.W) <= 8):
+            return None
+        geo = (self.KH, self.KW, d.stride, d.pad)
+        if geo == (3, 3, 1, 1) and mode == 2:
+            pin = pout = (self.H + 1, self.W + 1)
+        elif geo == (4, 4, 2, 1) and self.H % 2 == 0 and self.W % 2 == 0:
+            pin, pout = (self.H + 2, self.W + 2), (self.H // 2 + 1, self.W // 2 + 1)
+        else:
+            return None
+        gx = 1
+        while gx * gx < self.N:
+            gx += 1
+        g = (gx, (self.N + gx - 1) // gx, pin, pout)
+        # only where the grid image is large enough for the bf16 kernel of that mode (two 2x2 maps are not)
+        name = lib.load().avsep_conv_kernel_name(C.byref(self._grid_desc(g)), mode, 0).decode()
+        return g if name == ("wgradb_kernel" if mode == 2 else "convbf_kernel") else None
+
+    def _grid_x(self, g):
+        """The grid image of this call's activated input, shared by its forward and its weight gradient."""
+        x0, _, sc0, sh0 = self.keep[:4]
+        hit = self._grid_xg
+        if hit is not None and hit[0] is x0 and hit[1] == x0._version:
+            return hit[2]
+        gx, gy, (pyi, pxi), _ = g
+        xg = grid_pack(x0, self.N, self.Cin, self.H, self.W, gx, gy, pyi, pxi, sc0, sh0, self.d.act0)
+        self._grid_xg = (x0, x0._version, xg)
+        return xg
+
+    def _grid_inner(self, g):
+        gx, gy, _, (pyo, pxo) = g
+        d = self.d
+        inner = Conv(self._grid_x(g), self.Cout, (self.KH, self.KW), d.stride, d.pad, d.dil, prec="bf16")
+        if (inner.Ho, inner.Wo) != (gy * pyo, gx * pxo):
+            raise lib.AvsepError("grid image geometry")
+        return inner
+
+    def _grid_desc(self, g):
+        """Descriptor of the N = 1 convolution over the grid images (geometry only: for the dispatch queries)."""
+        gx, gy, (pyi, pxi), (pyo, pxo) = g
+        d = ConvDesc.from_buffer_copy(self.d)
+        d.N, d.H, d.W, d.Ho, d.Wo, d.plan_n = 1, gy * pyi, gx * pxi, gy * pyo, gx * pxo, 0
+        d.scale0 = d.shift0 = None
+        d.act0, d.xfmt = 0, FMT_B16
+        return d
 
     def _ws(self, query):
         nbytes = getattr(lib.load(), query)(self.ref)
@@ -226,6 +304,14 @@ class Conv:
     def fwd(self, w_packed, bias=None, stats=None, out_b16=None):
         """`out_b16`: ask for the output as a B16 image (default: whenever the arithmetic mode keeps B16 activations);
         granted when this call's kernel can write one, else the result is fp32 NCHW."""
+        g = self._grid_geometry(0)
+        if g is not None:                            # small maps: one conv over the grid image of the batch, then the real positions
+            gx, gy, _, (pyo, pxo) = g
+            yg = self._grid_inner(g).fwd(w_packed, bias, None, out_b16=False)
+            y, self.d.yfmt = self._out((self.N, self.Cout, self.Ho, self.Wo), want_b16(self.Cout) if out_b16 is None else out_b16, True)
+            call("avsep_grid_unpack", ptr(yg), self.N, self.Cout, self.Ho, self.Wo, gx, pyo, pxo, gy * pyo, gx * pxo, ptr(y),
+                 self.d.yfmt, ptr(stats))
+            return y
         need, allowed = self.io_formats(0)
         self._x_as(need)
         y, self.d.yfmt = self._out((self.N, self.Cout, self.Ho, self.Wo), want_b16(self.Cout) if out_b16 is None else out_b16,
@@ -246,7 +332,11 @@ class Conv:
 
     def kernel_name(self, mode, with_stats=True):
         """Kernel family the library dispatches this call to (mode: "fwd" | "dgrad" | "wgrad")."""
-        return lib.load().avsep_conv_kernel_name(self.ref, {"fwd": 0, "dgrad": 1, "wgrad": 2}[mode], int(with_stats)).decode()
+        ref = self.ref
+        g = self._grid_geometry({"fwd": 0, "wgrad": 2}.get(mode, 1))
+        if g is not None:                            # the call runs on the grid image of the batch
+            ref = C.byref(self._grid_desc(g))
+        return lib.load().avsep_conv_kernel_name(ref, {"fwd": 0, "dgrad": 1, "wgrad": 2}[mode], int(with_stats)).decode()
 
     def kernel_variant(self, mode, with_stats=True, plan_n=None):
         """Family + the grid-size dependent launch decisions (tile shape, workgroup size, split-K) of this call; with
@@ -280,6 +370,11 @@ class Conv:
         shape = (self.Cout, self.Cin, self.KH, self.KW)
         if out is not None and (tuple(out.shape) != shape or not out.is_contiguous() or out.dtype != torch.float32):
             raise lib.AvsepError("wgrad destination must be a dense fp32 OIHW tensor")
+        g = self._grid_geometry(2)
+        if g is not None:
+            gx, gy, _, (pyo, pxo) = g
+            dyg = grid_pack(dy, self.N, self.Cout, self.Ho, self.Wo, gx, gy, pyo, pxo)
+            return self._grid_inner(g).wgrad(dyg, want_bias, out, out_bias)
         need, _ = self.io_formats(2)
         self._x_as(need)
         dy = as_fmt(dy, need)

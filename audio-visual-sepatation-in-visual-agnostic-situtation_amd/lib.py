@@ -100,6 +100,8 @@ SIGNATURES = {
     "avsep_b16_to_f32": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "avsep_b16_affine_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_b16_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_b16_grid_pack": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "avsep_grid_unpack": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "avsep_bn_bwd_apply_to_b16": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "avsep_b16_bn_bwd_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "avsep_b16_relu_up2x_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -384,6 +384,18 @@ int avsep_b16_affine_act_bwd(const void* dz, const void* dz2, const void* y, con
 /* out = p*dz + q*y + r with pqr[3*C] from avsep_bn_bwd_coeffs (out may alias dz) */
 int avsep_b16_bn_bwd_apply(const void* dz, const void* y, const float* pqr, int32_t N, int32_t C, int32_t HW, void* out,
                            avsep_stream_t stream);
+/* Grid image of a batch of small maps (B16 out [1][C/16][HG][WG][16]): image n of x (fp32 NCHW or B16, `xfmt`) goes to rows
+ * (n / GX) * PY .., columns (n % GX) * PX .. after the folded affine (scale / shift per channel, or NULL) and activation `act`
+ * (AVSEP_ACT_NONE / RELU / LRELU02); every other position is zero.  HG = rows (a multiple of PY), WG = GX * PX.  With pitch
+ * H + 1 (3x3 / pad 1; X and dY) or H + 2 for X and H/2 + 1 for dY (4x4 / stride 2 / pad 1) the separators are every image's zero
+ * padding, and avsep_conv2d_wgrad over the two grid images (N = 1) returns the weight gradient of the batch. */
+int avsep_b16_grid_pack(const void* x, int32_t xfmt, int32_t N, int32_t C, int32_t H, int32_t W, int32_t GX, int32_t PY, int32_t PX,
+                        int32_t HG, int32_t WG, const float* scale, const float* shift, int32_t act, void* out, avsep_stream_t stream);
+/* The inverse for a convolution RESULT computed over grid images: out (B16 image or fp32 NCHW, `ofmt`) [N][C][H][W] = the real
+ * positions of the fp32 grid image [1][C][HG][WG] (image n at rows (n / GX) * PY, columns (n % GX) * PX); stats (or NULL) +=
+ * (sum y, sum y^2) per channel of those fp32 values, as avsep_conv2d_fwd accumulates them. */
+int avsep_grid_unpack(const float* grid, int32_t N, int32_t C, int32_t H, int32_t W, int32_t GX, int32_t PY, int32_t PX, int32_t HG,
+                      int32_t WG, void* out, int32_t ofmt, double* stats, avsep_stream_t stream);
 /* out (B16) = p*dz + q*y + r with dz, y fp32 NCHW: avsep_bn_bwd_apply + avsep_f32_to_b16 in one pass (the fp32 -> B16 boundary
  * below the fused decoder head) */
 int avsep_bn_bwd_apply_to_b16(const float* dz, const float* y, const float* pqr, int32_t N, int32_t C, int32_t HW, void* out,

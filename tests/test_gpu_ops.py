@@ -246,6 +246,68 @@ def test_conv_bf16_operands(dev, case):
     assert_close(db, (_bf16(dy) if bf_wgrad else dy.double()).sum((0, 2, 3)), 2e-5, "dbias")
 
 
+@pytest.mark.parametrize("case", [
+    # N, Cin, H, W, Cout, k, stride, pad, affine (0 none, 2 BatchNorm + LeakyReLU)
+    (5, 32, 4, 4, 48, 3, 1, 1, 0), (7, 64, 8, 8, 32, 3, 1, 1, 0), (3, 16, 4, 8, 16, 3, 1, 1, 2),
+    (6, 32, 8, 8, 32, 4, 2, 1, 2), (10, 48, 4, 4, 64, 4, 2, 1, 0), (40, 16, 2, 2, 16, 3, 1, 1, 0), (9, 16, 8, 4, 32, 4, 2, 1, 2),
+])
+def test_small_map_weight_gradient_over_grid_image(dev, case):
+    """bf16 mode, maps of at most 8x8 (the deep U-Net levels, audio_net.py:64-69,75-76): the weight gradient runs over ONE grid
+    image of the batch (avsep_b16_grid_pack: images side by side, zero separators = every image's padding) on wgradb_kernel.
+    Against float64 on the bf16-rounded operands; the grid image itself is checked position by position."""
+    K = _pkg().kernels
+    N, Cin, H, W, Cout, k, s, p, aff = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    t = lambda z: z.to(dev)
+    x16 = x.to(torch.bfloat16).float()
+    v = x16
+    if aff:
+        v = (x16.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
+        v = torch.where(v > 0, v, 0.2 * v)
+    for xin in (K.to_b16(t(x)), t(x)):                    # B16 and fp32 inputs (an fp32 input is rounded as a B16 image would be)
+        cv = K.Conv(xin, Cout, k, s, p, sc0=t(sc) if aff else None, sh0=t(sh) if aff else None, act0=aff, prec="bf16")
+        geo = cv._grid_geometry()
+        assert geo is not None and cv.kernel_name("wgrad") == "wgradb_kernel"
+        gx, gy, (pyi, pxi), (pyo, pxo) = geo
+        xg = K.to_f32(K.grid_pack(xin, N, Cin, H, W, gx, gy, pyi, pxi, t(sc) if aff else None, t(sh) if aff else None, aff)).cpu()
+        ref = torch.zeros(1, Cin, gy * pyi, gx * pxi)
+        for n in range(N):
+            ref[0, :, (n // gx) * pyi:(n // gx) * pyi + H, (n % gx) * pxi:(n % gx) * pxi + W] = v[n].to(torch.bfloat16).float()
+        assert torch.equal(xg, ref), "grid image"
+        dy = torch.randn(N, Cout, cv.Ho, cv.Wo, generator=g)
+        wz = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+        bz = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+        F.conv2d(_bf16(v), wz, bz, s, p).backward(_bf16(dy))
+        dw, db = cv.wgrad(K.to_b16(t(dy)) if K.is_b16(xin) else t(dy), want_bias=True)
+        assert_close(dw, wz.grad, 2e-5, "weight gradient over the grid image")
+        assert_close(db, bz.grad, 2e-5, "bias gradient over the grid image")
+    if k == 4:      # the stride-2 forward (U-Net encoder d5..d7) also runs over the grid image: real positions + statistics
+        assert cv._grid_geometry(0) is not None and cv.kernel_name("fwd") == "convbf_kernel"
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        y_ref = F.conv2d(_bf16(v), _bf16(w), b.double(), s, p)
+        st = K.zeros_stats(Cout, t(x))
+        y = cv.fwd(cv.pack(t(w), 0), t(b), st, out_b16=False)
+        assert y.dtype == torch.float32 and tuple(y.shape) == tuple(y_ref.shape)
+        assert_close(y, y_ref, 2e-5, "forward over the grid image")
+        assert_close(st, torch.cat([y_ref.sum((0, 2, 3)), (y_ref ** 2).sum((0, 2, 3))]), 1e-5, "statistics of the real positions")
+        y16 = cv.fwd(cv.pack(t(w), 0), t(b), None, out_b16=True)
+        assert K.is_b16(y16) and torch.equal(K.to_f32(y16), y.to(torch.bfloat16).float())
+    K.grid_small_maps = False
+    try:
+        assert cv._grid_geometry() is None and cv._grid_geometry(0) is None
+        if k == 4:
+            assert_close(cv.fwd(cv.pack(t(w), 0), t(b), None, out_b16=False), y, 2e-2, "grid forward vs per-image forward")
+        dw0, _ = cv.wgrad(t(dy))                          # the per-image path on the same operands (exact f32 or bf16 kernels)
+    finally:
+        K.grid_small_maps = True
+    assert_close(dw0, dw, 2e-2, "grid path vs per-image path (operand rounding apart)")
+    tiny = K.Conv(t(x[:2, :, :2, :2].contiguous()), Cout, 3, 1, 1, prec="bf16")
+    assert tiny._grid_geometry() is None                  # two 2x2 maps: no grid image is worth a bf16 weight-gradient launch
+
+
 def test_stem_weight_gradient_over_space_to_depth_b16(dev):
     """The ResNet stem's weight gradient in bf16 mode (vision_net.py:84-89 conv1): the 7x7/s2 conv runs as a 4x4/s1 conv over
     the space-to-depth frames (ONE 16-channel B16 block); csrc/wgrad_b16.hip wgradb_ci16_kernel makes (tap, ci) the GEMM's N
