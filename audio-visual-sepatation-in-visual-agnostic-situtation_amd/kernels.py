@@ -226,12 +226,21 @@ class Conv:
                    d.plan_n, bool(d.scale0), bool(d.scale1), d.act0, d.act1)
             hit = _pack_cache.get(key)
             if hit is not None:
+                if hit[2] is not None and torch.cuda.current_stream() != hit[3]:
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(hit[2])           # packed on another stream (fork_streams): order behind it ...
+                    hit[0].record_stream(cur)        # ... and keep its memory from being reused before this stream is done
                 return hit[0]
         n = lib.load().avsep_conv_packed_floats(ref, mode)
         out = _f32((n,), w)
         call("avsep_conv_pack_weights", ref, ptr(w), ptr(out), mode)
         if key is not None:
-            _pack_cache[key] = (out, w)      # holding `w` keeps a temporary weight tensor's address from being reused
+            ev = None
+            if out.is_cuda:                  # streams may share the cache (fork_streams, and the backward of such passes):
+                ev = torch.cuda.Event()      # remember where and when the image was built
+                ev.record()
+            # holding `w` keeps a temporary weight tensor's address from being reused
+            _pack_cache[key] = (out, w, ev, torch.cuda.current_stream() if ev is not None else None)
         return out
 
     def _grid_geometry(self, mode=2):
@@ -416,9 +425,10 @@ _arenas = {}
 def zeros_stats(c, like):
     """[2*c] zeroed doubles on like.device (see _StatsArena)."""
     dev = like.device
-    arena = _arenas.get(dev)
+    key = (dev, torch.cuda.current_stream(dev))        # one arena per stream: its re-clearing memset is ordered on that stream
+    arena = _arenas.get(key)
     if arena is None:
-        arena = _arenas[dev] = _StatsArena(dev)
+        arena = _arenas[key] = _StatsArena(dev)
     out = arena.take(2 * c)
     if out is None:
         return torch.zeros((2 * c,), dtype=torch.float64, device=dev)
@@ -431,12 +441,42 @@ def channel_stats(x, stats):
     call("avsep_channel_stats", ptr(x), N, Cc, x.numel() // (N * Cc), ptr(stats))
 
 
+class fork_streams:
+    """`with fork_streams():` — independent passes of one network (the visual trunk over source 0, source 1, ...) are being
+    issued on different HIP streams.  What they share is ordered with events instead of by the stream: a packed weight image
+    is waited for by the streams that did not build it (Conv.pack), and the running-statistics update of a BatchNorm layer
+    waits for the previous update of the same buffers — the passes update them in the order they were issued, exactly as
+    if they had run back to back (vision_net.py:126-147 is called once per source, main.py:117-121)."""
+
+    def __enter__(self):
+        global _order
+        self.prev, _order = _order, ({} if _order is None else _order)
+        return self
+
+    def __exit__(self, *exc):
+        global _order
+        _order = self.prev
+        return False
+
+
+_order = None      # fork_streams: running_mean.data_ptr() -> (event of the last update, its stream)
+
+
 def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, like, num_batches_tracked=None, updates=1):
     Cc = gamma.numel()
     out = _f32((4, Cc), like)  # scale, shift, mean, invstd
+    ordered = _order is not None and training and rmean is not None
+    if ordered:
+        last = _order.get(rmean.data_ptr())
+        if last is not None and last[1] != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_event(last[0])
     call("avsep_bn_finalize", ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
          float(momentum), float(eps), Cc, int(training), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
          ptr(num_batches_tracked), int(updates))
+    if ordered:
+        ev = torch.cuda.Event()
+        ev.record()
+        _order[rmean.data_ptr()] = (ev, torch.cuda.current_stream())
     return out
 
 

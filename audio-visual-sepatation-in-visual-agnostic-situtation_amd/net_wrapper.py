@@ -71,12 +71,41 @@ class NetWrapper(torch.nn.Module):
                      "gt_masks": [gt[..., i].unsqueeze(1) for i in range(S)],
                      "mag_mix": mag_mix, "mags": mags, "weight": w2}
 
+    # ------------------------------------------------------------------ main.py:117-121
+    fork_sources = os.environ.get("AVSEP_FORK_SOURCES", "1") != "0"
+
+    def _frame_features(self, frames, N, args):
+        """The visual trunk over each source's frames.  The passes are independent (the reference calls net_frame once per
+        source), and a single pass leaves the chip partly idle in its tail rounds and small layers: source n > 0 is issued on
+        its own HIP stream (forward here; autograd runs a node's backward on the stream of its forward), what the passes
+        share is ordered by events (kernels.fork_streams, FlatSGD.node_finished)."""
+        def one(n):
+            return activate(self.net_frame.forward_multiframe(frames[n], pool=args.not_pool_vis), args.img_activation)
+        if not (self.fork_sources and N > 1 and frames[0].is_cuda):
+            return [one(n) for n in range(N)]
+        main = torch.cuda.current_stream()
+        side = self.__dict__.setdefault("_src_streams", [])
+        while len(side) < N - 1:
+            side.append(torch.cuda.Stream())
+        fork = torch.cuda.Event()
+        fork.record(main)                                   # everything the passes read (frames, updated weights) is older
+        feats = [None] * N
+        with K.fork_streams():
+            feats[0] = one(0)
+            for n in range(1, N):
+                side[n - 1].wait_event(fork)
+                with torch.cuda.stream(side[n - 1]):
+                    feats[n] = one(n)
+                feats[n].record_stream(main)
+            for n in range(1, N):
+                main.wait_stream(side[n - 1])
+        return feats
+
     # ------------------------------------------------------------------ main.py:113-148
     def forward_av(self, data, args):
         N = args.num_mix
         frames, _, mags, mag_mix, log_mag_mix, gt_masks, weight = data
-        feat_frames = [activate(self.net_frame.forward_multiframe(frames[n], pool=args.not_pool_vis),
-                                args.img_activation) for n in range(N)]
+        feat_frames = self._frame_features(frames, N, args)
         kind = getattr(self.crit_av, "kind", "bce")
         act = ACT_BY_NAME.get(args.output_activation)
         if act is None:
@@ -195,6 +224,7 @@ class FlatSGD:
         self._pending, self._nodes_left, self._armed = set(), 0, False
         self._slot, self._written, self._returned = {}, set(), set()       # direct gradient placement (grad_dest)
         self._scratch = None
+        self._node_events = []
         self.param_groups = []
         params = []
         for g in groups:
@@ -251,10 +281,29 @@ class FlatSGD:
         gv = self._slot.get(p)
         if gv is None or p not in self._written or p.grad is None or p.grad.data_ptr() != gv.data_ptr():
             return None
-        if self._scratch is None:
-            self._scratch = torch.zeros_like(self.flat_grad)
+        sc = self._scratch_of_current_stream(create=True)
         off = gv.storage_offset()
-        return self._scratch[off:off + gv.numel()].view_as(gv)
+        return sc[off:off + gv.numel()].view_as(gv)
+
+    def _scratch_of_current_stream(self, create=False):
+        """One scratch buffer per stream: nodes that run on different streams (the visual trunk's passes, fork_streams) must
+        not overwrite one another's not yet folded contributions."""
+        if self._scratch is None:
+            self._scratch = {}
+        key = torch.cuda.current_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None
+        sc = self._scratch.get(key)
+        if sc is None and create:
+            sc = self._scratch[key] = torch.zeros_like(self.flat_grad)
+        return sc
+
+    def _wait_for_nodes(self):
+        """Order the current stream behind every autograd node of this step that has reported (node_finished): their kernels
+        wrote into the flat gradient buffer on whatever stream their forward ran on."""
+        if self._node_events:
+            cur = torch.cuda.current_stream(self.flat_grad.device)
+            for ev, st in self._node_events:
+                if st != cur:
+                    cur.wait_event(ev)
 
     def fold_scratch(self, params):
         """flat_grad += scratch over the flat ranges of `params` (merged into contiguous runs; padding holds zeros)."""
@@ -266,13 +315,19 @@ class FlatSGD:
                 runs[-1][1] = off + n
             else:
                 runs.append([off, off + n])
+        self._wait_for_nodes()                      # the first contributions (and earlier folds) may be on other streams
+        sc = self._scratch_of_current_stream()
         for a, b in runs:
-            self.flat_grad[a:b].add_(self._scratch[a:b])
+            self.flat_grad[a:b].add_(sc[a:b])
 
     def node_finished(self, group, returned):
         """An autograd node of network `group` has run its backward; `returned` = the parameters whose gradient it handed
         back to autograd (their AccumulateGrad — and post-accumulate hook — is still to come), the others are in place."""
         self._returned.update(returned)
+        if self.flat_grad.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._node_events.append((ev, torch.cuda.current_stream(self.flat_grad.device)))
         if group != self.param_groups[0]["name"] or not self._armed:
             return
         self._nodes_left -= 1
@@ -289,6 +344,7 @@ class FlatSGD:
     def _maybe_start_early_reduce(self):
         if self._armed and not self._pending and self._nodes_left <= 0 and self._early is None and self._flat_views_intact():
             import torch.distributed as dist
+            self._wait_for_nodes()
             a, b = self.param_groups[0]["range"]
             self._early = dist.all_reduce(self.flat_grad[a:b], group=self.process_group, async_op=True)
             self.early_reductions += 1
@@ -305,6 +361,7 @@ class FlatSGD:
             p.grad = gv
         self._written.clear()
         self._returned.clear()
+        self._node_events = []
         self._early, self._armed, self._nodes_left = None, False, 0     # disarmed until arm_early_reduce()
         self._pending = set()
 
@@ -395,6 +452,7 @@ class FlatSGD:
         """The data-parallel half of step(): fold stray .grad tensors back into the flat buffer, wait for the early
         all-reduce of the first group (if it was issued) and sum the rest of the active range over the ranks with ONE
         all-reduce.  Returns (active groups, scale): flat_grad[range] * scale is the mean gradient over the ranks."""
+        self._wait_for_nodes()
         self._collect()
         active = [g for g in self.param_groups
                   if (only is None or g["name"] in only) and g["range"][1] > g["range"][0] and not g.get("no_grad")]

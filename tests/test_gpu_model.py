@@ -1357,6 +1357,57 @@ def test_rccl_one_rank_group_carries_the_flat_gradient(dev, tmp_path):
           f"early all-reduces {f['early']}, sizes {res['calls']}")
 
 
+@pytest.mark.parametrize("nsrc,prec", [(2, "f32"), (3, "f32"), (2, "bf16")])
+def test_trunk_passes_on_forked_streams_equal_back_to_back(dev, nsrc, prec):
+    """NetWrapper._frame_features issues the visual trunk's pass over source n > 0 on its own HIP stream (main.py:117-121 calls
+    net_frame once per source: the passes are independent).  What they share — packed weight images, the BatchNorm running
+    statistics (updated in source order), the flat gradient buffer and its scratch — is ordered by events: three train steps
+    (AV, AO, AV) must leave the same losses, parameters, momentum and BatchNorm buffers as the same steps with every pass on one
+    stream, up to the run-to-run noise of the fp64 statistics atomics."""
+    P = _pkg()
+    K = P.kernels
+    from oracle import nets as O
+    gen = torch.Generator().manual_seed(21)
+    osnd = O.Unet(fc_dim=nsrc, num_downs=5, ngf=8, fusion_type="hidsep", att_type="sig")
+    O.wide_init(osnd, gen)
+    ofrm = O.VisualNet(fc_dim=64 // nsrc, pool_type="maxpool", dilate_scale=16)
+    args = _args(num_mix=nsrc)
+    srcs = [torch.rand(3, 1, 64, 64, generator=gen) ** 2 for _ in range(nsrc)]
+    frames = [torch.randn(3, 3, 2, 64, 64, generator=gen) for _ in range(nsrc)]
+    mb = P.ModelBuilder()
+    res = {}
+    K.set_precision(prec)
+    try:
+        for fork in (True, False):
+            torch.manual_seed(5)                       # the audio-only step of three sources draws a permutation per sample
+            snd = P.models.Unet(fc_dim=nsrc, num_downs=5, ngf=8, fusion_type="hidsep", att_type="sig")
+            frm = P.models.ResnetDilated(None, fc_dim=64 // nsrc, pool_type="maxpool")
+            snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict())
+            snd, frm = snd.to(dev), frm.to(dev)
+            wrap = P.NetWrapper((snd, frm), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
+            wrap.fork_sources = fork
+            opt = P.create_optimizer((snd, frm), args)
+            losses = []
+            for it, use_vis in enumerate((True, False, True)):
+                if nsrc == 2:
+                    snd.ao_draws = torch.tensor([it % 2 == 0, True, False])
+                b = {"mag_mix": sum(srcs).to(dev), "mags": [s.clone().to(dev) for s in srcs], "frames": [f.to(dev) for f in frames]}
+                err, match, outs = P.net_wrapper.train_step_async(wrap, b, opt, use_vis, args)
+                losses.append(err.item())
+            torch.cuda.synchronize()
+            assert (len(wrap.__dict__.get("_src_streams", [])) == nsrc - 1) == fork
+            res[fork] = (losses, {k: v.detach().double().cpu() for k, v in list(snd.state_dict().items()) + list(frm.state_dict().items())},
+                         opt.flat_buf.detach().double().cpu())
+    finally:
+        K.set_precision("f32")
+    tol = 1e-6 if prec == "f32" else 2e-3       # bf16: a last-bit difference of a statistic can flip a bf16 rounding downstream
+    for x, y in zip(res[True][0], res[False][0]):
+        assert abs(x - y) <= tol * max(1.0, abs(y)), (res[True][0], res[False][0])
+    for (k, v), (_, w) in zip(res[True][1].items(), res[False][1].items()):
+        assert_close(v, w, tol, "forked vs one stream: " + k)
+    assert_close(res[True][2], res[False][2], tol * 10, "momentum buffers")
+
+
 @pytest.mark.parametrize("ftype,att,loss,binary,weighted,log_freq", [
     ("CoLoc_Sel", "cos", "l1", 0, 0, 0), ("hidsep", "cos", "l2", 0, 1, 0), ("CoLoc_Sel", "sig", "bce", 1, 1, 1)])
 def test_step_variants_vs_oracle(dev, ftype, att, loss, binary, weighted, log_freq):
