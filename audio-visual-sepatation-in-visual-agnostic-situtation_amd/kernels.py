@@ -56,33 +56,54 @@ def empty_as(t):
     return torch.empty_like(t)
 
 
+def _twin_hit(t):
+    """The remembered other-format twin of `t` if it is current.  A twin built on another stream (two passes that share a
+    tensor run on forked streams) is waited for, and its memory is kept until this stream is done with it."""
+    twin = getattr(t, "_avsep_twin", None)
+    if twin is None or twin[1] != t._version:
+        return None
+    if twin[2] is not None:
+        cur = torch.cuda.current_stream(t.device)
+        if cur != twin[3]:
+            cur.wait_event(twin[2])
+            twin[0].record_stream(cur)
+    return twin[0]
+
+
+def _twin_set(t, out):
+    ev = st = None
+    if t.is_cuda:
+        ev, st = torch.cuda.Event(), torch.cuda.current_stream(t.device)
+        ev.record()
+    t._avsep_twin = (out, t._version, ev, st)
+    out._avsep_twin = (t, out._version, ev, st)
+
+
 def to_b16(t):
     """B16 image of an fp32 NCHW tensor (one HBM pass).  The converted twin is remembered on the tensor object, so an operand
     that several kernels of a step need in the other format (the forward and the weight gradient of a conv) is converted once."""
     if t is None or is_b16(t):
         return t
-    twin = getattr(t, "_avsep_twin", None)
-    if twin is not None and twin[1] == t._version:
-        return twin[0]
+    twin = _twin_hit(t)
+    if twin is not None:
+        return twin
     N, Cc, H, W = t.shape
     out = _b16((N, Cc, H, W), t)
     call("avsep_f32_to_b16", ptr(t), N, Cc, H * W, ptr(out))
-    t._avsep_twin = (out, t._version)
-    out._avsep_twin = (t, out._version)
+    _twin_set(t, out)
     return out
 
 
 def to_f32(t):
     if t is None or not is_b16(t):
         return t
-    twin = getattr(t, "_avsep_twin", None)
-    if twin is not None and twin[1] == t._version:
-        return twin[0]
+    twin = _twin_hit(t)
+    if twin is not None:
+        return twin
     N, Cc, H, W = dims(t)
     out = _f32((N, Cc, H, W), t)
     call("avsep_b16_to_f32", ptr(t), N, Cc, H * W, ptr(out))
-    t._avsep_twin = (out, t._version)
-    out._avsep_twin = (t, out._version)
+    _twin_set(t, out)
     return out
 
 

@@ -12,6 +12,8 @@ input (in-place aliasing, audio_net.py:64,119-122) so the decoder sees ReLU(z); 
 BatchNorm after the innermost down conv nor around the outermost block; the fusion sits between
 the innermost down and up convs.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -232,6 +234,15 @@ class ParamGrads:
         if bias_p is not None:
             self.add(bias_p, db, ob)
 
+    def fold_second(self):
+        """Add the scratch contributions placed so far into the gradient buffer NOW, on the current stream — the stream the
+        second decoder pass wrote them on when the two passes of an AV step run on forked streams."""
+        if self.sink is not None and self.second:
+            self.sink.fold_scratch(list(self.second))
+            for p in self.second:
+                self.placed[p] = self.sink._slot[p]      # any later contribution of this node adds into the gradient view
+            self.second = {}
+
     def finish(self, params, group=None):
         """The tuple autograd gets (None for the parameters already in their flat views)."""
         out = [self.d.get(p) for p in params]
@@ -316,10 +327,22 @@ def _decode(net, E, vs, draws, training):
     return D
 
 
-def _decode_bwd(net, E, D, dlogits, dsecond, has_vis, grads, Gd):
+def _decode_bwd(net, E, D, dlogits, dsecond, has_vis, grads, Gd, order=None):
     """Decoder + fusion backward, outermost -> innermost.  Accumulates parameter gradients into `grads` and the
-    skip-path gradients into Gd[i] (gradient reaching BN(yd[i]), already ReLU-masked); returns (dbot, dvs)."""
+    skip-path gradients into Gd[i] (gradient reaching BN(yd[i]), already ReLU-masked); returns (dbot, dvs).
+    `order` = ("record" | "wait", events): the two passes of an AV step on forked streams — the first records an event
+    after it has written Gd[i], the second waits for it before accumulating into the same tensor."""
     lv, x = E["lv"], E["x"]
+
+    def gd_sync(i, when):
+        if order is None:
+            return
+        mode, evs = order
+        if mode == "record" and when == "after":
+            evs[i] = torch.cuda.Event()
+            evs[i].record()
+        elif mode == "wait" and when == "before" and evs[i] is not None:
+            torch.cuda.current_stream().wait_event(evs[i])
     L = len(lv)
     g = dlogits.contiguous()
     dfeat = dbot = None
@@ -330,7 +353,9 @@ def _decode_bwd(net, E, D, dlogits, dsecond, has_vis, grads, Gd):
         if cv.head:                                        # fused head: straight to the low-res sources
             ubn = D["ubn"][i + 1]
             bst = K.zeros_stats(ubn.shape[1], x)
+            gd_sync(i, "before")
             Gd[i], dz = cv.dgrad_up2x(w, g, mean1=ubn[2], invstd1=ubn[3], bstats1=bst, g0_acc=Gd[i])
+            gd_sync(i, "after")
             yu = D["yu"][i + 1]
             # the consumers of g (level i + 1's weight / data gradient) are bf16 kernels in bf16 mode: write the B16 image directly
             g = K.bn_bwd_apply_(dz, yu, _bn_back(grads, lv[i + 1].up_bn, ubn, bst, K.per_channel(yu)),
@@ -346,7 +371,9 @@ def _decode_bwd(net, E, D, dlogits, dsecond, has_vis, grads, Gd):
         else:
             ubn = D["ubn"][i + 1]
             bst = K.zeros_stats(ubn.shape[1], x)
+            gd_sync(i, "before")
             Gd[i], dz = cat.bwd(dU, mean1=ubn[2], invstd1=ubn[3], bstats1=bst, g0_acc=Gd[i])
+            gd_sync(i, "after")
             yu = D["yu"][i + 1]
             pqr = _bn_back(grads, lv[i + 1].up_bn, ubn, bst, K.per_channel(yu))
             g = K.bn_bwd_apply_(dz, yu, pqr)
@@ -416,6 +443,20 @@ class _UnetFn(torch.autograd.Function):
         return (None, None, None, None, *dvs, *grads.finish(net.param_list(), "sound"))
 
 
+_FORK_PAIR = os.environ.get("AVSEP_FORK_PAIR", "1") != "0"
+
+
+def _pair_stream(net, x):
+    """The side stream of the second decoder pass of an AV step, or None (CPU tensors, AVSEP_FORK_PAIR=0)."""
+    if not (x.is_cuda and getattr(net, "fork_pair", _FORK_PAIR)):
+        return None
+    s = net.__dict__.get("_pair_side")
+    if s is None:
+        s = torch.cuda.Stream()
+        object.__setattr__(net, "_pair_side", s)
+    return s
+
+
 class _UnetPairFn(torch.autograd.Function):
     """The two U-Net passes of an audio-visual step (main.py:128-141: reversed, then natural visual order) as ONE
     node: both passes see the same input, so the encoder (and its batch statistics) is identical — it runs once
@@ -426,10 +467,26 @@ class _UnetPairFn(torch.autograd.Function):
     def forward(ctx, net, nv, x, *rest):
         training = net.training
         E = _encode(net, x, training, repeat=2)
-        Da = _decode(net, E, list(rest[:nv]), None, training)
-        Db = _decode(net, E, list(rest[nv:2 * nv]), None, training)
+        side = _pair_stream(net, x)
+        if side is None:
+            Da = _decode(net, E, list(rest[:nv]), None, training)
+            Db = _decode(net, E, list(rest[nv:2 * nv]), None, training)
+        else:
+            # The two decoder passes only share what they read (encoder activations, weights) and the BatchNorm running
+            # statistics: the second is issued on its own stream, kernels.fork_streams orders the statistics updates.
+            main, fork = torch.cuda.current_stream(), torch.cuda.Event()
+            fork.record()
+            with K.fork_streams():
+                Da = _decode(net, E, list(rest[:nv]), None, training)
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    Db = _decode(net, E, list(rest[nv:2 * nv]), None, training)
+                main.wait_stream(side)
         ctx.E, ctx.Da, ctx.Db, ctx.net, ctx.training = E, Da, Db, net, training
         oa, ob = _outputs(net, Da, x), _outputs(net, Db, x)
+        if side is not None:
+            for t in ob:
+                t.record_stream(torch.cuda.current_stream())
         ctx.mark_non_differentiable(oa[2], ob[2])
         return (*oa, *ob)
 
@@ -439,8 +496,28 @@ class _UnetPairFn(torch.autograd.Function):
             raise lib.AvsepError("backward through the U-Net needs train mode (batch statistics)")
         net, E = ctx.net, ctx.E
         grads, Gd = ParamGrads(net), [None] * len(E["lv"])
-        dbot_a, dva = _decode_bwd(net, E, ctx.Da, dla, dma, True, grads, Gd)
-        dbot_b, dvb = _decode_bwd(net, E, ctx.Db, dlb, dmb, True, grads, Gd)
+        side = _pair_stream(net, E["x"]) if grads.sink is not None else None
+        if side is None:
+            dbot_a, dva = _decode_bwd(net, E, ctx.Da, dla, dma, True, grads, Gd)
+            dbot_b, dvb = _decode_bwd(net, E, ctx.Db, dlb, dmb, True, grads, Gd)
+        else:
+            # pass A on this stream, pass B on the side stream: B's parameter gradients go to the side stream's scratch buffer
+            # (ParamGrads: the second contribution of a node) and are folded in there, after A's direct writes; the
+            # accumulation into the shared skip gradients Gd[i] is ordered level by level.
+            main, fork, evs = torch.cuda.current_stream(), torch.cuda.Event(), [None] * len(E["lv"])
+            fork.record()
+            dbot_a, dva = _decode_bwd(net, E, ctx.Da, dla, dma, True, grads, Gd, order=("record", evs))
+            done_a = torch.cuda.Event()
+            done_a.record()
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                dbot_b, dvb = _decode_bwd(net, E, ctx.Db, dlb, dmb, True, grads, Gd, order=("wait", evs))
+                side.wait_event(done_a)
+                grads.fold_second()
+            main.wait_stream(side)
+            for t in [dbot_b, *dvb]:
+                if t is not None:
+                    t.record_stream(main)
         _encode_bwd(net, E, dbot_a.add_(dbot_b), Gd, grads)
         ctx.E = ctx.Da = ctx.Db = None
         return (None, None, None, *dva, *dvb, *grads.finish(net.param_list(), "sound"))

@@ -1385,7 +1385,7 @@ def test_trunk_passes_on_forked_streams_equal_back_to_back(dev, nsrc, prec):
             snd.load_state_dict(osnd.state_dict()); frm.load_state_dict(ofrm.state_dict())
             snd, frm = snd.to(dev), frm.to(dev)
             wrap = P.NetWrapper((snd, frm), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
-            wrap.fork_sources = fork
+            wrap.fork_sources = snd.fork_pair = fork            # the trunk's passes and the U-Net's two decoder passes
             opt = P.create_optimizer((snd, frm), args)
             losses = []
             for it, use_vis in enumerate((True, False, True)):
