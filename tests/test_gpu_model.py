@@ -1408,6 +1408,39 @@ def test_trunk_passes_on_forked_streams_equal_back_to_back(dev, nsrc, prec):
     assert_close(res[True][2], res[False][2], tol * 10, "momentum buffers")
 
 
+def test_forked_streams_at_the_benched_size(dev):
+    """The same comparison where the streams really overlap: the full-size model at the benched batch (unet7 +
+    resnet18dilated, batch 64, 3 x 224^2 frames per source, fp32).  Four AV steps from identical seeds with the trunk's
+    passes and the decoder pair forked over streams, against everything on one stream: losses equal to 2e-6 relative (run-to-run
+    noise of the statistics atomics: 1e-7 on the first steps), parameters and BatchNorm buffers to 1e-5."""
+    import os
+    import sys
+    P = _pkg()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res = {}
+    for fork in (True, False):
+        a, snd, frm, wrap = bench.build(P, dev, 0, "hip")
+        wrap.fork_sources = snd.fork_pair = fork
+        opt = P.create_optimizer((snd, frm), a)
+        raw = P.synth.make_batch(64, a.num_mix, a.num_frames, 224, a.audLen, seed=1, device=dev)
+        losses = []
+        for _ in range(4):
+            b = {"audios": list(raw["audios"]), "audio_mix": raw["audio_mix"], "frames": list(raw["frames"])}
+            err, _, _ = P.net_wrapper.train_step_async(wrap, b, opt, True, a)
+            losses.append(float(err))
+        torch.cuda.synchronize()
+        nets = (snd, frm)
+        res[fork] = (losses, torch.cat([p.detach().reshape(-1) for n in nets for p in n.parameters()]).double().cpu(),
+                     torch.cat([b_.detach().reshape(-1).double() for n in nets for b_ in n.buffers()]).cpu())
+        del wrap, opt, snd, frm, raw, nets
+        torch.cuda.empty_cache()
+    for x, y in zip(res[True][0], res[False][0]):
+        assert abs(x - y) <= 2e-6 * max(1.0, abs(y)), (res[True][0], res[False][0])
+    assert_close(res[True][1], res[False][1], 1e-5, "parameters after 4 full-size steps, forked vs one stream")
+    assert_close(res[True][2], res[False][2], 1e-5, "BatchNorm buffers after 4 full-size steps, forked vs one stream")
+
+
 @pytest.mark.parametrize("ftype,att,loss,binary,weighted,log_freq", [
     ("CoLoc_Sel", "cos", "l1", 0, 0, 0), ("hidsep", "cos", "l2", 0, 1, 0), ("CoLoc_Sel", "sig", "bce", 1, 1, 1)])
 def test_step_variants_vs_oracle(dev, ftype, att, loss, binary, weighted, log_freq):

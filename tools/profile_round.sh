@@ -6,16 +6,19 @@ TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ck
 FLAGS="--no-cpu-baseline --no-extra --no-instrumented"
+# kernel durations and counters are taken with every pass of the step on ONE stream (a kernel alone on the chip, as bench.py's
+# instrumented pass measures them); the headline step runs the independent passes on forked streams
+export AVSEP_FORK_SOURCES=0 AVSEP_FORK_PAIR=0
 python bench.py --steps 2 --warmup 1 $FLAGS > gpurun_out/ck/warm.log 2>&1
 for P in f32 bf16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ck/tr_$P -- python3 bench.py --steps 3 --warmup 1 $FLAGS --precision $P > gpurun_out/ck/tr_$P.log 2>&1
-  python profiles/summarise_trace.py gpurun_out/ck/tr_$P "python3 bench.py --steps 3 --warmup 1 $FLAGS --precision $P (full-HIP AV step, batch 64, 4 steps in the trace)" > gpurun_out/ck/${TAG}_bench_kernel_stats_$P.txt
+  python profiles/summarise_trace.py gpurun_out/ck/tr_$P "python3 bench.py --steps 3 --warmup 1 $FLAGS --precision $P (full-HIP AV step, batch 64, 4 steps in the trace; AVSEP_FORK_SOURCES=0 AVSEP_FORK_PAIR=0: one stream)" > gpurun_out/ck/${TAG}_bench_kernel_stats_$P.txt
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/ck/f_$P -- python3 bench.py --steps 2 --warmup 1 $FLAGS --precision $P > gpurun_out/ck/f_$P.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/ck/w_$P -- python3 bench.py --steps 2 --warmup 1 $FLAGS --precision $P > gpurun_out/ck/w_$P.log 2>&1
   python profiles/summarise_pmc.py gpurun_out/ck/f_$P gpurun_out/ck/w_$P "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 $FLAGS --precision $P" 3 64 gpurun_out/ck/pmc_$P.json > gpurun_out/ck/pmc_$P.log
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/ck/sq_$P -- python3 bench.py --steps 1 --warmup 1 $FLAGS --precision $P > gpurun_out/ck/sq_$P.log 2>&1
-  python profiles/summarise_sq.py gpurun_out/ck/sq_$P "rocprofv3 --pmc SQ_* --kernel-trace -- python3 bench.py --steps 1 --warmup 1 $FLAGS --precision $P (full-HIP AV step, batch 64)" > gpurun_out/ck/${TAG}_sq_counters_$P.txt
-  python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extra --precision $P --layers gpurun_out/ck/${TAG}_layers_$P.txt > gpurun_out/ck/layers_$P.log 2>&1
+  python profiles/summarise_sq.py gpurun_out/ck/sq_$P "rocprofv3 --pmc SQ_* --kernel-trace -- python3 bench.py --steps 1 --warmup 1 $FLAGS --precision $P (full-HIP AV step, batch 64; one stream)" > gpurun_out/ck/${TAG}_sq_counters_$P.txt
+  AVSEP_FORK_SOURCES=1 AVSEP_FORK_PAIR=1 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extra --precision $P --layers gpurun_out/ck/${TAG}_layers_$P.txt > gpurun_out/ck/layers_$P.log 2>&1
   rm -rf gpurun_out/ck/tr_$P gpurun_out/ck/f_$P gpurun_out/ck/w_$P gpurun_out/ck/sq_$P
   echo done $P
 done
