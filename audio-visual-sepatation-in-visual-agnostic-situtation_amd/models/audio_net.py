@@ -139,13 +139,21 @@ class Unet(nn.Module):
                 ps += [l.up_bn.weight, l.up_bn.bias]
         return ps
 
-    def forward_pair(self, x, v_a, v_b):
+    def forward_pair(self, x, v_a, v_b, before_decode=None):
         """Two audio-visual passes on the same input with different visual inputs (the AV step of main.py:113-148),
-        sharing the encoder.  Returns ((feat_a, meta_a), (feat_b, meta_b)) exactly like two forward() calls."""
+        sharing the encoder.  Returns ((feat_a, meta_a), (feat_b, meta_b)) exactly like two forward() calls.
+        `before_decode`: called once the encoder has been issued and before anything reads the visual inputs (they may
+        still be in flight on other streams: NetWrapper.forward)."""
         lib.require_gpu(x)
         if self.extra_size is not None or len(v_a) != len(v_b) or not 2 <= len(v_a) <= 4:
+            if before_decode is not None:
+                before_decode()
             return self.forward(x, v_a), self.forward(x, v_b)
+        if before_decode is not None and not all(t.is_contiguous() and t.dtype == torch.float32 for t in (*v_a, *v_b)):
+            before_decode()
+            before_decode = None
         vs = [t.contiguous().float() for t in (*v_a, *v_b)]
+        object.__setattr__(self, "_before_decode", before_decode)
         fa, ma, aa, fb, mb, ab = _UnetPairFn.apply(self, len(v_a), x.contiguous().float(), *vs, *self.param_list())
         return (fa, (ma, aa)), (fb, (mb, ab))
 
@@ -467,6 +475,9 @@ class _UnetPairFn(torch.autograd.Function):
     def forward(ctx, net, nv, x, *rest):
         training = net.training
         E = _encode(net, x, training, repeat=2)
+        hook = net.__dict__.pop("_before_decode", None)
+        if hook is not None:
+            hook()                                   # the visual inputs' streams are joined here, behind the encoder
         side = _pair_stream(net, x)
         if side is None:
             Da = _decode(net, E, list(rest[:nv]), None, training)

@@ -73,39 +73,58 @@ class NetWrapper(torch.nn.Module):
 
     # ------------------------------------------------------------------ main.py:117-121
     fork_sources = os.environ.get("AVSEP_FORK_SOURCES", "1") != "0"
+    early_trunk = os.environ.get("AVSEP_EARLY_TRUNK", "1") != "0"
 
-    def _frame_features(self, frames, N, args):
+    def _frame_features(self, frames, N, args, early=False):
         """The visual trunk over each source's frames.  The passes are independent (the reference calls net_frame once per
-        source), and a single pass leaves the chip partly idle in its tail rounds and small layers: source n > 0 is issued on
-        its own HIP stream (forward here; autograd runs a node's backward on the stream of its forward), what the passes
-        share is ordered by events (kernels.fork_streams, FlatSGD.node_finished)."""
+        source), and a single pass leaves the chip partly idle in its tail rounds and small layers: the passes are issued on
+        HIP streams of their own (forward here; autograd runs a node's backward on the stream of its forward), what they
+        share is ordered by events (kernels.fork_streams, FlatSGD.node_finished).
+        early=False: source 0 on the current stream, the others on side streams, joined before returning -> list of features.
+        early=True (NetWrapper.forward, before the STFT): every source on a side stream; returns (features, join) and the
+        caller joins when the features are needed — the STFT, the mask preparation and the U-Net encoder of the current stream
+        run meanwhile."""
         def one(n):
             return activate(self.net_frame.forward_multiframe(frames[n], pool=args.not_pool_vis), args.img_activation)
         if not (self.fork_sources and N > 1 and frames[0].is_cuda):
-            return [one(n) for n in range(N)]
+            feats = [one(n) for n in range(N)]
+            return (feats, None) if early else feats
         main = torch.cuda.current_stream()
         side = self.__dict__.setdefault("_src_streams", [])
-        while len(side) < N - 1:
+        while len(side) < N:
             side.append(torch.cuda.Stream())
         fork = torch.cuda.Event()
         fork.record(main)                                   # everything the passes read (frames, updated weights) is older
-        feats = [None] * N
+        feats, used = [None] * N, []
         with K.fork_streams():
-            feats[0] = one(0)
-            for n in range(1, N):
-                side[n - 1].wait_event(fork)
-                with torch.cuda.stream(side[n - 1]):
+            for n in range(N):
+                if n == 0 and not early:
+                    feats[0] = one(0)
+                    continue
+                s = side[n]
+                s.wait_event(fork)
+                with torch.cuda.stream(s):
                     feats[n] = one(n)
                 feats[n].record_stream(main)
-            for n in range(1, N):
-                main.wait_stream(side[n - 1])
+                used.append(s)
+
+        def join():
+            for s in used:
+                main.wait_stream(s)
+        if early:
+            return feats, join
+        join()
         return feats
 
     # ------------------------------------------------------------------ main.py:113-148
-    def forward_av(self, data, args):
+    def forward_av(self, data, args, early_feats=None):
         N = args.num_mix
         frames, _, mags, mag_mix, log_mag_mix, gt_masks, weight = data
-        feat_frames = self._frame_features(frames, N, args)
+        join = None
+        if early_feats is not None:
+            feat_frames, join = early_feats
+        else:
+            feat_frames = self._frame_features(frames, N, args)
         kind = getattr(self.crit_av, "kind", "bce")
         act = ACT_BY_NAME.get(args.output_activation)
         if act is None:
@@ -115,8 +134,13 @@ class NetWrapper(torch.nn.Module):
         errs, sums_both, matches = [], [], []
         # pass 1: visual features in reversed order against reversed targets; pass 2: natural order.
         # Both passes read the same spectrogram: the U-Net shares its encoder between them (forward_pair).
-        if hasattr(self.net_sound, "forward_pair") and getattr(self, "share_encoder", True) and 2 <= N <= 4:
-            passes = self.net_sound.forward_pair(log_mag_mix, feat_frames[::-1], feat_frames)
+        pair = hasattr(self.net_sound, "forward_pair") and getattr(self, "share_encoder", True) and 2 <= N <= 4
+        if join is not None and not (pair and all(t.is_contiguous() and t.dtype == torch.float32 for t in feat_frames)):
+            join()                                     # no node that could take the join between its encoder and its decoder
+            join = None
+        if pair:
+            # `before_decode`: the trunk's streams are joined after the encoder has been issued (it does not read the features)
+            passes = self.net_sound.forward_pair(log_mag_mix, feat_frames[::-1], feat_frames, before_decode=join)
             self.unet_nodes = 1 if getattr(self.net_sound, "extra_size", None) is None else 2
         else:
             passes = None
@@ -171,13 +195,18 @@ class NetWrapper(torch.nn.Module):
 
     # ------------------------------------------------------------------ main.py:150-160
     def forward(self, batch_data, args, use_vis, is_share=False):
+        early = None
+        if use_vis and args.fusion_type != "MixVis" and self.fork_sources and self.early_trunk and args.num_mix > 1 and \
+                batch_data["frames"][0].is_cuda:
+            # the visual trunk does not read the spectrograms: issue its passes first, on their streams
+            early = self._frame_features(batch_data["frames"], args.num_mix, args, early=True)
         if "mag_mix" not in batch_data:
             self.attach_stft(batch_data, args)
         data = self.prepare(batch_data, args, use_vis, is_share)
         if use_vis:
             if args.fusion_type == "MixVis":
                 return self.forward_avmiximg(data, args)
-            return self.forward_av(data, args)
+            return self.forward_av(data, args, early_feats=early)
         return self.forward_ao(data, args)
 
     # ------------------------------------------------------------------ dataset/base.py:142-147,174-189 on the GPU

@@ -1395,7 +1395,7 @@ def test_trunk_passes_on_forked_streams_equal_back_to_back(dev, nsrc, prec):
                 err, match, outs = P.net_wrapper.train_step_async(wrap, b, opt, use_vis, args)
                 losses.append(err.item())
             torch.cuda.synchronize()
-            assert (len(wrap.__dict__.get("_src_streams", [])) == nsrc - 1) == fork
+            assert (len(wrap.__dict__.get("_src_streams", [])) == nsrc) == fork      # one stream per source (issued before the STFT)
             res[fork] = (losses, {k: v.detach().double().cpu() for k, v in list(snd.state_dict().items()) + list(frm.state_dict().items())},
                          opt.flat_buf.detach().double().cpu())
     finally:
