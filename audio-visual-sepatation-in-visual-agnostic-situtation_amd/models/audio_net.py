@@ -430,6 +430,7 @@ class _UnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, draws, nv, x, *rest):
         vs, training = list(rest[:nv]), net.training
+        _release_deferred(net)
         E = _encode(net, x, training)
         D = _decode(net, E, vs, draws, training)
         ctx.E, ctx.D, ctx.net, ctx.nv, ctx.training = E, D, net, nv, training
@@ -452,6 +453,18 @@ class _UnetFn(torch.autograd.Function):
 
 
 _FORK_PAIR = os.environ.get("AVSEP_FORK_PAIR", "1") != "0"
+_ENC_SIDE = os.environ.get("AVSEP_ENC_SIDE", "1") != "0"
+
+
+def _release_deferred(net):
+    """Drop the tensors a previous backward left to its side stream (the encoder's backward runs there while the caller's
+    stream has moved on): first order the current stream behind that stream, so that memory handed back to the current
+    stream's pool is not reused under kernels that still read it."""
+    if net.__dict__.get("_pair_deferred") is not None:
+        s = net.__dict__.get("_pair_side")
+        if s is not None:
+            torch.cuda.current_stream().wait_stream(s)
+        object.__setattr__(net, "_pair_deferred", None)
 
 
 def _pair_stream(net, x):
@@ -474,6 +487,7 @@ class _UnetPairFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, nv, x, *rest):
         training = net.training
+        _release_deferred(net)
         E = _encode(net, x, training, repeat=2)
         hook = net.__dict__.pop("_before_decode", None)
         if hook is not None:
@@ -523,12 +537,37 @@ class _UnetPairFn(torch.autograd.Function):
             side.wait_event(fork)
             with torch.cuda.stream(side):
                 dbot_b, dvb = _decode_bwd(net, E, ctx.Db, dlb, dmb, True, grads, Gd, order=("wait", evs))
+                done_b = torch.cuda.Event()
+                done_b.record()
                 side.wait_event(done_a)
                 grads.fold_second()
-            main.wait_stream(side)
-            for t in [dbot_b, *dvb]:
+            if not getattr(net, "encoder_bwd_on_side", _ENC_SIDE):
+                main.wait_stream(side)
+                for t in [dbot_b, *dvb]:
+                    if t is not None:
+                        t.record_stream(main)
+                _encode_bwd(net, E, dbot_a.add_(dbot_b), Gd, grads)
+                ctx.E = ctx.Da = ctx.Db = None
+                return (None, None, None, *dva, *dvb, *grads.finish(net.param_list(), "sound"))
+            with torch.cuda.stream(side):
+                # The encoder's backward continues HERE, on the side stream, and this stream returns to autograd with the
+                # gradients of the visual inputs: the visual trunk's nodes start while the encoder's gradients are computed
+                # (they need nothing from it).  Its parameter gradients are covered by the node's event (FlatSGD.node_finished,
+                # recorded on the side stream), which the optimizer step and the all-reduces wait for.
+                _encode_bwd(net, E, dbot_b.add_(dbot_a), Gd, grads)
+                pg = grads.finish(net.param_list(), "sound")
+            main.wait_event(done_b)
+            for t in dvb:
                 if t is not None:
                     t.record_stream(main)
+            if any(g is not None for g in pg):
+                main.wait_stream(side)               # a gradient handed back to autograd: it must be complete on this stream
+            # what the side stream is still reading stays alive until the streams have met again: at the end of this backward
+            # pass (FlatSGD._end_of_backward), or at the latest before the next forward
+            object.__setattr__(net, "_pair_deferred", (E, ctx.Da, ctx.Db, Gd, dbot_a, dbot_b))
+            grads.sink.at_end_of_backward(lambda: _release_deferred(net))
+            ctx.E = ctx.Da = ctx.Db = None
+            return (None, None, None, *dva, *dvb, *pg)
         _encode_bwd(net, E, dbot_a.add_(dbot_b), Gd, grads)
         ctx.E = ctx.Da = ctx.Db = None
         return (None, None, None, *dva, *dvb, *grads.finish(net.param_list(), "sound"))

@@ -254,6 +254,7 @@ class FlatSGD:
         self._slot, self._written, self._returned = {}, set(), set()       # direct gradient placement (grad_dest)
         self._scratch = None
         self._node_events = []
+        self._end_queued, self._at_end = False, []
         self.param_groups = []
         params = []
         for g in groups:
@@ -357,12 +358,32 @@ class FlatSGD:
             ev = torch.cuda.Event()
             ev.record()
             self._node_events.append((ev, torch.cuda.current_stream(self.flat_grad.device)))
+            self._queue_end_of_backward()
         if group != self.param_groups[0]["name"] or not self._armed:
             return
         self._nodes_left -= 1
         if self._nodes_left == 0:
             self._pending -= (self._written - self._returned)       # placed by a kernel and complete: no hook will fire
             self._maybe_start_early_reduce()
+
+    def _queue_end_of_backward(self):
+        """Nodes whose forward ran on a forked stream wrote their gradients on that stream and handed autograd nothing to
+        synchronise on: when the engine has run the last node of this backward pass, order the CALLER's stream behind every
+        node (the contract of .backward(): its results are usable on the calling stream) and run the deferred releases."""
+        if not self._end_queued:
+            self._end_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def at_end_of_backward(self, fn):
+        self._at_end.append(fn)
+        self._queue_end_of_backward()
+
+    def _end_of_backward(self):
+        self._end_queued = False
+        self._wait_for_nodes()
+        fns, self._at_end = self._at_end, []
+        for fn in fns:
+            fn()
 
     def _on_first_group_grad(self, p):
         """Fires once per parameter of the first group after autograd accumulated into its flat view."""
@@ -391,6 +412,7 @@ class FlatSGD:
         self._written.clear()
         self._returned.clear()
         self._node_events = []
+        self._end_queued, self._at_end = False, []       # (a backward pass that raised never ran its final callback)
         self._early, self._armed, self._nodes_left = None, False, 0     # disarmed until arm_early_reduce()
         self._pending = set()
 

@@ -1386,6 +1386,7 @@ def test_trunk_passes_on_forked_streams_equal_back_to_back(dev, nsrc, prec):
             snd, frm = snd.to(dev), frm.to(dev)
             wrap = P.NetWrapper((snd, frm), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
             wrap.fork_sources = snd.fork_pair = fork            # the trunk's passes and the U-Net's two decoder passes
+            snd.encoder_bwd_on_side = fork
             opt = P.create_optimizer((snd, frm), args)
             losses = []
             for it, use_vis in enumerate((True, False, True)):
