@@ -1425,6 +1425,16 @@ def test_forked_streams_at_the_benched_size(dev):
         wrap.fork_sources = snd.fork_pair = fork
         opt = P.create_optimizer((snd, frm), a)
         raw = P.synth.make_batch(64, a.num_mix, a.num_frames, 224, a.audLen, seed=1, device=dev)
+        # first a forward + backward WITHOUT the optimizer step, and the flat gradient read on the calling stream at once, with
+        # no device synchronisation in between: .backward()'s contract (results usable on the caller's stream) is restored by
+        # FlatSGD._end_of_backward for the nodes that ran on forked streams.  (At the initial weights: after a few steps the
+        # gradient of this random problem is chaotic — two forked runs differ by 25 % — while losses and weights still agree.)
+        opt.zero_grad()
+        with P.kernels.pack_scope():
+            b = {"audios": list(raw["audios"]), "audio_mix": raw["audio_mix"], "frames": list(raw["frames"])}
+            err, _ = wrap.forward(b, a, True)
+            err.mean().backward()
+        g_now = opt.flat_grad.clone()                      # ordered on the calling stream only
         losses = []
         for _ in range(4):
             b = {"audios": list(raw["audios"]), "audio_mix": raw["audio_mix"], "frames": list(raw["frames"])}
@@ -1433,13 +1443,14 @@ def test_forked_streams_at_the_benched_size(dev):
         torch.cuda.synchronize()
         nets = (snd, frm)
         res[fork] = (losses, torch.cat([p.detach().reshape(-1) for n in nets for p in n.parameters()]).double().cpu(),
-                     torch.cat([b_.detach().reshape(-1).double() for n in nets for b_ in n.buffers()]).cpu())
-        del wrap, opt, snd, frm, raw, nets
+                     torch.cat([b_.detach().reshape(-1).double() for n in nets for b_ in n.buffers()]).cpu(), g_now.double().cpu())
+        del wrap, opt, snd, frm, raw, nets, g_now, err, b
         torch.cuda.empty_cache()
     for x, y in zip(res[True][0], res[False][0]):
         assert abs(x - y) <= 2e-6 * max(1.0, abs(y)), (res[True][0], res[False][0])
     assert_close(res[True][1], res[False][1], 1e-5, "parameters after 4 full-size steps, forked vs one stream")
     assert_close(res[True][2], res[False][2], 1e-5, "BatchNorm buffers after 4 full-size steps, forked vs one stream")
+    assert_close(res[True][3], res[False][3], 1e-4, "flat gradient read right after the first backward(), forked vs one stream")
 
 
 @pytest.mark.parametrize("ftype,att,loss,binary,weighted,log_freq", [
