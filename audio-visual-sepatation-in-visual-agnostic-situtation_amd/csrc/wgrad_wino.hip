@@ -76,7 +76,6 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
   const int wi = wave & 3, wcb = wave >> 2;
   const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
   const int m0 = mt * B, c0 = ct * B;
-  const long long HW = (long long)a.H * a.W;
   const int iHW = a.H * a.W;
   // the 64-channel input block lies in one source
   const bool src1 = c0 >= a.C0;
