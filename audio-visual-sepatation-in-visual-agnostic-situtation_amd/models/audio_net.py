@@ -221,7 +221,7 @@ class ParamGrads:
         if wrote is not None and g is wrote:
             return
         if p in self.second:
-            self.sink.scratch_dest(p).add_(g)
+            self.second[p].add_(g)               # the view handed out for it (the scratch buffer is per stream)
         elif p in self.placed:
             self.placed[p].add_(g)
         elif p in self.d:
