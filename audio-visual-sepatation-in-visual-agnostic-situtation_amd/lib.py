@@ -101,6 +101,10 @@ SIGNATURES = {
     "avsep_b16_affine_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "avsep_b16_affine_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "avsep_b16_grid_pack": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "avsep_bss_corr": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "avsep_bss_solve_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "avsep_bss_solve": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P]),
+    "avsep_bss_project": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "avsep_grid_unpack": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "avsep_bn_bwd_apply_to_b16": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "avsep_b16_bn_bwd_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),

@@ -423,6 +423,23 @@ int avsep_b16_maxpool_bn_relu_bwd(const void* g, const void* g2, const void* idx
 /* avsep_space_to_depth2 written as a one-block B16 image [N][1][H/2+3][W/2+3][16] (4*C <= 16) */
 int avsep_b16_space_to_depth2(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, void* xs, avsep_stream_t stream);
 
+/* ---- BSS-eval SDR / SIR / SAR (eval path; replaces asteroid -> mir_eval.separation.bss_eval_sources, main.py:260-266) ----------
+ * float64 throughout, as mir_eval.  refs [B][S][L], ests [B][E][L] (E == S in the reference's use), flen <= 512 delayed copies.
+ * avsep_bss_corr:    R [B][S][S][2*flen-1]: R[..][tau + flen - 1] = sum_t ref_i[t + tau] * ref_j[t]  (the block-Toeplitz Gram matrix),
+ *                    D [B][E][S][flen]:     D[..][k] = sum_t ref_i[t - k] * est_e[t]                 (the right-hand sides).
+ * avsep_bss_solve:   least-squares filters by LU with partial pivoting (numpy.linalg.solve's algorithm), one workgroup per system.
+ *                    mode 0: all sources, C [B][S*flen][E];  mode 1: own source only (E == S), C [B*S][flen][1].
+ *                    info[system] = 0, or k + 1 when pivot k is exactly zero (a silent source): C is zero there and the caller
+ *                    solves that system by minimum-norm least squares, as mir_eval does.  workspace: avsep_bss_solve_workspace_bytes.
+ * avsep_bss_project: out [B][E][L + flen - 1] = sum_i conv(C_i, ref_i) (mode 0) or conv(C_e, ref_e) (mode 1). */
+int avsep_bss_corr(const double* refs, const double* ests, int32_t B, int32_t S, int32_t E, int32_t L, int32_t flen, double* R, double* D,
+                   avsep_stream_t stream);
+size_t avsep_bss_solve_workspace_bytes(int32_t B, int32_t S, int32_t flen, int32_t mode);
+int avsep_bss_solve(const double* R, const double* D, int32_t B, int32_t S, int32_t E, int32_t flen, int32_t mode, double* workspace,
+                    size_t workspace_bytes, double* C, int32_t* info, avsep_stream_t stream);
+int avsep_bss_project(const double* refs, const double* C, int32_t B, int32_t S, int32_t E, int32_t L, int32_t flen, int32_t mode,
+                      double* out, avsep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -962,6 +962,63 @@ def test_bss_eval_vs_oracle(dev):
     assert sdr[1, 0].item() > 25 and plain < 3
 
 
+@pytest.mark.parametrize("B,S,L,flen", [(3, 2, 20000, 512), (2, 3, 9000, 512), (2, 2, 3000, 64), (1, 1, 5000, 512)])
+def test_bss_eval_kernels_vs_oracle(dev, B, S, L, flen):
+    """csrc/bsseval.hip against the numpy restatement of mir_eval (oracle/bss_eval.py) on correlated mixtures: more samples,
+    three sources (a 1536 x 1536 system per sample), a short filter, a single source; and the pieces on their own — the
+    lagged correlations against numpy.correlate, the solved filters against numpy.linalg.solve on the same Gram matrix."""
+    from oracle import bss_eval as OB
+    from avsep_amd import bss_eval as PB
+    P = _pkg()
+    rs = np.random.RandomState(B * 100 + S * 10 + flen)
+    s = rs.randn(B, S, L)
+    s[:, :, 1:] += 0.6 * s[:, :, :-1]                                     # coloured sources: an ill-conditioned Gram matrix
+    mixm = np.eye(S) + 0.2 * rs.randn(S, S)
+    ests = np.einsum("es,bsl->bel", mixm, s) + 0.03 * rs.randn(B, S, L)
+    sdr, sir, sar = PB.bss_eval_sources(torch.from_numpy(s).to(dev), torch.from_numpy(ests).to(dev), flen)
+    for b in range(B):
+        o = OB.bss_eval_sources(s[b], ests[b], flen)
+        for got, ref, name in zip((sdr, sir, sar), o, ("sdr", "sir", "sar")):
+            for j in range(S):
+                if np.isfinite(ref[j]) and ref[j] < 100:
+                    assert abs(got[b, j].item() - ref[j]) < 1e-3, (name, b, j, got[b, j].item(), ref[j])
+    # the pieces: correlations and one solved system
+    K = P.kernels
+    R = torch.empty((B, S, S, 2 * flen - 1), dtype=torch.float64, device=dev)
+    D = torch.empty((B, S, S, flen), dtype=torch.float64, device=dev)
+    rt, et = torch.from_numpy(s).to(dev), torch.from_numpy(ests).to(dev)
+    P.lib.call("avsep_bss_corr", K.ptr(rt), K.ptr(et), B, S, S, L, flen, K.ptr(R), K.ptr(D))
+    i, j, e = 0, S - 1, S - 1
+    full = np.correlate(s[0, i], s[0, j], "full")                         # full[L - 1 + tau] = sum_t a[t + tau] * b[t]
+    assert_close(R[0, i, j], torch.from_numpy(full[L - 1 - (flen - 1):L - 1 + flen].copy()), 1e-11, "lagged correlations")
+    fe = np.correlate(ests[0, e], s[0, i], "full")                        # fe[L - 1 + k] = sum_t est[t + k] * ref[t] = sum_t ref[t - k] est[t]
+    assert_close(D[0, e, i], torch.from_numpy(fe[L - 1:L - 1 + flen].copy()), 1e-11, "right-hand sides")
+    C = PB._solve(R, D, B, S, S, flen, 0)
+    G = PB._gram(R, 0, list(range(S)), flen).cpu().numpy()
+    rhs = D[0].reshape(S, S * flen).t().cpu().numpy()
+    assert_close(C[0], torch.from_numpy(np.linalg.solve(G, rhs)), 1e-6, "filters vs numpy.linalg.solve on the same Gram matrix")
+
+
+def test_bss_eval_silent_source_takes_the_least_squares_fallback(dev):
+    """A silent reference makes the Gram matrix exactly singular: mir_eval catches numpy's LinAlgError and solves by least
+    squares; the solve kernel reports the zero pivot (info) and the host side does the same for that system only."""
+    from oracle import bss_eval as OB
+    from avsep_amd import bss_eval as PB
+    rs = np.random.RandomState(5)
+    L = 4000
+    s = rs.randn(2, 2, L)
+    s[1, 1] = 0.0                                                          # sample 1: source 1 is silent
+    ests = s + 0.1 * rs.randn(2, 2, L)
+    sdr, sir, sar = PB.bss_eval_sources(torch.from_numpy(s).to(dev), torch.from_numpy(ests).to(dev))
+    for b in range(2):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            o = OB.bss_eval_sources(s[b], ests[b])
+        for got, ref in zip((sdr, sir, sar), o):
+            for j in range(2):
+                if np.isfinite(ref[j]) and abs(ref[j]) < 100:
+                    assert abs(got[b, j].item() - ref[j]) < 1e-3, (b, j, got[b, j].item(), ref[j])
+
+
 @pytest.mark.parametrize("att", ["sig", "cos"])
 @pytest.mark.parametrize("B,S,K,H,W", [(3, 2, 32, 14, 28), (2, 3, 8, 5, 7), (1, 4, 128, 20, 40),
                                        (1, 4, 128, 64, 64)])     # the limit shape of the ABI: 67 KB / 151 KB of dynamic LDS
