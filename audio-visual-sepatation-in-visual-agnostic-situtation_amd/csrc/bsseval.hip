@@ -148,8 +148,16 @@ __global__ __launch_bounds__(1024) void bss_solve_kernel(const double* __restric
       if (r > k) {
         const double l = A[(long long)k * M + r] * inv;
         A[(long long)k * M + r] = l;
-#pragma unroll 4
-        for (int c = k + 1; c < M; ++c) A[(long long)c * M + r] = fma(-l, rowk[c], A[(long long)c * M + r]);
+        // the sweep is latency-bound (an 8 MB matrix per system, one row element per column): 16 independent loads in flight
+        int c = k + 1;
+        for (; c + 16 <= M; c += 16) {
+          double v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = A[(long long)(c + u) * M + r];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) A[(long long)(c + u) * M + r] = fma(-l, rowk[c + u], v[u]);
+        }
+        for (; c < M; ++c) A[(long long)c * M + r] = fma(-l, rowk[c], A[(long long)c * M + r]);
         for (int q = 0; q < nrhs; ++q) x[q * M + r] = fma(-l, x[q * M + k], x[q * M + r]);
       }
     __syncthreads();
