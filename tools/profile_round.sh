@@ -29,3 +29,11 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/ck/w
 python profiles/summarise_pmc.py gpurun_out/ck/f5 gpurun_out/ck/w5 "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --config 5 --steps 2 --warmup 1 $FLAGS --precision $P" 3 32 gpurun_out/ck/pmc_${P}_config5.json > gpurun_out/ck/pmc_config5.log
 rm -rf gpurun_out/ck/f5 gpurun_out/ck/w5
 echo done config5
+# the step as shipped (independent passes on forked streams): a kernel trace for the record — per-kernel durations are NOT exclusive here
+export AVSEP_FORK_SOURCES=1 AVSEP_FORK_PAIR=1
+for P in f32 bf16; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ck/trf_$P -- python3 bench.py --steps 3 --warmup 1 $FLAGS --precision $P > gpurun_out/ck/trf_$P.log 2>&1
+  python profiles/summarise_trace.py gpurun_out/ck/trf_$P "python3 bench.py --steps 3 --warmup 1 $FLAGS --precision $P (the step as shipped: passes on forked streams; kernels of different streams overlap, durations are not exclusive)" > gpurun_out/ck/${TAG}_bench_kernel_stats_${P}_forked.txt
+  rm -rf gpurun_out/ck/trf_$P
+done
+echo done forked
