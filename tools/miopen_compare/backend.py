@@ -291,5 +291,5 @@ def install(net, backend):
         raise ValueError(backend)
     net.backend = backend
     # note: the package's FlatSGD keeps conv weights OIHW; MIOpen's NHWC kernels re-lay them out per call (round 3 kept
-    # them OHWI inside the flat buffers for this comparison: 533 mixtures/s at batch 64; without it expect a few % less)
+    # them OHWI inside the flat buffers for this comparison: 533 mixtures/s at batch 64; round 4 measures 531 without it)
     return net
