@@ -255,6 +255,7 @@ class FlatSGD:
         self._scratch = None
         self._node_events = []
         self._end_queued, self._at_end = False, []
+        self._caller_stream = None
         self.param_groups = []
         params = []
         for g in groups:
@@ -379,11 +380,21 @@ class FlatSGD:
         self._queue_end_of_backward()
 
     def _end_of_backward(self):
+        # The engine may run this on one of its worker threads, whose current stream is that thread's default: the stream to
+        # order is the CALLER's — the one zero_grad() ran on at the start of the step.
         self._end_queued = False
-        self._wait_for_nodes()
-        fns, self._at_end = self._at_end, []
-        for fn in fns:
-            fn()
+        caller = self._caller_stream
+        if caller is None or not self.flat_grad.is_cuda:
+            self._wait_for_nodes()
+            fns, self._at_end = self._at_end, []
+            for fn in fns:
+                fn()
+            return
+        with torch.cuda.stream(caller):
+            self._wait_for_nodes()
+            fns, self._at_end = self._at_end, []
+            for fn in fns:
+                fn()
 
     def _on_first_group_grad(self, p):
         """Fires once per parameter of the first group after autograd accumulated into its flat view."""
@@ -413,6 +424,7 @@ class FlatSGD:
         self._returned.clear()
         self._node_events = []
         self._end_queued, self._at_end = False, []       # (a backward pass that raised never ran its final callback)
+        self._caller_stream = torch.cuda.current_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None
         self._early, self._armed, self._nodes_left = None, False, 0     # disarmed until arm_early_reduce()
         self._pending = set()
 

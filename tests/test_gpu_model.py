@@ -1399,6 +1399,19 @@ def test_trunk_passes_on_forked_streams_equal_back_to_back(dev, nsrc, prec):
             assert (len(wrap.__dict__.get("_src_streams", [])) == nsrc) == fork      # one stream per source (issued before the STFT)
             res[fork] = (losses, {k: v.detach().double().cpu() for k, v in list(snd.state_dict().items()) + list(frm.state_dict().items())},
                          opt.flat_buf.detach().double().cpu())
+            if fork:
+                # a caller on a stream of its own: the end-of-backward ordering goes to THAT stream (the engine runs the callback
+                # on a worker thread whose current stream is the default one)
+                mine = torch.cuda.Stream()
+                mine.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(mine):
+                    opt.zero_grad()
+                    with K.pack_scope():
+                        e2, _ = wrap.forward(b, args, True)
+                        e2.mean().backward()
+                    g_now = opt.flat_grad.clone()
+                torch.cuda.synchronize()
+                assert torch.equal(g_now, opt.flat_grad), "gradient read on the caller's stream right after backward()"
     finally:
         K.set_precision("f32")
     tol = 1e-6 if prec == "f32" else 2e-3       # bf16: a last-bit difference of a statistic can flip a bf16 rounding downstream
