@@ -384,7 +384,8 @@ int avsep_b16_affine_act_bwd(const void* dz, const void* dz2, const void* y, con
 /* out = p*dz + q*y + r with pqr[3*C] from avsep_bn_bwd_coeffs (out may alias dz) */
 int avsep_b16_bn_bwd_apply(const void* dz, const void* y, const float* pqr, int32_t N, int32_t C, int32_t HW, void* out,
                            avsep_stream_t stream);
-/* Grid image of a batch of small maps (B16 out [1][C/16][HG][WG][16]): image n of x (fp32 NCHW or B16, `xfmt`) goes to rows
+/* Grid image of a batch of small maps — the 2x2 ... 8x8 maps of the deep U-Net levels, models/audio_net.py:64-69,75-76 —
+ * (B16 out [1][C/16][HG][WG][16]): image n of x (fp32 NCHW or B16, `xfmt`) goes to rows
  * (n / GX) * PY .., columns (n % GX) * PX .. after the folded affine (scale / shift per channel, or NULL) and activation `act`
  * (AVSEP_ACT_NONE / RELU / LRELU02); every other position is zero.  HG = rows (a multiple of PY), WG = GX * PX.  With pitch
  * H + 1 (3x3 / pad 1; X and dY) or H + 2 for X and H/2 + 1 for dY (4x4 / stride 2 / pad 1) the separators are every image's zero
