@@ -39,13 +39,10 @@ __global__ void c3_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // conv_flat.hip: flat-pixel tiles for the small square maps of the visual trunk
 int c3_flat_width(int H, int W, int dil);
 int c3_flat_launch(C3Args& a, int dil, hipStream_t st);
-static bool c3_flat_enabled() {
-  static const bool on = getenv("AVSEP_NO_FLAT") == nullptr;      // read once per process, like every AVSEP_* switch
-  return on;
-}
+static bool c3_flat_enabled(int algo) { return !(algo & AVSEP_ALGO_NO_FLAT); }
 static bool c3_flat(const avsep_conv_desc* d) {
   return !d->up2x && d->C0 == d->Cin && c3_flat_width(d->H, d->W, d->dil) > 0 && (long long)d->N * d->H * d->W < 0x7fffffffLL &&
-         c3_flat_enabled();
+         c3_flat_enabled(d->algo);
 }
 
 bool c3_applicable(const avsep_conv_desc* d, int mode) {
@@ -69,7 +66,7 @@ int c3_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
 
 static int c3_launch(C3Args& a, hipStream_t st, int dil = 1) {
   a.Ho = a.H; a.Wo = a.W; a.padh = a.padw = dil; a.os = 1; a.ooh = a.oow = 0; a.OHs = a.H; a.OWs = a.W;
-  if (!a.up2x && a.C1 == 0 && c3_flat_width(a.H, a.W, dil) > 0 && c3_flat_enabled())
+  if (!a.up2x && a.C1 == 0 && c3_flat_width(a.H, a.W, dil) > 0 && c3_flat_enabled(a.algo))
     return c3_flat_launch(a, dil, st);
   const bool wide = a.W >= 32;
   a.tilesX = cdiv(a.W, wide ? 32 : 16);
@@ -108,7 +105,7 @@ void c3_variant_text(int M, int Ho, int Wo, long long planN, bool flat, bool qua
   snprintf(buf, cap, "%s,BM%d", wide ? "4x32" : "8x16", c3_narrow_rule(M, wg128, quantise) ? 64 : 128);
 }
 void c3_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
-  const bool flat = !d->up2x && d->C0 == d->Cin && c3_flat_width(d->H, d->W, d->dil) > 0 && c3_flat_enabled();
+  const bool flat = !d->up2x && d->C0 == d->Cin && c3_flat_width(d->H, d->W, d->dil) > 0 && c3_flat_enabled(d->algo);
   c3_variant_text(mode == 0 ? d->Cout : d->Cin, d->H, d->W, plan_batch(d), flat, true, buf, cap);
 }
 void c4_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
@@ -118,7 +115,7 @@ void c4_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
 
 int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st) {
   C3Args a{};
-  a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.N = d->N; a.planN = d->plan_n; a.algo = d->algo; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = d->up2x;
   a.Hs = d->up2x ? d->H / 2 : d->H; a.Ws = d->up2x ? d->W / 2 : d->W;
   a.rh = (d->up2x && d->H > 1) ? (float)(a.Hs - 1) / (float)(d->H - 1) : 0.f;
@@ -131,7 +128,7 @@ int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
 // dX[N,Cin,H,W] = conv3x3(dY[N,Cout,H,W], flipped/transposed weights)
 int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st) {
   C3Args a{};
-  a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
+  a.N = d->N; a.planN = d->plan_n; a.algo = d->algo; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
   a.C0 = d->Cout; a.C1 = 0; a.Hs = d->H; a.Ws = d->W;
   a.x0 = dy; a.wp = wp; a.wp_ld = roundup(d->Cin, 128); a.out = dx;
   return c3_launch(a, st, d->dil);      // the flipped-weight identity holds for any dilation with pad == dil
@@ -206,7 +203,7 @@ static int c4_launch(C3Args& a, hipStream_t st) {
 
 int c4_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* y, double* stats, hipStream_t st) {
   C3Args a{};
-  a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.N = d->N; a.planN = d->plan_n; a.algo = d->algo; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.act0 = d->act0; a.act1 = d->act1; a.up2x = 0;
   a.Hs = d->H; a.Ws = d->W;
   a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
@@ -221,7 +218,7 @@ int c4_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* 
   for (int cls = 0; cls < 4; ++cls) {
     const int ph = cls >> 1, pw = cls & 1;
     C3Args a{};
-    a.N = d->N; a.planN = d->plan_n; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
+    a.N = d->N; a.planN = d->plan_n; a.algo = d->algo; a.Cin = d->Cout; a.H = d->Ho; a.W = d->Wo; a.Cout = d->Cin;     // the conv runs over dY
     a.C0 = d->Cout; a.C1 = 0; a.Hs = d->Ho; a.Ws = d->Wo;
     a.x0 = dy; a.wp = wp + (size_t)cls * d->Cout * 4 * ld; a.wp_ld = ld; a.out = dx;
     a.Ho = d->H / 2; a.Wo = d->W / 2; a.padh = ph ? 0 : 1; a.padw = pw ? 0 : 1;

@@ -66,11 +66,7 @@ __global__ void bf_pack_kernel(const float* __restrict__ w, unsigned* __restrict
   reinterpret_cast<u32x4*>(out)[i] = o;
 }
 
-// read once per process (like every AVSEP_* switch): the packed-weight layout and the launch can never disagree
-static inline bool bf_enabled() {
-  static const bool on = getenv("AVSEP_NO_BF16_KERNELS") == nullptr;
-  return on;
-}
+static inline bool bf_enabled(const avsep_conv_desc* d) { return !(d->algo & AVSEP_ALGO_NO_BF16_KERNELS); }
 
 // geometry classes served by convbf_kernel; mode 0 forward, 1 data gradient
 static int bf_class(const avsep_conv_desc* d) {
@@ -127,7 +123,7 @@ static long long bf_flat_wgs(int M, long long P) {
 
 size_t bf_workspace_bytes(const avsep_conv_desc* d, int mode);
 bool bf_applicable(const avsep_conv_desc* d, int mode) {
-  if (d->prec != AVSEP_PREC_BF16 || !bf_enabled()) return false;
+  if (d->prec != AVSEP_PREC_BF16 || !bf_enabled(d)) return false;
   const int cls = bf_class(d);
   if (!cls) return false;
   const int kc = mode == 0 ? d->Cin : d->Cout, m = mode == 0 ? d->Cout : d->Cin;

@@ -10,10 +10,7 @@
 
 #include "halo_kernel.h"
 
-static inline bool cm_enabled() {
-  static const bool on = getenv("AVSEP_NO_MISC_PATCH") == nullptr;      // read once per process
-  return on;
-}
+static inline bool cm_enabled(const avsep_conv_desc* d) { return !(d->algo & AVSEP_ALGO_NO_MISC_PATCH); }
 static int cm_class(const avsep_conv_desc* d) {
   if (d->up2x || d->dil != 1) return 0;
   if (d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1) return 5;
@@ -23,7 +20,7 @@ static int cm_class(const avsep_conv_desc* d) {
 }
 bool cm_applicable(const avsep_conv_desc* d, int mode) {
   const int cls = cm_class(d);
-  if (!cls || !cm_enabled() || d->N > 65535 || d->Wo < 12 || d->Ho < 4) return false;
+  if (!cls || !cm_enabled(d) || d->N > 65535 || d->Wo < 12 || d->Ho < 4) return false;
   if (cls == 6 && mode != 0) return false;
   if (mode == 0) {
     if (cls == 5 || cls == 6) return d->Cin % 2 == 0 && d->C0 % 2 == 0 && d->Cout >= 32;

@@ -391,9 +391,8 @@ struct WnCfg { int gh, gw, g; };     // pixels per group, groups per workgroup
 static const WnCfg WN_CFGS[4] = {{16, 16, 1}, {4, 32, 2}, {8, 8, 4}, {2, 16, 8}};
 
 // the group shape that wastes the fewest tiles on an Hq x Wq map (ties: the shape with the smaller halo overhead)
-static int wn_cfg(int Hq, int Wq) {
-  static const char* force = getenv("AVSEP_WINO_CFG");      // tuning / debugging: force one group shape (0..3)
-  if (force && force[0] >= '0' && force[0] <= '3') return force[0] - '0';
+static int wn_cfg(int Hq, int Wq, int tune) {
+  if ((tune & 15) >= 1 && (tune & 15) <= 4) return (tune & 15) - 1;      // avsep_conv_desc.tune: measurement tools force a group shape
   int best = 0;
   double be = 0.0;
   for (int c = 0; c < 4; ++c) {
@@ -410,7 +409,7 @@ static WnPlan wn_plan(const avsep_conv_desc* d, int mode) {
   const bool sub = d->dil == 2;
   p.Hq = sub ? (d->H + 1) / 2 : d->H;
   p.Wq = sub ? (d->W + 1) / 2 : d->W;
-  p.cfg = wn_cfg(p.Hq, p.Wq);
+  p.cfg = wn_cfg(p.Hq, p.Wq, d->tune);
   const WnCfg& k = WN_CFGS[p.cfg];
   p.gyn = cdiv(p.Hq, k.gh);
   p.gxn = cdiv(p.Wq, k.gw);
@@ -421,8 +420,7 @@ static WnPlan wn_plan(const avsep_conv_desc* d, int mode) {
 }
 
 bool wn_applicable(const avsep_conv_desc* d, int mode) {
-  static const bool off = getenv("AVSEP_NO_WINOGRAD") != nullptr;
-  if (off || d->prec != AVSEP_PREC_F32) return false;
+  if ((d->algo & AVSEP_ALGO_NO_WINOGRAD) || d->prec != AVSEP_PREC_F32) return false;
   if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil) || d->up2x) return false;
   if ((d->H & 1) || (d->W & 1) || d->H < (d->dil == 1 ? 8 : 14) || d->W < (d->dil == 1 ? 8 : 14)) return false;   // float2 stores; tiny maps stay on split-K
   const int cin = mode == 0 ? d->Cin : d->Cout, cout = mode == 0 ? d->Cout : d->Cin;

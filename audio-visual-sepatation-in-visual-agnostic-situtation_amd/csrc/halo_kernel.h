@@ -23,6 +23,7 @@ struct C3Args {
   int kts;
   long long slab;
   int planN;             // host only: batch the tile-size heuristics are planned for (avsep_conv_desc.plan_n; 0 = N)
+  int algo;              // host only: avsep_conv_desc.algo
   int out16;             // bf16 kernels: `out` is a B16 image ([N][Cout/16][OHs][OWs][16] bf16) instead of fp32 NCHW
 };
 static inline long long c3_plan_n(const C3Args& a) { return a.planN > 0 ? a.planN : a.N; }

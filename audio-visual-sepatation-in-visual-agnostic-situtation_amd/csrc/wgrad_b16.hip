@@ -366,12 +366,9 @@ static int wbn_class(const avsep_conv_desc* d) {
     return 7;                                              // the stem over space-to-depth frames (raw input)
   return 0;
 }
-static inline bool wbn_enabled() {
-  static const bool on = getenv("AVSEP_NO_BF16_KERNELS") == nullptr;
-  return on;
-}
+static inline bool wbn_enabled(const avsep_conv_desc* d) { return !(d->algo & AVSEP_ALGO_NO_BF16_KERNELS); }
 bool wbn_applicable(const avsep_conv_desc* d) {
-  if (!wbn_enabled() || !wbn_class(d)) return false;
+  if (!wbn_enabled(d) || !wbn_class(d)) return false;
   if (d->Cin % 16 || d->Cout % 16 || d->Cin < 16 || d->Cout < 16) return false;
   if (d->Wo < 8 || d->Ho < 4 || d->N > 65535) return false;
   if (wbn_class(d) == 7 && d->Wo <= 16) return false;          // the Cin == 16 form has the 8 x 32 chunk only

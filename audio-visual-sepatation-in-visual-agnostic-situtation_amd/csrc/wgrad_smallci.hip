@@ -161,8 +161,7 @@ static int scw_slabs(const avsep_conv_desc* d) {
   return (int)(tiles < want ? tiles : (want < 1 ? 1 : want));
 }
 bool scw_applicable(const avsep_conv_desc* d) {
-  static const bool off = getenv("AVSEP_NO_SMALLCI_WGRAD") != nullptr;
-  if (off || !scw_class(d)) return false;
+  if ((d->algo & AVSEP_ALGO_NO_SMALLCI_WGRAD) || !scw_class(d)) return false;
   if ((d->W & 3) || (d->Wo & 3) || d->Wo < 8 || d->Wo > 128 || d->W > 256) return false;      // register-staged rows: ND / NX pieces per thread
   if ((long long)d->N * d->Ho > 0x7fffffffLL || d->Cout > 65535 * 64) return false;
   return scw_smem(d) <= 72 * 1024;                                 // two workgroups per CU

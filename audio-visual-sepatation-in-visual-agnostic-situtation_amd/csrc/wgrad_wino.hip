@@ -586,9 +586,9 @@ int w3_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t s
 
 struct WwCfg { int gh, gw, g; };     // pixels per group, groups per chunk
 static const WwCfg WW_CFGS[4] = {{4, 16, 1}, {8, 8, 1}, {2, 16, 2}, {4, 8, 1}};     // [3]: dilation 2 (4x8 sub-pixels x both column parities)
-static int ww_cfg(int Hq, int Wq) {
-  static const char* force = getenv("AVSEP_WINOW_CFG");
-  if (force && force[0] >= '0' && force[0] <= '2') return force[0] - '0';
+static int ww_cfg(int Hq, int Wq, int tune) {
+  const int force = (tune >> 4) & 15;                   // avsep_conv_desc.tune: measurement tools force a group shape
+  if (force >= 1 && force <= 3) return force - 1;
   int best = 0;
   double be = 0.0;
   for (int c = 0; c < 3; ++c) {
@@ -604,7 +604,7 @@ static WwPlan ww_plan(const avsep_conv_desc* d) {
   const bool sub = d->dil == 2;
   p.Hq = sub ? (d->H + 1) / 2 : d->H;
   p.Wq = sub ? (d->W + 1) / 2 : d->W;
-  p.cfg = sub ? 3 : ww_cfg(p.Hq, p.Wq);
+  p.cfg = sub ? 3 : ww_cfg(p.Hq, p.Wq, d->tune);
   const WwCfg& k = WW_CFGS[p.cfg];
   p.gyn = cdiv(p.Hq, k.gh);
   p.gxn = cdiv(p.Wq, k.gw);
@@ -616,8 +616,8 @@ static WwPlan ww_plan(const avsep_conv_desc* d) {
   // of workgroups is the fastest plan at every layer shape of the step (measured 256 / 384 / 512 / 768 / 1024 / 1536
   // workgroups: 186 / 144 / 186 / 182 / 180 / 173 TFLOP/s at 1024 -> 256 @ 32x32, 121 / 91 / 101 / 83 / 71 / 63 at
   // 64 -> 64 @ 56x56) — fewer epilogues and slabs, no partial last round
-  static const char* tw = getenv("AVSEP_WINOW_WGS");      // tuning: target workgroup count
-  int want = (tw ? atoi(tw) : cu_count()) / (p.gridM * p.gridC);
+  const int tw = (d->tune >> 8) & 0xffff;                 // avsep_conv_desc.tune: measurement tools set the target workgroup count
+  int want = (tw ? tw : cu_count()) / (p.gridM * p.gridC);
   const int maxs = p.nchunks / 8 > 0 ? p.nchunks / 8 : 1;    // at least 8 chunks per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -628,7 +628,7 @@ static WwPlan ww_plan(const avsep_conv_desc* d) {
 }
 
 bool ww_applicable(const avsep_conv_desc* d) {
-  static const bool off = getenv("AVSEP_NO_WINOGRAD") != nullptr || getenv("AVSEP_NO_WINOGRAD_WGRAD") != nullptr;
+  const bool off = (d->algo & (AVSEP_ALGO_NO_WINOGRAD | AVSEP_ALGO_NO_WINOGRAD_WGRAD)) != 0;
   if (off || d->prec != AVSEP_PREC_F32) return false;
   if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil) || d->up2x) return false;
   if ((d->H & 1) || (d->W & 1) || d->H < (d->dil == 1 ? 8 : 14) || d->W < (d->dil == 1 ? 8 : 14)) return false;
@@ -705,7 +705,7 @@ static WwPlan w4d_plan(const avsep_conv_desc* d) {
   return ww_plan(&e);
 }
 bool w4d_applicable(const avsep_conv_desc* d) {
-  static const bool off = getenv("AVSEP_NO_WINOGRAD") != nullptr || getenv("AVSEP_NO_WINOGRAD_WGRAD") != nullptr;
+  const bool off = (d->algo & (AVSEP_ALGO_NO_WINOGRAD | AVSEP_ALGO_NO_WINOGRAD_WGRAD)) != 0;
   // (bf16 descriptors too: conv.hip asks the bf16 kernel first, and the maps it does not take — 8 / 4 wide at the deep
   // U-Net levels — are better off here in fp32 than on the im2col kernel: 0.31 against 0.60 ms at 512 -> 512 @ 16x16)
   if (off) return false;

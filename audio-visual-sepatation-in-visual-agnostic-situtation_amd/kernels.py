@@ -154,6 +154,34 @@ def get_precision():
     return "bf16" if _precision else "f32"
 
 
+# Kernel families the convolutions must NOT use (avsep_conv_desc.algo, a bit set of lib.ALGO_NO values): A/B runs and the
+# gradient-error attribution (tools/grad_attribution.py).  The library itself reads no environment variable; this host
+# layer takes the initial mask from AVSEP_ALGO_NO="winograd,flat,..." (or the older per-family AVSEP_NO_<FAMILY>=1 names) once,
+# at import, and every descriptor built afterwards carries the module's current mask.
+def _algo_from_env():
+    mask = 0
+    for name in os.environ.get("AVSEP_ALGO_NO", "").replace(" ", "").split(","):
+        if name:
+            mask |= lib.ALGO_NO[name.lower()]
+    for name, bit in lib.ALGO_NO.items():
+        if os.environ.get("AVSEP_NO_" + name.upper()) is not None:
+            mask |= bit
+    return mask
+
+
+algo_mask = _algo_from_env()
+conv_tune = 0      # avsep_conv_desc.tune (tools/conv_bench.py only)
+
+
+def set_algo_mask(*names):
+    """set_algo_mask("winograd", ...) — forbid those kernel families from now on; set_algo_mask() clears the mask."""
+    global algo_mask
+    algo_mask = 0
+    for n in names:
+        algo_mask |= lib.ALGO_NO[n]
+    return algo_mask
+
+
 # Batch the launch heuristics are planned for, as a multiple of the real batch (avsep_conv_desc.plan_n): the parity tests
 # set 8 so that a batch-8 step takes, layer by layer, the kernel instantiations of the batch-64 step bench.py times.
 plan_batch_scale = 1
@@ -206,6 +234,7 @@ class Conv:
         d.C0, d.act0, d.act1, d.up2x = C0, act0, act1, int(up2x)
         d.prec = _precision if prec is None else PREC_BY_NAME[prec]
         d.plan_n = N * plan_batch_scale if plan_batch_scale != 1 else 0
+        d.algo, d.tune = algo_mask, conv_tune
         d.x0, d.x1 = ptr(x0), ptr(x1)
         d.xfmt = fmt_of(x0)
         d.scale0, d.shift0, d.scale1, d.shift1 = ptr(sc0), ptr(sh0), ptr(sc1), ptr(sh1)
@@ -244,7 +273,7 @@ class Conv:
         key = None
         if _pack_cache is not None:
             key = (w.data_ptr(), w._version, mode, d.N, d.Cin, d.H, d.W, d.Cout, d.KH, d.KW, d.stride, d.pad, d.dil, d.C0, d.up2x, d.prec,
-                   d.plan_n, bool(d.scale0), bool(d.scale1), d.act0, d.act1)
+                   d.plan_n, bool(d.scale0), bool(d.scale1), d.act0, d.act1, d.algo, d.tune)
             hit = _pack_cache.get(key)
             if hit is not None:
                 if hit[2] is not None and torch.cuda.current_stream() != hit[3]:

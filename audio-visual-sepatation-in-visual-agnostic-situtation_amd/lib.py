@@ -16,6 +16,8 @@ ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SIGMOID, ACT_TANH, ACT_SOFTMAX2 = range(6)
 ACT_BY_NAME = {"no": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH,
                "softmax": ACT_SOFTMAX2}
 LOSS_BY_NAME = {"bce": 0, "l1": 1, "l2": 2}
+# avsep_conv_desc.algo: kernel families a call must not use (include/avsep.h AVSEP_ALGO_NO_*)
+ALGO_NO = {"winograd": 1, "winograd_wgrad": 2, "flat": 4, "misc_patch": 8, "bf16_kernels": 16, "smallci_wgrad": 32, "winograd4": 64}
 
 
 class AvsepError(RuntimeError):
@@ -24,7 +26,7 @@ class AvsepError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                "N Cin H W Cout Ho Wo KH KW stride pad dil C0 act0 act1 up2x prec plan_n xfmt yfmt dyfmt dxfmt".split()] + \
+                "N Cin H W Cout Ho Wo KH KW stride pad dil C0 act0 act1 up2x prec plan_n xfmt yfmt dyfmt dxfmt algo tune".split()] + \
                [(n, C.c_void_p) for n in "x0 x1 scale0 shift0 scale1 shift1".split()]
 
 

@@ -195,9 +195,15 @@ class NetWrapper(torch.nn.Module):
 
     # ------------------------------------------------------------------ main.py:150-160
     def forward(self, batch_data, args, use_vis, is_share=False):
+        sink = getattr(self.net_sound, "_grad_sink", None)
+        if sink is not None and torch.is_grad_enabled():
+            sink.note_caller_stream()          # the stream a following .backward() is ordered on (FlatSGD._end_of_backward)
         early = None
+        # Under HIP-graph capture source 0 stays on the capturing stream (early=False): with EVERY trunk pass on a side stream
+        # hipStreamEndCapture crashed on ROCm 7.0; the topology below is the one that captures and replays.
+        capturing = batch_data["frames"][0].is_cuda and torch.cuda.is_current_stream_capturing() if use_vis else False
         if use_vis and args.fusion_type != "MixVis" and self.fork_sources and self.early_trunk and args.num_mix > 1 and \
-                batch_data["frames"][0].is_cuda:
+                batch_data["frames"][0].is_cuda and not capturing:
             # the visual trunk does not read the spectrograms: issue its passes first, on their streams
             early = self._frame_features(batch_data["frames"], args.num_mix, args, early=True)
         if "mag_mix" not in batch_data:
@@ -277,9 +283,11 @@ class FlatSGD:
         self.flat_buf = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
         self._views = []
-        for g in self.param_groups:
+        self._group_of = {}
+        for gi, g in enumerate(self.param_groups):
             g["range"] = [off, off]
             for p in g["params"]:
+                self._group_of[p] = gi
                 n = p.numel()
                 self.flat_param[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[off:off + n].view_as(p.data)
@@ -312,19 +320,23 @@ class FlatSGD:
         gv = self._slot.get(p)
         if gv is None or p not in self._written or p.grad is None or p.grad.data_ptr() != gv.data_ptr():
             return None
-        sc = self._scratch_of_current_stream(create=True)
-        off = gv.storage_offset()
+        gi = self._group_of[p]
+        sc = self._scratch_of_current_stream(gi, create=True)
+        off = gv.storage_offset() - self.param_groups[gi]["range"][0]
         return sc[off:off + gv.numel()].view_as(gv)
 
-    def _scratch_of_current_stream(self, create=False):
-        """One scratch buffer per stream: nodes that run on different streams (the visual trunk's passes, fork_streams) must
-        not overwrite one another's not yet folded contributions."""
+    def _scratch_of_current_stream(self, gi, create=False):
+        """One scratch buffer per (stream, parameter group), covering that group's flat range only: nodes that run on different
+        streams (the visual trunk's passes, fork_streams) must not overwrite one another's not yet folded contributions, and
+        a stream only ever holds second contributions of the network its nodes belong to (a trunk stream never needs the
+        U-Net's 130 MB)."""
         if self._scratch is None:
             self._scratch = {}
-        key = torch.cuda.current_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None
+        key = (torch.cuda.current_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None, gi)
         sc = self._scratch.get(key)
         if sc is None and create:
-            sc = self._scratch[key] = torch.zeros_like(self.flat_grad)
+            a, b = self.param_groups[gi]["range"]
+            sc = self._scratch[key] = torch.zeros(b - a, dtype=self.flat_grad.dtype, device=self.flat_grad.device)
         return sc
 
     def _wait_for_nodes(self):
@@ -347,9 +359,16 @@ class FlatSGD:
             else:
                 runs.append([off, off + n])
         self._wait_for_nodes()                      # the first contributions (and earlier folds) may be on other streams
-        sc = self._scratch_of_current_stream()
         for a, b in runs:
-            self.flat_grad[a:b].add_(sc[a:b])
+            for gi, g in enumerate(self.param_groups):          # a run may span neighbouring groups
+                lo, hi = max(a, g["range"][0]), min(b, g["range"][1])
+                if lo >= hi:
+                    continue
+                sc = self._scratch_of_current_stream(gi)
+                if sc is None:
+                    raise lib.AvsepError("fold_scratch: the current stream holds no scratch contribution for parameter group "
+                                         f"'{g['name']}' (scratch_dest was never called on this stream for it)")
+                self.flat_grad[lo:hi].add_(sc[lo - g["range"][0]:hi - g["range"][0]])
 
     def node_finished(self, group, returned):
         """An autograd node of network `group` has run its backward; `returned` = the parameters whose gradient it handed
@@ -379,9 +398,15 @@ class FlatSGD:
         self._at_end.append(fn)
         self._queue_end_of_backward()
 
+    def note_caller_stream(self):
+        """Remember the stream the step is being issued on: called on the CALLER's thread by NetWrapper.forward (every forward
+        pass that can be followed by a backward pass) and by arm_early_reduce (between forward and backward) — not by
+        zero_grad(), which a caller may run on another stream or skip between two accumulated backward passes."""
+        self._caller_stream = torch.cuda.current_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None
+
     def _end_of_backward(self):
         # The engine may run this on one of its worker threads, whose current stream is that thread's default: the stream to
-        # order is the CALLER's — the one zero_grad() ran on at the start of the step.
+        # order is the CALLER's — the one the forward pass of this backward was issued on (note_caller_stream).
         self._end_queued = False
         caller = self._caller_stream
         if caller is None or not self.flat_grad.is_cuda:
@@ -424,7 +449,6 @@ class FlatSGD:
         self._returned.clear()
         self._node_events = []
         self._end_queued, self._at_end = False, []       # (a backward pass that raised never ran its final callback)
-        self._caller_stream = torch.cuda.current_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None
         self._early, self._armed, self._nodes_left = None, False, 0     # disarmed until arm_early_reduce()
         self._pending = set()
 
@@ -434,6 +458,7 @@ class FlatSGD:
         autograd has been accumulated (AccumulateGrad runs once per leaf and backward, then the post-accumulate hook);
         parameters whose gradient the kernels placed directly (grad_dest) and no node returned need no hook.  Nodes that
         do not report (plain torch modules): the hooks alone count, as before."""
+        self.note_caller_stream()
         if self._dist and self.overlap and accumulations > 0:
             self._armed = True
             self._pending = set(self.param_groups[0]["params"])

@@ -103,12 +103,15 @@ class KernelTimer:
             family = "head_dgrad_kernel" if name == "dgrad_up2x" else cv.kernel_name(mode, with_stats)
             flops = 2.0 * cv.N * cv.Ho * cv.Wo * cv.Cout * cv.Cin * cv.KH * cv.KW
             wts = cv.Cout * cv.Cin * cv.KH * cv.KW
+            # bytes per activation element: the bf16 kernels read and write B16 images (2 bytes); weights stay fp32 masters
+            # (the packed bf16 image is built from them once per step)
+            eb = 2.0 if family.startswith(("convbf", "wgradb")) else 4.0
             if family.startswith("head_"):
                 # the hi-res 128-channel input is never materialised: low-res sources (+ their gradients) and the logits
                 lo = cv.N * cv.Cin * cv.H * cv.W // 4
                 nbytes = 4.0 * ((2 * lo if mode == "dgrad" else lo) + cv.N * cv.Cout * cv.Ho * cv.Wo + wts)
             else:   # each of the three operands (input, output / cotangent, weights) touched once
-                nbytes = 4.0 * (cv.N * cv.Cin * cv.H * cv.W + cv.N * cv.Cout * cv.Ho * cv.Wo + wts)
+                nbytes = eb * (cv.N * cv.Cin * cv.H * cv.W + cv.N * cv.Cout * cv.Ho * cv.Wo) + 4.0 * wts
             layer = (cv.N, cv.Cin, cv.H, cv.W, cv.Cout, cv.KH, cv.d.stride, cv.d.pad, cv.d.dil, cv.d.up2x)
             return timer._time(orig, (cv,) + a, kw, family, mode, flops, nbytes, layer)
         setattr(self.K.Conv, name, wrapped)
@@ -124,7 +127,8 @@ class KernelTimer:
             hi = N * (C0 + C1) * 4 * H * W
             # forward: read the sources, write the hi-res tensor; backward: read its gradient (+ the sources for the
             # ReLU mask / BatchNorm sums), write the source gradients
-            nbytes = 4.0 * (src + hi) if name == "fwd" else 4.0 * (hi + 2 * src)
+            eb = 2.0 if timer.K.get_precision() == "bf16" else 4.0        # bf16 mode: B16 images on both sides
+            nbytes = eb * (src + hi) if name == "fwd" else eb * (hi + 2 * src)
             return timer._time(orig, (cat,) + a, kw, "relu_up2x_" + name, "glue", 0.0, nbytes)
         setattr(self.K.Cat, name, wrapped)
 
@@ -345,6 +349,78 @@ def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer
     return res
 
 
+def sdr_on_synthetic_val(P, dev, seed, steps=300, batch=16, val_batches=2, precisions=("f32", "bf16"), log=None):
+    """"SDR on val", the second half of BASELINE.json's metric, on synthetic sources (the MUSIC media are not
+    in the image), and the evidence that bf16 mode TRAINS: the full-size model (unet7 + hidsep(sig) + resnet18dilated, reference
+    initialisation, the shipped flags of scripts/train_MUSIC.sh) is trained from the same seed in fp32 and in bf16 mode for
+    `steps` train steps at batch `batch` on a seeded stream of fresh synthetic mixtures (synth.make_batch_on_device: harmonic
+    tones; a source's frames encode its f0), with the schedule the shipped flags produce (AV step on even iterations, audio-only
+    on odd ones: main.py:578-581), and evaluated before and after on a HELD-OUT seeded validation set with the reference's
+    evaluate() protocol (main.py:421-503: eval mode, AV and audio-only, loss + get_metrics' SI-SDR / SDR / SIR / SAR — here
+    evaluate.calc_metrics with the BSS-eval kernels).  Outside every timed region."""
+    import copy
+    from avsep_amd.train import av_ao_schedule
+    a0 = step_args(P)
+    val = [P.synth.make_batch_on_device(batch, a0.num_mix, a0.num_frames, 224, a0.audLen, seed=seed + 100000 + i, device=dev)
+           for i in range(val_batches)]
+
+    def evaluate(wrap, a):
+        out = {}
+        wrap.eval()
+        with torch.no_grad():
+            for use_vis in (True, False):
+                tot = torch.zeros(5, dtype=torch.float64, device=dev)
+                for vb in val:
+                    b = {"audios": list(vb["audios"]), "audio_mix": vb["audio_mix"], "frames": list(vb["frames"])}
+                    err, outputs = wrap.forward(b, a, use_vis)
+                    m = P.evaluate.calc_metrics(b, outputs, a, wrap.stft_plan, bss=True)
+                    tot += torch.stack([err.mean().double(), m["si_sdr_mean"].double(), m["sdr_mean"].double(),
+                                        m["sir_mean"].double(), m["sar_mean"].double()])
+                loss, si_sdr, sdr, sir, sar = (tot / len(val)).tolist()
+                out["val_av" if use_vis else "val_ao"] = {"loss": loss, "si_sdr": si_sdr, "sdr": sdr, "sir": sir, "sar": sar}
+        torch.set_grad_enabled(True)
+        return out
+
+    res = {"steps": steps, "batch": batch, "val_mixtures": batch * val_batches,
+           "data": "synthetic harmonic-tone mixtures, fresh seeded batch per step; held-out seeded validation set; frames encode f0",
+           "schedule": "AV on even iterations, audio-only on odd ones (iter_per_av 2, start_av_first, num_fsteps 0)"}
+    for prec in precisions:
+        P.kernels.set_precision(prec)
+        try:
+            a, snd, frm, wrap = build(P, dev, seed, "hip")
+            a = copy.copy(a)
+            opt = P.create_optimizer((snd, frm), a)
+            r = {"before": evaluate(wrap, a)}
+            curve = {"av": [], "ao": []}
+            errs = []
+            for i in range(steps):
+                use_vis = av_ao_schedule(i, a)
+                tb = P.synth.make_batch_on_device(batch, a.num_mix, a.num_frames, 224, a.audLen, seed=seed + 1 + i, device=dev)
+                b = {"audios": list(tb["audios"]), "audio_mix": tb["audio_mix"], "frames": list(tb["frames"])}
+                err, match, _ = P.net_wrapper.train_step_async(wrap, b, opt, use_vis, a)
+                errs.append((use_vis, err if match is None else err - a.match_weight * match))      # like main.py:718
+            window = max(2, steps // 10)
+            for use_vis, e in errs:
+                curve["av" if use_vis else "ao"].append(float(e))
+            for k, v in curve.items():
+                if v:
+                    w = min(window // 2 or 1, len(v))
+                    r["train_loss_" + k] = {"first": sum(v[:w]) / w, "last": sum(v[-w:]) / w, "window": w}
+            r["after"] = evaluate(wrap, a)
+            res[prec] = r
+            if log is not None:
+                log("sdr-on-synthetic-val %s: %s" % (prec, json.dumps(r)))
+            del wrap, opt, snd, frm
+            gc.collect()
+            torch.cuda.empty_cache()
+        finally:
+            P.kernels.set_precision("f32")
+    if "f32" in res and "bf16" in res:
+        f, b = res["f32"]["after"], res["bf16"]["after"]
+        res["bf16_minus_f32_after"] = {k: {m: b[k][m] - f[k][m] for m in ("loss", "si_sdr", "sdr")} for k in ("val_av", "val_ao")}
+    return res
+
+
 def config5_line(P, dev, world, seed, rank, o, timer):
     """BASELINE.json configs[4] on one GPU: 3-source mix, 5 frames per source, 512x256 tiles, batch 32 — the workload
     that stresses the fusion / mask head (C! = 6 permutations in the N-source fusion kernel, 15 frames per mixture
@@ -387,7 +463,7 @@ def roofline_of(kernels, prec, step_ms, B_total_per_gpu):
     dom = max(mfma, key=lambda k: mfma[k]["ms_per_step"])
     d = mfma[dom]
     # a kernel family computes in bf16 only if it is one of the bf16 kernels; the rest of a bf16 step is exact f32
-    peak = PEAK_TFLOPS["bf16"] if dom in ("convbf_kernel", "wgradbf_kernel", "wgrad4bf_kernel") else PEAK_TFLOPS["f32"]
+    peak = PEAK_TFLOPS["bf16"] if dom.startswith(("convbf", "wgradb")) else PEAK_TFLOPS["f32"]
     tot_fl = sum(v["gflop_per_step"] for v in kernels.values())
     tot_ms = sum(v["ms_per_step"] for k, v in kernels.items() if v["gflop_per_step"] > 0)
     # Winograd families execute 16 multiplies per 2x2 tile and channel pair where the direct form has 36: the MFMA roofline
@@ -431,6 +507,9 @@ def main():
     ap.add_argument("--rehearse", action="store_true", help="launcher / rendezvous / all-reduce rehearsal without a train step "
                     "(runs on CPU ranks over gloo too); prints a line marked \"rehearsal\": true")
     ap.add_argument("--rehearse-elems", type=int, default=0, help="elements of the rehearsal's flat buffer (default: the step's)")
+    ap.add_argument("--sdr-steps", type=int, default=300, help="train steps of the 'SDR on synthetic val' leg (extra.sdr_on_synthetic_val; "
+                    "fp32 and bf16 from the same seed, batch 16; 0 = skip)")
+    ap.add_argument("--sdr-only", action="store_true", help="run only the 'SDR on synthetic val' leg and print its JSON")
     ap.add_argument("--force-collective", action="store_true", help="--gpus 1 only: create a 1-rank RCCL group and issue the "
                     "step's early + late gradient all-reduce anyway; the line carries allreduce_ms and the no-collective time")
     o = ap.parse_args()
@@ -454,6 +533,10 @@ def main():
     seed, B = 1234, o.batch
     if o.config == 5:
         B = min(B, CONFIG5_BATCH)
+    if o.sdr_only:
+        print(json.dumps({"sdr_on_synthetic_val": sdr_on_synthetic_val(P, dev, seed, steps=o.sdr_steps,
+                                                                        log=lambda s: print(s, file=sys.stderr, flush=True))}))
+        return
     if o.force_collective:
         # RCCL readiness line (one GPU): the same step with and without the collectives of the N > 1 path
         plain = run_config(P, dev, world, seed, rank, o.precision, o.backend, B, o.steps, o.warmup, config=o.config)
@@ -515,6 +598,8 @@ def main():
         extras["av_ao_1to1_blend_mixtures_per_s"] = 2.0 / (1.0 / head["value"] + 1.0 / ao["value"])
         if o.config != 5:
             extras["config5"] = config5_line(P, dev, world, seed, rank, o, timer)
+        if o.sdr_steps > 0 and o.config != 5:
+            extras["sdr_on_synthetic_val"] = sdr_on_synthetic_val(P, dev, seed, steps=o.sdr_steps)
 
     if rank == 0:
         roof, roof_step, hbm = roofline_of(kernels, o.precision, head["ms_per_step"], B)

@@ -66,6 +66,15 @@ const char* avsep_strerror(int code);
  * (align_corners=True, audio_net.py:68-69) of that tensor; H,W are then the
  * UPSAMPLED sizes and the sources are [N,C,H/2,W/2].
  * ------------------------------------------------------------------------- */
+/* avsep_conv_desc.algo */
+#define AVSEP_ALGO_NO_WINOGRAD        1   /* 3x3/s1 forward + data gradient: direct form instead of Winograd F(2x2,3x3) / F(4x4,3x3) */
+#define AVSEP_ALGO_NO_WINOGRAD_WGRAD  2   /* weight gradients: direct form instead of the Winograd-domain kernels */
+#define AVSEP_ALGO_NO_FLAT            4   /* no flat-pixel tiles on the 14x14 / 7x7 maps */
+#define AVSEP_ALGO_NO_MISC_PATCH      8   /* 3x3/s2, 1x1, stem: im2col kernel instead of the halo-patch kernel */
+#define AVSEP_ALGO_NO_BF16_KERNELS   16   /* prec = bf16 ignored: every call runs its exact f32 kernel */
+#define AVSEP_ALGO_NO_SMALLCI_WGRAD  32   /* stem / first U-Net conv weight gradient on the im2col kernel */
+#define AVSEP_ALGO_NO_WINOGRAD4      64   /* Winograd layers stay on F(2x2,3x3): no F(4x4,3x3) kernel */
+
 typedef struct avsep_conv_desc {
   int32_t N, Cin, H, W;        /* virtual input  [N,Cin,H,W]   */
   int32_t Cout, Ho, Wo;        /* output         [N,Cout,Ho,Wo] */
@@ -84,6 +93,12 @@ typedef struct avsep_conv_desc {
   int32_t xfmt, yfmt;          /* AVSEP_FMT_* of x0 (forward / weight gradient) and of y as avsep_conv2d_fwd writes it */
   int32_t dyfmt, dxfmt;        /* AVSEP_FMT_* of dy (data / weight gradient) and of dx as avsep_conv2d_dgrad writes it.
                                   avsep_conv_io_formats tells which formats a call takes; B16 pointers are passed as float* */
+  int32_t algo;                /* bit set of AVSEP_ALGO_NO_*: kernel families this call must NOT use (0 = the library's choice).
+                                  This is the ONLY way to steer the dispatch: the library reads no environment variable and keeps
+                                  no process-wide switch, so pack / workspace / launch calls of one descriptor cannot disagree. */
+  int32_t tune;                /* measurement tools only (tools/conv_bench.py), 0 = the library's heuristics: bits 0-3 group shape
+                                  of the Winograd forward / data gradient + 1, bits 4-7 of the Winograd weight gradient + 1,
+                                  bits 8-23 target workgroup count of its K-split */
   const float* x0;
   const float* x1;
   const float* scale0;         /* [C0] or NULL */

@@ -1412,6 +1412,29 @@ def test_trunk_passes_on_forked_streams_equal_back_to_back(dev, nsrc, prec):
                     g_now = opt.flat_grad.clone()
                 torch.cuda.synchronize()
                 assert torch.equal(g_now, opt.flat_grad), "gradient read on the caller's stream right after backward()"
+                # The caller's stream is taken where the backward pass starts (NetWrapper.forward / arm_early_reduce), not in
+                # zero_grad(): zero_grad() issued on ANOTHER stream, then two ACCUMULATED backward passes on `mine` — the
+                # gradient read on `mine` right after the second backward() must be complete and equal twice the single one
+                other = torch.cuda.Stream()
+                other.wait_stream(mine)
+                with torch.cuda.stream(other):
+                    opt.zero_grad()
+                mine.wait_stream(other)
+                with torch.cuda.stream(mine):
+                    with K.pack_scope():
+                        for _ in range(2):
+                            e2, _ = wrap.forward(b, args, True)
+                            e2.mean().backward()
+                    g_twice = opt.flat_grad.clone()
+                torch.cuda.synchronize()
+                assert opt._caller_stream == mine
+                assert torch.equal(g_twice, opt.flat_grad), "gradient read right after the second accumulated backward()"
+                # (train-mode BatchNorm updates no parameter between the two passes: the second gradient equals the first)
+                assert_close(g_twice.double().cpu(), 2.0 * g_now.double().cpu(), 1e-5 if prec == "f32" else 2e-2,
+                             "two accumulated backward passes = twice the gradient")
+                with pytest.raises(P.lib.AvsepError):          # a fold on a stream that was never handed a scratch view
+                    with torch.cuda.stream(torch.cuda.Stream()):
+                        opt.fold_scratch([next(iter(frm.parameters()))])
     finally:
         K.set_precision("f32")
     tol = 1e-6 if prec == "f32" else 2e-3       # bf16: a last-bit difference of a statistic can flip a bf16 rounding downstream
@@ -1420,6 +1443,66 @@ def test_trunk_passes_on_forked_streams_equal_back_to_back(dev, nsrc, prec):
     for (k, v), (_, w) in zip(res[True][1].items(), res[False][1].items()):
         assert_close(v, w, tol, "forked vs one stream: " + k)
     assert_close(res[True][2], res[False][2], tol * 10, "momentum buffers")
+
+
+_CAPTURE_SCRIPT = r"""
+import argparse, sys, torch
+sys.path.insert(0, sys.argv[1])
+import avsep_amd as P
+K = P.kernels
+dev = torch.device("cuda:0")
+a = argparse.Namespace(num_mix=2, log_freq=0, weighted_loss=1, binary_mask=1, output_activation="sigmoid", img_activation="relu",
+                       not_pool_vis=False, fusion_type="hidsep", match_weight=0.1, lr_sound=1e-3, lr_frame=1e-4, fix_vis=False,
+                       beta1=0.9, weight_decay=1e-4, stft_frame=1022, stft_hop=256)
+gen = torch.Generator().manual_seed(1)
+srcs = [(torch.rand(2, 1, 64, 64, generator=gen) ** 2).to(dev) for _ in range(2)]
+frames = [torch.randn(2, 3, 2, 64, 64, generator=gen).to(dev) for _ in range(2)]
+def batch(): return {"mag_mix": srcs[0] + srcs[1], "mags": [s.clone() for s in srcs], "frames": list(frames)}
+def model():
+    torch.manual_seed(0)
+    snd = P.models.Unet(fc_dim=2, num_downs=5, ngf=8, fusion_type="hidsep", att_type="sig").to(dev)
+    frm = P.models.ResnetDilated(None, fc_dim=32, pool_type="maxpool").to(dev)
+    mb = P.ModelBuilder()
+    wrap = P.NetWrapper((snd, frm), mb.build_criterion("bce", use_pit=True), mb.build_criterion("bce"))
+    assert wrap.fork_sources and wrap.early_trunk and snd.fork_pair          # the shipped topology
+    return wrap, P.create_optimizer((snd, frm), a)
+# eager: 5 warm-up steps + 3 more
+wrap, opt = model()
+for _ in range(8): e_eager, _, _ = P.net_wrapper.train_step_async(wrap, batch(), opt, True, a)
+torch.cuda.synchronize()
+ref = float(e_eager)
+# captured: 5 eager warm-up steps on the capture stream, one captured step, replayed 3 times
+wrap, opt = model()
+s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    for _ in range(4): P.net_wrapper.train_step_async(wrap, batch(), opt, True, a)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, stream=s):
+    for ar in K._arenas.values():
+        ar.buf.zero_(); ar.off = 0
+    err, match, _ = P.net_wrapper.train_step_async(wrap, batch(), opt, True, a)
+torch.cuda.synchronize()
+for _ in range(4): g.replay()
+torch.cuda.synchronize()
+print("CAPTURE_OK eager %.8f replay %.8f" % (ref, float(err)))
+assert abs(float(err) - ref) <= 1e-5 * max(1.0, abs(ref)), (float(err), ref)
+"""
+
+
+def test_train_step_captures_into_a_hip_graph(dev, tmp_path):
+    """The whole AV train step (forked trunk passes, forked decoder pair, autograd backward, end-of-backward callback, fused
+    SGD) captured into ONE HIP graph and replayed: same loss trajectory as eager.  Under capture NetWrapper.forward keeps
+    source 0's trunk pass on the capturing stream (with every pass on a side stream hipStreamEndCapture crashed on ROCm 7.0:
+    DESIGN.md 8c).  Run once, in a child process: a crash inside the HIP runtime must not take the test session down."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "capture_step.py"
+    script.write_text(_CAPTURE_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CAPTURE_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_forked_streams_at_the_benched_size(dev):

@@ -245,7 +245,7 @@ def test_pack_scope_and_plan_batch_are_scoped():
             K._pack_cache["x"] = 1
         assert K._pack_cache == {"x": 1}
     assert K._pack_cache is None
-    assert P.lib.ConvDesc().plan_n == 0 and ctypes.sizeof(P.lib.ConvDesc) == 22 * 4 + 6 * 8
+    assert P.lib.ConvDesc().plan_n == 0 and ctypes.sizeof(P.lib.ConvDesc) == 24 * 4 + 6 * 8
 
 
 def test_flat_sgd_state_dict_is_layout_independent_and_reads_older_blobs():

@@ -37,8 +37,13 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--leftovers", action="store_true", help="the layer shapes still on the im2col kernel in round 2")
     ap.add_argument("--affine", action="store_true", help="forward over a folded BatchNorm + ReLU input, with statistics")
+    ap.add_argument("--tune", type=lambda v: int(v, 0), default=0, help="avsep_conv_desc.tune (include/avsep.h): bits 0-3 Winograd "
+                    "group shape + 1, bits 4-7 Winograd weight-gradient group shape + 1, bits 8-23 its target workgroup count")
+    ap.add_argument("--algo-no", default="", help="comma list of kernel families the calls must not use (lib.ALGO_NO)")
     o = ap.parse_args()
     K = P.kernels
+    K.conv_tune = o.tune
+    K.set_algo_mask(*[n for n in o.algo_no.split(",") if n])
     K.set_precision(o.prec)
     dev = torch.device("cuda:0")
     for (N, Cin, H, W, Cout, k, s, p, d) in (LEFTOVERS if o.leftovers else SHAPES):
