@@ -349,7 +349,7 @@ def run_config(P, dev, world, seed, rank, prec, backend, B, steps, warmup, timer
     return res
 
 
-def sdr_on_synthetic_val(P, dev, seed, steps=300, batch=16, val_batches=2, precisions=("f32", "bf16"), log=None):
+def sdr_on_synthetic_val(P, dev, seed, steps=300, batch=16, val_batches=4, precisions=("f32", "bf16", "f32_reseed"), log=None):
     """"SDR on val", the second half of BASELINE.json's metric, on synthetic sources (the MUSIC media are not
     in the image), and the evidence that bf16 mode TRAINS: the full-size model (unet7 + hidsep(sig) + resnet18dilated, reference
     initialisation, the shipped flags of scripts/train_MUSIC.sh) is trained from the same seed in fp32 and in bf16 mode for
@@ -357,7 +357,9 @@ def sdr_on_synthetic_val(P, dev, seed, steps=300, batch=16, val_batches=2, preci
     tones; a source's frames encode its f0), with the schedule the shipped flags produce (AV step on even iterations, audio-only
     on odd ones: main.py:578-581), and evaluated before and after on a HELD-OUT seeded validation set with the reference's
     evaluate() protocol (main.py:421-503: eval mode, AV and audio-only, loss + get_metrics' SI-SDR / SDR / SIR / SAR — here
-    evaluate.calc_metrics with the BSS-eval kernels).  Outside every timed region."""
+    evaluate.calc_metrics with the BSS-eval kernels).  "f32_reseed" is the yardstick for the bf16 - f32 differences: the fp32
+    run once more with another weight-initialisation seed (same data stream, same validation set) — how far two equally
+    valid fp32 trainings of this length end up from one another.  Outside every timed region."""
     import copy
     from avsep_amd.train import av_ao_schedule
     a0 = step_args(P)
@@ -385,9 +387,9 @@ def sdr_on_synthetic_val(P, dev, seed, steps=300, batch=16, val_batches=2, preci
            "data": "synthetic harmonic-tone mixtures, fresh seeded batch per step; held-out seeded validation set; frames encode f0",
            "schedule": "AV on even iterations, audio-only on odd ones (iter_per_av 2, start_av_first, num_fsteps 0)"}
     for prec in precisions:
-        P.kernels.set_precision(prec)
+        P.kernels.set_precision("f32" if prec == "f32_reseed" else prec)
         try:
-            a, snd, frm, wrap = build(P, dev, seed, "hip")
+            a, snd, frm, wrap = build(P, dev, seed + (977 if prec == "f32_reseed" else 0), "hip")
             a = copy.copy(a)
             opt = P.create_optimizer((snd, frm), a)
             r = {"before": evaluate(wrap, a)}
@@ -418,6 +420,9 @@ def sdr_on_synthetic_val(P, dev, seed, steps=300, batch=16, val_batches=2, preci
     if "f32" in res and "bf16" in res:
         f, b = res["f32"]["after"], res["bf16"]["after"]
         res["bf16_minus_f32_after"] = {k: {m: b[k][m] - f[k][m] for m in ("loss", "si_sdr", "sdr")} for k in ("val_av", "val_ao")}
+    if "f32" in res and "f32_reseed" in res:
+        f, b = res["f32"]["after"], res["f32_reseed"]["after"]
+        res["f32_reseed_minus_f32_after"] = {k: {m: b[k][m] - f[k][m] for m in ("loss", "si_sdr", "sdr")} for k in ("val_av", "val_ao")}
     return res
 
 
