@@ -596,6 +596,13 @@ int head_dgrad(const avsep_conv_desc* d, const float* w, const float* dy, float*
 bool smallci_applicable(const avsep_conv_desc* d);
 int smallci_dgrad(const avsep_conv_desc* d, const float* w_oihw, const float* dy, float* dx, hipStream_t st);
 // conv_wino.hip: Winograd F(2x2, 3x3) form of the 3x3 / stride 1 / 'same' convs (forward and dgrad), fp32
+// conv_wino4.hip: Winograd F(4x4, 3x3) for the maps that tile by 4 (asked before F(2x2, 3x3))
+bool w4_applicable(const avsep_conv_desc* d, int mode);
+size_t w4_packed_floats(const avsep_conv_desc* d, int mode);
+int w4_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
+int w4_fwd(const avsep_conv_desc* d, const float* up, const float* bias, float* y, double* stats, hipStream_t st);
+int w4_dgrad(const avsep_conv_desc* d, const float* up, const float* dy, float* dx, hipStream_t st);
+void w4_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap);
 bool wn_applicable(const avsep_conv_desc* d, int mode);
 size_t wn_packed_floats(const avsep_conv_desc* d, int mode);
 int wn_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
@@ -707,6 +714,7 @@ extern "C" size_t avsep_conv_packed_floats(const avsep_conv_desc* d, int mode) {
   if (!d || (mode != 0 && mode != 1)) return 0;
   if (mode == 1 && smallci_applicable(d)) return (size_t)d->Cout * d->Cin * d->KH * d->KW;   // OIHW as is
   if (bf_applicable(d, mode)) return bf_packed_floats(d, mode);
+  if (w4_applicable(d, mode)) return w4_packed_floats(d, mode);
   if (wn_applicable(d, mode)) return wn_packed_floats(d, mode);
   if (c3_applicable(d, mode)) return c3_packed_floats(d, mode);
   if (c4_applicable(d, mode)) return c4_packed_floats(d, mode);
@@ -724,6 +732,7 @@ extern "C" int avsep_conv_pack_weights(const avsep_conv_desc* d, const float* w,
     return AVSEP_OK;
   }
   if (bf_applicable(d, mode)) return bf_pack(d, w, packed, mode, (hipStream_t)stream);
+  if (w4_applicable(d, mode)) return w4_pack(d, w, packed, mode, (hipStream_t)stream);
   if (wn_applicable(d, mode)) return wn_pack(d, w, packed, mode, (hipStream_t)stream);
   if (c3_applicable(d, mode)) return c3_pack(d, w, packed, mode, (hipStream_t)stream);
   if (c4_applicable(d, mode)) return c4_pack(d, w, packed, mode, (hipStream_t)stream);
@@ -757,8 +766,8 @@ static SplitPlan splitk_plan(long long tiles, int K) {
   return p;
 }
 static bool fwd_uses_igemm(const avsep_conv_desc* d, const double* stats) {
-  return !((!stats && (smallco_applicable(d) || head_applicable(d))) || bf_applicable(d, 0) || wn_applicable(d, 0) || c3_applicable(d, 0) ||
-           c4_applicable(d, 0) || cm_applicable(d, 0));
+  return !((!stats && (smallco_applicable(d) || head_applicable(d))) || bf_applicable(d, 0) || w4_applicable(d, 0) || wn_applicable(d, 0) ||
+           c3_applicable(d, 0) || c4_applicable(d, 0) || cm_applicable(d, 0));
 }
 // the im2col kernel's tile size and split-K are decided on the planned batch (plan_desc), like every launch heuristic
 static bool fwd_big(const avsep_conv_desc* d) { return use_big(d->Cout, (long long)plan_batch(d) * d->Ho * d->Wo); }
@@ -812,7 +821,7 @@ extern "C" size_t avsep_conv2d_fwd_workspace_bytes(const avsep_conv_desc* d) {
 }
 extern "C" size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (!check_desc(d) && !smallci_applicable(d) && bf_applicable(d, 1)) return bf_workspace_bytes(d, 1);
-  if (check_desc(d) || bf_applicable(d, 1) || wn_applicable(d, 1) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1) ||
+  if (check_desc(d) || bf_applicable(d, 1) || w4_applicable(d, 1) || wn_applicable(d, 1) || c3_applicable(d, 1) || smallci_applicable(d) || c4_applicable(d, 1) ||
       cm_applicable(d, 1))
     return 0;
   SplitPlan p = dgrad_split(d);
@@ -830,6 +839,7 @@ extern "C" int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed,
     return head_fwd(d, w_packed, packed_ld(d, 0), bias, y, (float*)workspace, (hipStream_t)stream);
   }
   if (bf_applicable(d, 0)) return bf_fwd(d, w_packed, bias, y, stats, workspace, workspace_bytes, (hipStream_t)stream);
+  if (w4_applicable(d, 0)) return w4_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (wn_applicable(d, 0)) return wn_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (c3_applicable(d, 0)) return c3_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
   if (c4_applicable(d, 0)) return c4_fwd(d, w_packed, bias, y, stats, (hipStream_t)stream);
@@ -875,6 +885,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
   if (smallci_applicable(d)) return smallci_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (bf_applicable(d, 1)) return bf_dgrad(d, w_packed_dgrad, dy, dx, workspace, workspace_bytes, (hipStream_t)stream);
+  if (w4_applicable(d, 1)) return w4_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (wn_applicable(d, 1)) return wn_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c3_applicable(d, 1)) return c3_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c4_applicable(d, 1)) return c4_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
@@ -1014,6 +1025,7 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
     if (!with_stats && smallco_applicable(d)) return "smallco_fwd";
     if (!with_stats && head_applicable(d)) return "head_fwd_kernel";
     if (bf_applicable(d, 0)) return "convbf_kernel";
+    if (w4_applicable(d, 0)) return "wino4_kernel";
     if (wn_applicable(d, 0)) return "wino_kernel";
     if (c3_applicable(d, 0) || c4_applicable(d, 0) || cm_applicable(d, 0)) return "conv3x3_kernel";
     return "igemm_kernel<fwd>";
@@ -1022,6 +1034,7 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
     if (head_applicable(d)) return "head_dgrad_kernel";
     if (smallci_applicable(d)) return "smallci_dgrad";
     if (bf_applicable(d, 1)) return "convbf_kernel";
+    if (w4_applicable(d, 1)) return "wino4_kernel";
     if (wn_applicable(d, 1)) return "wino_kernel";
     if (c3_applicable(d, 1) || c4_applicable(d, 1) || cm_applicable(d, 1)) return "conv3x3_kernel";
     return "igemm_kernel<dgrad>";
@@ -1047,6 +1060,7 @@ extern "C" int avsep_conv_kernel_variant(const avsep_conv_desc* d, int32_t mode,
   char tail[64] = "";
   if (!strcmp(fam, "convbf_kernel")) bf_variant(d, mode, tail, sizeof(tail));
   else if (!strcmp(fam, "wgradb_kernel")) wbn_variant(d, tail, sizeof(tail));
+  else if (!strcmp(fam, "wino4_kernel")) w4_variant(d, mode, tail, sizeof(tail));
   else if (!strcmp(fam, "conv3x3_kernel")) {
     if (c3_applicable(d, mode)) c3_variant(d, mode, tail, sizeof(tail));
     else if (c4_applicable(d, mode)) c4_variant(d, mode, tail, sizeof(tail));

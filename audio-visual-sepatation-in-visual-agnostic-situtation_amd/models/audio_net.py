@@ -534,7 +534,9 @@ class _UnetPairFn(torch.autograd.Function):
             dbot_a, dva = _decode_bwd(net, E, ctx.Da, dla, dma, True, grads, Gd, order=("record", evs))
             done_a = torch.cuda.Event()
             done_a.record()
-            side.wait_event(fork)
+            # (a backward pass ACCUMULATED onto an earlier one has put A's gradients into scratch views that B adds into:
+            # then B waits for all of A)
+            side.wait_event(done_a if grads.second else fork)
             with torch.cuda.stream(side):
                 dbot_b, dvb = _decode_bwd(net, E, ctx.Db, dlb, dmb, True, grads, Gd, order=("wait", evs))
                 done_b = torch.cuda.Event()

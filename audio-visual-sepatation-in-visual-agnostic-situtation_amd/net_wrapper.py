@@ -259,6 +259,7 @@ class FlatSGD:
         self._pending, self._nodes_left, self._armed = set(), 0, False
         self._slot, self._written, self._returned = {}, set(), set()       # direct gradient placement (grad_dest)
         self._scratch = None
+        self._scratch_src = {}
         self._node_events = []
         self._end_queued, self._at_end = False, []
         self._caller_stream = None
@@ -322,6 +323,7 @@ class FlatSGD:
             return None
         gi = self._group_of[p]
         sc = self._scratch_of_current_stream(gi, create=True)
+        self._scratch_src[p] = sc              # fold_scratch adds THIS buffer, whichever stream folds
         off = gv.storage_offset() - self.param_groups[gi]["range"][0]
         return sc[off:off + gv.numel()].view_as(gv)
 
@@ -351,24 +353,26 @@ class FlatSGD:
     def fold_scratch(self, params):
         """flat_grad += scratch over the flat ranges of `params` (merged into contiguous runs; padding holds zeros)."""
         A = self.ALIGN
-        spans = sorted((self._slot[p].storage_offset(), (self._slot[p].numel() + A - 1) // A * A) for p in params)
-        runs = []
-        for off, n in spans:
-            if runs and runs[-1][1] == off:
-                runs[-1][1] = off + n
-            else:
-                runs.append([off, off + n])
+        by_buf = {}
+        for p in params:
+            sc = self._scratch_src.get(p)
+            if sc is None:
+                raise lib.AvsepError("fold_scratch: a parameter that was never handed a scratch view (scratch_dest) in this step")
+            by_buf.setdefault(id(sc), (sc, self._group_of[p], []))[2].append(p)
         self._wait_for_nodes()                      # the first contributions (and earlier folds) may be on other streams
-        for a, b in runs:
-            for gi, g in enumerate(self.param_groups):          # a run may span neighbouring groups
-                lo, hi = max(a, g["range"][0]), min(b, g["range"][1])
-                if lo >= hi:
-                    continue
-                sc = self._scratch_of_current_stream(gi)
-                if sc is None:
-                    raise lib.AvsepError("fold_scratch: the current stream holds no scratch contribution for parameter group "
-                                         f"'{g['name']}' (scratch_dest was never called on this stream for it)")
-                self.flat_grad[lo:hi].add_(sc[lo - g["range"][0]:hi - g["range"][0]])
+        for sc, gi, ps in by_buf.values():          # one scratch buffer = one (stream, group): runs never span groups
+            base = self.param_groups[gi]["range"][0]
+            spans = sorted((self._slot[p].storage_offset(), (self._slot[p].numel() + A - 1) // A * A) for p in ps)
+            runs = []
+            for off, n in spans:
+                if runs and runs[-1][1] == off:
+                    runs[-1][1] = off + n
+                else:
+                    runs.append([off, off + n])
+            for a, b in runs:
+                self.flat_grad[a:b].add_(sc[a - base:b - base])
+            for p in ps:
+                del self._scratch_src[p]
 
     def node_finished(self, group, returned):
         """An autograd node of network `group` has run its backward; `returned` = the parameters whose gradient it handed
@@ -447,6 +451,7 @@ class FlatSGD:
             p.grad = gv
         self._written.clear()
         self._returned.clear()
+        self._scratch_src = {}
         self._node_events = []
         self._end_queued, self._at_end = False, []       # (a backward pass that raised never ran its final callback)
         self._early, self._armed, self._nodes_left = None, False, 0     # disarmed until arm_early_reduce()

@@ -84,6 +84,12 @@ CONV_CASES = [
     (64, 64, 32, 32, 80, 4, 2, 1, 1),      # 4x16-pixel chunks, ragged second output-channel tile
     (64, 64, 24, 24, 72, 4, 2, 1, 1),      # 8x8-pixel chunks
     (72, 64, 20, 36, 72, 4, 2, 1, 1),      # ragged group grid
+    # conv_wino4.hip: Winograd F(4x4, 3x3) forward + data gradient (H, W multiples of 4 and >= 16, >= 192 workgroups of
+    # 64 channels x 32 tiles at the planned batch); kernel family ASSERTED
+    (40, 72, 32, 64, 80, 3, 1, 1, 1),      # one 4x8-tile group per workgroup (16x32 pixels), 9 / 10 K-tiles, ragged second M tile
+    (200, 72, 16, 16, 136, 3, 1, 1, 1),    # two 4x4-tile groups (16x16 maps: two images per workgroup), three M tiles
+    (16, 72, 56, 56, 72, 3, 1, 1, 1),      # eight 2x2-tile groups (56x56: 7x7 groups per image)
+    (72, 72, 20, 36, 72, 3, 1, 1, 1),      # ragged group grid, last workgroup partial
 ]
 
 
@@ -95,10 +101,15 @@ def _rows_after(marker_case, count):
 # kernel family a row exists to exercise: a moved dispatch threshold must fail the test, not silently fall back to the
 # direct-form kernel (which passes the same numeric bound)
 EXPECT_FAMILY = {}
+EXPECT_MASK = {}          # kernel families a row forbids (kernels.set_algo_mask): the F(2x2) rows keep F(4x4) out of their way
 for _c in _rows_after((64, 48, 32, 32, 80, 3, 1, 1, 1), 7):
     EXPECT_FAMILY[_c] = {"fwd": "wino_kernel", "dgrad": "wino_kernel"}
+    EXPECT_MASK[_c] = ("winograd4",)
 for _c in _rows_after((64, 64, 32, 32, 80, 3, 1, 1, 1), 4):
     EXPECT_FAMILY[_c] = {"fwd": "wino_kernel", "dgrad": "wino_kernel", "wgrad": "winow_kernel"}
+    EXPECT_MASK[_c] = ("winograd4",)
+for _c in _rows_after((40, 72, 32, 64, 80, 3, 1, 1, 1), 4):
+    EXPECT_FAMILY[_c] = {"fwd": "wino4_kernel", "dgrad": "wino4_kernel"}
 for _c in _rows_after((64, 64, 32, 32, 80, 4, 2, 1, 1), 3):
     EXPECT_FAMILY[_c] = {"wgrad": "wgrad4d_kernel"}
 for _c in _rows_after((3, 3, 32, 64, 72, 7, 2, 3, 1), 3) + [(2, 1, 32, 48, 24, 4, 2, 1, 1)]:
@@ -108,6 +119,14 @@ for _c in _rows_after((3, 3, 32, 64, 72, 7, 2, 3, 1), 3) + [(2, 1, 32, 48, 24, 4
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(dev, case):
     K = _pkg().kernels
+    K.set_algo_mask(*EXPECT_MASK.get(case, ()))
+    try:
+        _conv_case(dev, K, case)
+    finally:
+        K.set_algo_mask()
+
+
+def _conv_case(dev, K, case):
     N, Cin, H, W, Cout, k, s, p, d = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -439,12 +458,13 @@ def test_b16_relu_up2x_and_stem_tail(dev, N, C0, C1, H, W):
     assert K.is_b16(s2d16) and torch.equal(K.to_f32(s2d16), s2d32.to(torch.bfloat16).float())
 
 
-def test_conv_virtual_input_winograd(dev):
-    """the same folded two-source input (C0 == C1) through the Winograd kernel's staging (conv_wino.hip), with the
-    BatchNorm sums of the result."""
+@pytest.mark.parametrize("N,family", [(32, "wino_kernel"), (64, "wino4_kernel")])
+def test_conv_virtual_input_winograd(dev, N, family):
+    """the same folded two-source input (C0 == C1) through the Winograd kernels' staging (conv_wino.hip at 128 workgroups,
+    conv_wino4.hip from 192), with the BatchNorm sums of the result."""
     K = _pkg().kernels
     g = torch.Generator().manual_seed(11)
-    N, C0, C1, Cout, H, W = 32, 64, 64, 72, 32, 32
+    C0, C1, Cout, H, W = 64, 64, 72, 32, 32
     x0, x1 = torch.randn(N, C0, H, W, generator=g), torch.randn(N, C1, H, W, generator=g)
     sc0, sh0 = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g)
     sc1, sh1 = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g)
@@ -458,7 +478,7 @@ def test_conv_virtual_input_winograd(dev):
     y_ref = y_ref.detach()
     t = lambda z: z.to(dev)
     cv = K.Conv(t(x0), Cout, 3, 1, 1, x1=t(x1), sc0=t(sc0), sh0=t(sh0), act0=2, sc1=t(sc1), sh1=t(sh1), act1=1)
-    assert cv.kernel_name("fwd", True) == "wino_kernel" and cv.kernel_name("wgrad") == "winow_kernel"
+    assert cv.kernel_name("fwd", True) == family and cv.kernel_name("wgrad") == "winow_kernel"
     assert_close(cv.wgrad(t(dy))[0], wr.grad, 2e-5, "wgrad")
     st = K.zeros_stats(Cout, cv.like)
     assert_close(cv.fwd(cv.pack(t(w), 0), None, st), y_ref, 2e-5, "fwd")
@@ -476,7 +496,7 @@ def test_conv_virtual_input_winograd(dev):
     assert cv4.kernel_name("wgrad") == "wgrad4d_kernel"
     assert_close(cv4.wgrad(t(dy4))[0], w4.grad, 2e-5, "wgrad 4x4/s2")
     cv1 = K.Conv(t(x01), Cout, 3, 1, 1, act0=1)
-    assert cv1.kernel_name("fwd", False) == "wino_kernel"
+    assert cv1.kernel_name("fwd", False) == family
     assert_close(cv1.fwd(cv1.pack(t(w), 0)), F.conv2d(F.relu(x01), w, None, 1, 1), 2e-5, "fwd relu")
 
 
