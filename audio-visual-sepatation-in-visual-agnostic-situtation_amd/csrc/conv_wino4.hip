@@ -46,7 +46,8 @@ constexpr int W4_V_FLOATS = 36 * W4_CK * W4_NT;     // transformed input of one 
 
 struct W4Args {
   int N, C0, C1, Cin, H, W, Cout;   // Cin = C0 + C1
-  int gyn, gxn, ngroups;            // tile groups per image along y / x, and in total
+  int Hq, Wq;                       // the (sub-)image the tiles live in: H x W, or H/2 x W/2 per parity class (dilation 2)
+  int gyn, gxn, ngroups;            // tile groups per (sub-)image along y / x, and in total
   int gridM, act0, act1;
   const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
   const float* up;                  // [K-tile][M-tile][cb][q][chunk 9][lk 2][li 32][4]
@@ -121,9 +122,13 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict
   } while (0)
 
 // G groups of GH x GW tiles (G*GH*GW = 32); PW = LDS row stride of a group's patch (multiple of 4: the transform reads
-// rows as b128 + b64), GS = LDS stride between groups; RAW: no affine and no activation on the staged tensor.
-template <int G, int GH, int GW, int PW, int GS, bool RAW>
+// rows as b128 + b64), GS = LDS stride between groups; RAW: no affine and no activation on the staged tensor; SUB: the
+// groups tile the four parity sub-images of a dilation-2 conv (a dilated 'same' conv is four independent undilated convs
+// over the pixels of equal row / column parity); FULL: H and W are multiples of 4 (whole tiles, 16-byte row stores) —
+// otherwise the last tile row / column of a (sub-)image is partial: its inputs load as zeros, its outputs are masked.
+template <int G, int GH, int GW, int PW, int GS, bool RAW, bool SUB, bool FULL>
 __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
+  static_assert(!(SUB && FULL), "sub-image stores are strided");
   static_assert(G * GH * GW == W4_NT, "32 tiles per workgroup");
   constexpr int CK = W4_CK, BM = W4_BM, NT = W4_THREADS;
   constexpr int PHG = 4 * GH + 2, PCG = 4 * GW + 2;                 // patch of one group (valid elements)
@@ -178,9 +183,15 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
     const int g = posc / (PHG * PCG), r = (posc % (PHG * PCG)) / PCG, col = posc % PCG;
     const int img = gtab[g][0], y = gtab[g][1] - 1 + r, x = gtab[g][2] - 1 + col;
     const bool valid = pos < NPOS;
-    const bool inimg = valid && gtab[g][3] && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    const bool inimg = valid && gtab[g][3] && (unsigned)y < (unsigned)a.Hq && (unsigned)x < (unsigned)a.Wq;
+    int n = img, fy = y, fx = x;
+    if constexpr (SUB) {
+      n = img >> 2;
+      fy = 2 * y + ((img >> 1) & 1);
+      fx = 2 * x + (img & 1);
+    }
     // BYTE offset from the source's base (the channel offset is scalar): element offsets < 2^30, host check
-    p_off[sl] = inimg ? 4u * (unsigned)((long long)img * a.C0 * HW + (long long)y * a.W + x) : 0xffffffffu;   // C1 == C0 when there is a source 1
+    p_off[sl] = inimg ? 4u * (unsigned)((long long)n * a.C0 * HW + (long long)fy * a.W + fx) : 0xffffffffu;   // C1 == C0 when there is a source 1
     const int word = g * GS + r * PW + col;
     if constexpr (RAW) {
       p_lds[sl] = valid ? word : DEAD;           // an element outside the image loads as 0: stored like any other
@@ -359,8 +370,11 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
   const int ec = tid >> 5, etile = tid & 31; // output role: channel within the pass, tile
   const int eg = etile / (GH * GW), ety = (etile % (GH * GW)) / GW, etx = etile % GW;
   const int img = gtab[eg][0], oy = gtab[eg][1] + 4 * ety, ox = gtab[eg][2] + 4 * etx;
-  const bool tok = gtab[eg][3] && oy < a.H && ox < a.W;          // H, W multiples of 4 (host): a started tile is whole
-  const long long obase = (long long)img * a.Cout * HW + (long long)oy * a.W + ox;
+  const bool tok = gtab[eg][3] && oy < a.Hq && ox < a.Wq;        // FULL: a started tile is whole
+  long long obase;
+  if constexpr (SUB) obase = (long long)(img >> 2) * a.Cout * HW + (long long)(2 * oy + ((img >> 1) & 1)) * a.W + 2 * ox + (img & 1);
+  else obase = (long long)img * a.Cout * HW + (long long)oy * a.W + ox;
+  constexpr int XS = SUB ? 2 : 1;
   const bool want_stats = a.stats != nullptr;
 #pragma unroll
   for (int cbp = 0; cbp < 2; ++cbp) {
@@ -391,10 +405,23 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
           f32x4 y;
           W4_AT4(r_[i][0], r_[i][1], r_[i][2], r_[i][3], r_[i][4], r_[i][5], y[0], y[1], y[2], y[3]);
           y += bias;
-          if (rok && tok) {
-            *reinterpret_cast<f32x4*>(o + (long long)i * a.W) = y;
-            s += (y[0] + y[1]) + (y[2] + y[3]);
-            q += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+          if constexpr (FULL) {
+            if (rok && tok) {
+              *reinterpret_cast<f32x4*>(o + (long long)i * a.W) = y;
+              s += (y[0] + y[1]) + (y[2] + y[3]);
+              q += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+            }
+          } else {
+            if (rok && tok && oy + i < a.Hq) {
+              float* orow = o + (long long)(XS * i) * a.W;
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (ox + j < a.Wq) {
+                  orow[XS * j] = y[j];
+                  s += y[j];
+                  q += y[j] * y[j];
+                }
+            }
           }
         }
         if (want_stats) {
@@ -438,14 +465,17 @@ static int w4_cfg(int H, int W) {
   return best;
 }
 
-struct W4Plan { int cfg, gyn, gxn, ngroups, ptiles, gridM; };
+struct W4Plan { int Hq, Wq, cfg, gyn, gxn, ngroups, ptiles, gridM; };
 static W4Plan w4_plan(const avsep_conv_desc* d, int mode) {
   W4Plan p{};
-  p.cfg = w4_cfg(d->H, d->W);
+  const bool sub = d->dil == 2;
+  p.Hq = sub ? d->H / 2 : d->H;
+  p.Wq = sub ? d->W / 2 : d->W;
+  p.cfg = w4_cfg(p.Hq, p.Wq);
   const W4Cfg& k = W4_CFGS[p.cfg];
-  p.gyn = cdiv(d->H, k.gh);
-  p.gxn = cdiv(d->W, k.gw);
-  p.ngroups = d->N * p.gyn * p.gxn;
+  p.gyn = cdiv(p.Hq, k.gh);
+  p.gxn = cdiv(p.Wq, k.gw);
+  p.ngroups = d->N * (sub ? 4 : 1) * p.gyn * p.gxn;
   p.ptiles = cdiv(p.ngroups, k.g);
   p.gridM = cdiv(mode == 0 ? d->Cout : d->Cin, W4_BM);
   return p;
@@ -453,8 +483,12 @@ static W4Plan w4_plan(const avsep_conv_desc* d, int mode) {
 
 bool w4_applicable(const avsep_conv_desc* d, int mode) {
   if ((d->algo & (AVSEP_ALGO_NO_WINOGRAD | AVSEP_ALGO_NO_WINOGRAD4)) || d->prec != AVSEP_PREC_F32) return false;
-  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1) || d->up2x) return false;
-  if ((d->H & 3) || (d->W & 3) || d->H < 16 || d->W < 16) return false;          // whole 4x4 tiles, 16-byte row stores
+  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil) || d->up2x) return false;
+  if ((d->H & 1) || (d->W & 1) || d->H < 14 || d->W < 14) return false;          // even maps (dilation 2: equal parity sub-images)
+  {   // tile fill: F(4x4) pays 36 products per 4x4 tile, F(2x2) 16 per 2x2 — worth it from ~60 % of whole tiles
+    const int hq = d->dil == 2 ? d->H / 2 : d->H, wq = d->dil == 2 ? d->W / 2 : d->W;
+    if ((double)hq * wq < 0.6 * (double)roundup(hq, 4) * roundup(wq, 4)) return false;
+  }
   const int cin = mode == 0 ? d->Cin : d->Cout, cout = mode == 0 ? d->Cout : d->Cin;
   if (cin % W4_CK || cin < 32 || cin > W4_AFF_MAX || cout < 48) return false;
   if (mode == 0) {
@@ -480,32 +514,35 @@ int w4_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, h
   return AVSEP_OK;
 }
 void w4_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
-  const avsep_conv_desc e = plan_desc(d);
-  const W4Cfg& k = W4_CFGS[w4_plan(&e, mode).cfg];
-  snprintf(buf, cap, "%dx%dx%d", k.g, k.gh, k.gw);
+  const W4Cfg& k = W4_CFGS[w4_plan(d, mode).cfg];
+  snprintf(buf, cap, "%dx%dx%d%s", k.g, k.gh, k.gw, d->dil == 2 ? ",sub" : "");
 }
 
-template <bool RAW>
+template <bool RAW, bool SUB, bool FULL>
 static void w4_launch_cfg(const W4Args& a, int cfg, dim3 grid, hipStream_t st) {
   // <G, GH, GW, PW, GS>: row strides chosen so that the b128 row reads of the transform spread over the 64 banks
   switch (cfg) {
-    case 0: hipLaunchKernelGGL((wino4_kernel<1, 4, 8, 40, 18 * 40, RAW>), grid, dim3(W4_THREADS), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((wino4_kernel<2, 4, 4, 20, 384, RAW>), grid, dim3(W4_THREADS), 0, st, a); break;
-    default: hipLaunchKernelGGL((wino4_kernel<8, 2, 2, 12, 10 * 12 + 8, RAW>), grid, dim3(W4_THREADS), 0, st, a); break;
+    case 0: hipLaunchKernelGGL((wino4_kernel<1, 4, 8, 40, 18 * 40, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((wino4_kernel<2, 4, 4, 20, 384, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL((wino4_kernel<8, 2, 2, 12, 10 * 12 + 8, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
   }
 }
 
 static int w4_launch(W4Args& a, const avsep_conv_desc* d, int mode, bool raw, hipStream_t st) {
-  const avsep_conv_desc e = plan_desc(d);
-  const int cfg = w4_plan(&e, mode).cfg;           // the group shape is a launch decision: planned batch
-  const W4Cfg& k = W4_CFGS[cfg];
-  a.gyn = cdiv(d->H, k.gh);
-  a.gxn = cdiv(d->W, k.gw);
-  a.ngroups = d->N * a.gyn * a.gxn;
-  a.gridM = cdiv(mode == 0 ? d->Cout : d->Cin, W4_BM);
-  dim3 grid((unsigned)((long long)cdiv(a.ngroups, k.g) * a.gridM));
-  if (raw) w4_launch_cfg<true>(a, cfg, grid, st);
-  else w4_launch_cfg<false>(a, cfg, grid, st);
+  const W4Plan p = w4_plan(d, mode);               // (the group shape depends on the map only, not on the batch)
+  a.Hq = p.Hq; a.Wq = p.Wq; a.gyn = p.gyn; a.gxn = p.gxn; a.ngroups = p.ngroups; a.gridM = p.gridM;
+  dim3 grid((unsigned)((long long)p.ptiles * p.gridM));
+  const bool sub = d->dil == 2, full = !sub && !(d->H & 3) && !(d->W & 3);
+  if (sub) {
+    if (raw) w4_launch_cfg<true, true, false>(a, p.cfg, grid, st);
+    else w4_launch_cfg<false, true, false>(a, p.cfg, grid, st);
+  } else if (full) {
+    if (raw) w4_launch_cfg<true, false, true>(a, p.cfg, grid, st);
+    else w4_launch_cfg<false, false, true>(a, p.cfg, grid, st);
+  } else {
+    if (raw) w4_launch_cfg<true, false, false>(a, p.cfg, grid, st);
+    else w4_launch_cfg<false, false, false>(a, p.cfg, grid, st);
+  }
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }

@@ -90,6 +90,10 @@ CONV_CASES = [
     (200, 72, 16, 16, 136, 3, 1, 1, 1),    # two 4x4-tile groups (16x16 maps: two images per workgroup), three M tiles
     (16, 72, 56, 56, 72, 3, 1, 1, 1),      # eight 2x2-tile groups (56x56: 7x7 groups per image)
     (72, 72, 20, 36, 72, 3, 1, 1, 1),      # ragged group grid, last workgroup partial
+    (400, 72, 14, 14, 72, 3, 1, 1, 1),     # 14x14 (ResNet layer3): partial last tile row / column, masked scalar stores
+    (72, 72, 18, 30, 72, 3, 1, 1, 1),      # H, W = 2 mod 4 on the 2x2-tile groups
+    (260, 72, 14, 14, 72, 3, 1, 2, 2),     # dilation 2: the four 7x7 parity sub-images, one 2x2-tile group each (ResNet layer4)
+    (80, 72, 28, 28, 72, 3, 1, 2, 2),      # dilation 2 at 28x28: 14x14 sub-images on the 4x4-tile groups
 ]
 
 
@@ -108,7 +112,7 @@ for _c in _rows_after((64, 48, 32, 32, 80, 3, 1, 1, 1), 7):
 for _c in _rows_after((64, 64, 32, 32, 80, 3, 1, 1, 1), 4):
     EXPECT_FAMILY[_c] = {"fwd": "wino_kernel", "dgrad": "wino_kernel", "wgrad": "winow_kernel"}
     EXPECT_MASK[_c] = ("winograd4",)
-for _c in _rows_after((40, 72, 32, 64, 80, 3, 1, 1, 1), 4):
+for _c in _rows_after((40, 72, 32, 64, 80, 3, 1, 1, 1), 8):
     EXPECT_FAMILY[_c] = {"fwd": "wino4_kernel", "dgrad": "wino4_kernel"}
 for _c in _rows_after((64, 64, 32, 32, 80, 4, 2, 1, 1), 3):
     EXPECT_FAMILY[_c] = {"wgrad": "wgrad4d_kernel"}
@@ -500,10 +504,20 @@ def test_conv_virtual_input_winograd(dev, N, family):
     assert_close(cv1.fwd(cv1.pack(t(w), 0)), F.conv2d(F.relu(x01), w, None, 1, 1), 2e-5, "fwd relu")
 
 
-def test_conv_dilated_folded_input_winograd(dev):
+@pytest.mark.parametrize("family", ["wino_kernel", "wino4_kernel"])
+def test_conv_dilated_folded_input_winograd(dev, family):
     """dilation 2 over a folded BatchNorm + ReLU input (the ResNet layer3/4 form): the parity-sub-image instantiations of the
-    Winograd forward, data-gradient and weight-gradient kernels with the affine staging path, and the BatchNorm sums."""
+    Winograd forward, data-gradient (F(2x2) and F(4x4)) and weight-gradient kernels with the affine staging path, and the
+    BatchNorm sums."""
     K = _pkg().kernels
+    K.set_algo_mask(*(("winograd4",) if family == "wino_kernel" else ()))
+    try:
+        _dilated_folded_case(dev, K, family)
+    finally:
+        K.set_algo_mask()
+
+
+def _dilated_folded_case(dev, K, family):
     g = torch.Generator().manual_seed(12)
     N, Cin, Cout, H, W = 260, 128, 72, 14, 14
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -515,7 +529,7 @@ def test_conv_dilated_folded_input_winograd(dev):
     y_ref.backward(dy)
     t = lambda z: z.to(dev)
     cv = K.Conv(t(x), Cout, 3, 1, 2, 2, sc0=t(sc), sh0=t(sh), act0=1)
-    assert (cv.kernel_name("fwd", True), cv.kernel_name("dgrad"), cv.kernel_name("wgrad")) == ("wino_kernel", "wino_kernel", "winow_kernel")
+    assert (cv.kernel_name("fwd", True), cv.kernel_name("dgrad"), cv.kernel_name("wgrad")) == (family, family, "winow_kernel")
     st = K.zeros_stats(Cout, cv.like)
     yd = y_ref.detach()
     assert_close(cv.fwd(cv.pack(t(w.detach()), 0), None, st), yd, 2e-5, "fwd")
