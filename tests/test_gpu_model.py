@@ -732,9 +732,17 @@ def _check_flat_grads(prec, nets, ograds, ograds64):
     1e-4..5e-3 of a tensor's norm (a ReLU / max-pool decision on a pre-activation of ~1e-7 flips between any two fp32
     implementations): the arbiter is the oracle in FLOAT64, run once from the same weights and inputs.  Per tensor, with
     e(x) = ||x - g64||_2 / ||g64||_2:
-      fp32:  e(hip) <= max(25 * e(oracle fp32), 1e-3) — the distance of the reference's own fp32 arithmetic from the exact
-             gradient is the yardstick (measured: decoder 0.3x-1x, encoder 2x-5x, trunk 1x of the oracle's own error; the
-             BatchNorm bias of the innermost 4x4 level, a sum of 128 cancelling terms with |g| = 3e-4, 19x = 6e-3);
+      fp32:  the distance of the reference's own fp32 arithmetic from the exact gradient is the yardstick, r = e(hip) / e(oracle
+             fp32).  Attribution (tools/grad_attribution.py, profiles/r05_grad_attribution_*.txt: the same check with the
+             Winograd kernels off, on one stream, from the HIP STFT): neither the Winograd transforms (the direct-form kernels
+             are slightly WORSE: decoder 1.5-2x against 0.3-0.9x with F(2x2)) nor the order of the statistics atomics carry the
+             5-19x a few tensors showed in round 4 — those were single ReLU / max-pool decisions flipping at the bottleneck (they
+             moved to other tensors, or vanished, whenever any kernel's rounding changed; with the F(4x4,3x3) kernels the same
+             tensors sit at 1.2-2.3x), i.e. one noise realisation, while the F(4x4,3x3) kernels raise the SMOOTH error of everything
+             downstream of them to ~2x the oracle's own (median r 1.08 -> 1.75; trunk convs 1.1x -> 2.0x, decoder 0.3-0.9x ->
+             1.6-1.9x).  Bounds: per parameter family (decoder / encoder / trunk convs and BatchNorms, fc) the MEDIAN r <= 5 — a
+             kernel family that is systematically off moves its family's median; and per tensor e(hip) <= max(25 * e(oracle
+             fp32), 1e-3), which leaves room for one flipped decision (19x seen);
       bf16:  every operand and every stored activation / gradient carries a 2^-9 rounding and this network doubles a
              relative error per decoder level on the way back (the fp32 errors above grow the same way); the visual trunk only
              receives the gradient that went through the whole decoder and the fusion.  What arrives there is one noise
@@ -764,6 +772,18 @@ def _check_flat_grads(prec, nets, ograds, ograds64):
                 ok = cos >= (0.85 if (prefix == "sound." and "up_forward" in k) else 0.3) and (not head or e_hip <= 2e-2)
             if not ok:
                 bad.append(rows[-1])
+    if prec == "f32":
+        fam = {}
+        for name, e_hip, e_o32, _ in rows:
+            sound = name.startswith("sound.")
+            conv = name.endswith("weight") and (".down_forward.0." in name or ".down_forward.1." in name or "up_forward.2." in name or
+                                                ".conv" in name or name.endswith("features.0.weight") or ".fc." in name or "downsample.0" in name)
+            key = ("U-Net decoder " if "up_forward" in name else "U-Net encoder " if sound else "trunk ") + ("conv" if conv else "BatchNorm")
+            fam.setdefault(key, []).append(e_hip / max(e_o32, 1e-300))
+        for key, v in sorted(fam.items()):
+            v.sort()
+            print(f"    family {key:24s} n={len(v):3d}  median e_hip/e_oracle32 {v[len(v) // 2]:.2f}  worst {v[-1]:.2f}")
+            assert v[len(v) // 2] <= 5.0, (key, v)
     by_err = sorted(rows, key=lambda r: -r[1])
     med = sorted(r[1] for r in rows)[len(rows) // 2]
     med_cos = sorted(r[3] for r in rows)[len(rows) // 2]
@@ -859,6 +879,80 @@ def test_benched_dispatch_full_size_step_vs_oracle(dev, prec, err_tol):
             assert must in fams, (must, sorted(fams))
         big = [r for r in log.rows if r[2].startswith("convbf_kernel") and r[2].endswith("x256")]
         assert len(big) >= 20, "the 512-thread (256-pixel) bf16 tiles must be on the tested path: %d" % len(big)
+
+
+# (Cin, H, W, Cout, k, stride, pad, dil) of the step's convolutions that have bf16 backward kernels, at their true sizes
+_BENCHED_BACKWARD_SHAPES = [
+    (64, 128, 128, 128, 4, 2, 1, 1), (128, 64, 64, 256, 4, 2, 1, 1), (256, 32, 32, 512, 4, 2, 1, 1), (512, 16, 16, 512, 4, 2, 1, 1),
+    (256, 128, 128, 64, 3, 1, 1, 1), (512, 64, 64, 128, 3, 1, 1, 1), (1024, 32, 32, 256, 3, 1, 1, 1), (1024, 16, 16, 512, 3, 1, 1, 1),
+    (1024, 8, 8, 512, 3, 1, 1, 1),
+    (64, 56, 56, 64, 3, 1, 1, 1), (64, 56, 56, 128, 3, 2, 1, 1), (128, 28, 28, 128, 3, 1, 1, 1), (128, 28, 28, 256, 3, 2, 1, 1),
+    (256, 14, 14, 256, 3, 1, 1, 1), (256, 14, 14, 512, 3, 1, 1, 1), (512, 14, 14, 512, 3, 1, 2, 2), (512, 14, 14, 256, 3, 1, 1, 1),
+    (64, 56, 56, 128, 1, 2, 0, 1), (256, 14, 14, 512, 1, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("shape", _BENCHED_BACKWARD_SHAPES)
+def test_bf16_backward_kernels_at_benched_shapes(dev, shape):
+    """The check of bf16 mode's BACKWARD arithmetic that can fail for a wrong kernel (the whole-step gradient comparison of
+    _check_flat_grads[bf16] is dominated by the chaos of a 14-level network: a wiring check).  Every convolution geometry of the
+    step, at its true size and on the kernel instantiation of the batch-64 step (plan_n), gets operands that are EXACTLY
+    representable in bf16 (so the bf16 kernels' operand rounding is the identity) and its bf16-mode data and weight gradients
+    must equal the fp32 kernels' of this library (pinned against torch in tests/test_gpu_ops.py) up to fp32 accumulation order:
+    2e-5 of the tensor's maximum, as test_conv_bf16_operands does at small shapes."""
+    P = _pkg()
+    K = P.kernels
+    Cin, H, W, Cout, k, s, p, d = shape
+    N = 8
+    g = torch.Generator().manual_seed(sum(shape))
+    r16 = lambda z: z.to(torch.bfloat16).float().to(dev)
+    x = r16(torch.randn(N, Cin, H, W, generator=g))
+    w = r16(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    K.plan_batch_scale = BENCH_BATCH // N
+    try:
+        cb = K.Conv(x, Cout, k, s, p, d, prec="bf16")
+        cf = K.Conv(x, Cout, k, s, p, d, prec="f32")
+        dy = r16(torch.randn(N, Cout, cb.Ho, cb.Wo, generator=g))
+        fams = (cb.kernel_name("dgrad"), cb.kernel_name("wgrad"))
+        assert fams[1] == "wgradb_kernel", fams                      # every listed geometry has a bf16 weight-gradient kernel
+        dx16, dx32 = cb.dgrad(cb.pack(w, 1), dy), cf.dgrad(cf.pack(w, 1), dy)
+        dw16, dw32 = cb.wgrad(dy)[0], cf.wgrad(dy)[0]
+        e_dx = rel_err(K.to_f32(dx16), dx32)
+        e_dw = rel_err(dw16, dw32)
+        print(f"{shape}: {fams[0]} dgrad {e_dx:.2e}, {fams[1]} wgrad {e_dw:.2e}")
+        assert e_dx <= 2e-5 and e_dw <= 2e-5, (shape, fams, e_dx, e_dw)
+    finally:
+        K.plan_batch_scale = 1
+
+
+def test_sdr_on_synthetic_val_trains_in_both_precisions(dev):
+    """bench.py's "SDR on synthetic val" leg (BASELINE.json's metric, second half) at a reduced length: the full-size model
+    trained from the same seed in fp32 and in bf16 mode on the seeded synthetic stream with the shipped AV / audio-only schedule,
+    evaluated on a held-out seeded set with the reference's evaluate() protocol (main.py:421-503).  The model must LEARN in both
+    precisions — training loss down by >= 15 %, validation SDR up by >= 8 dB from the untrained masks — and bf16 must track fp32:
+    final training losses within 10 %, validation SDR within 4 dB (two fp32 runs that differ only in their initialisation seed
+    end 0.5-2.3 dB apart at this length: profiles/r05_sdr_on_synthetic_val_*.json)."""
+    import os
+    import sys
+    P = _pkg()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    r = bench.sdr_on_synthetic_val(P, dev, 1234, steps=160, batch=8, val_batches=2, precisions=("f32", "bf16"))
+    for prec in ("f32", "bf16"):
+        x = r[prec]
+        print(prec, {k: (round(x["before"][k]["sdr"], 2), round(x["after"][k]["sdr"], 2)) for k in ("val_av", "val_ao")},
+              x["train_loss_av"], x["train_loss_ao"])
+        for k in ("av", "ao"):
+            t = x["train_loss_" + k]
+            assert t["last"] <= 0.85 * t["first"], (prec, k, t)
+        for k in ("val_av", "val_ao"):
+            assert x["after"][k]["sdr"] >= x["before"][k]["sdr"] + 8.0, (prec, k, x["before"][k], x["after"][k])
+            assert all(v == v for v in x["after"][k].values())
+    for k in ("av", "ao"):
+        a, b = r["f32"]["train_loss_" + k]["last"], r["bf16"]["train_loss_" + k]["last"]
+        assert abs(a - b) <= 0.10 * a, (k, a, b)
+    for k in ("val_av", "val_ao"):
+        assert abs(r["bf16_minus_f32_after"][k]["sdr"]) <= 4.0, r["bf16_minus_f32_after"]
 
 
 def test_eval_path_vs_oracle(dev):
