@@ -126,14 +126,17 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict
 // groups tile the four parity sub-images of a dilation-2 conv (a dilated 'same' conv is four independent undilated convs
 // over the pixels of equal row / column parity); FULL: H and W are multiples of 4 (whole tiles, 16-byte row stores) —
 // otherwise the last tile row / column of a (sub-)image is partial: its inputs load as zeros, its outputs are masked.
-template <int G, int GH, int GW, int PW, int GS, bool RAW, bool SUB, bool FULL>
+// GX: extra words on the odd groups and on the groups with bit 1 set (g*GS + GX*(g&1) + GX*((g>>1)&1)): with eight 2x2-tile
+// groups no uniform group stride spreads the row reads of a 16-lane b128 access over all 64 banks (4-way conflicts measured).
+template <int G, int GH, int GW, int PW, int GS, int GX, bool RAW, bool SUB, bool FULL>
 __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
   static_assert(!(SUB && FULL), "sub-image stores are strided");
+  auto goff = [](int g) __attribute__((always_inline)) { return g * GS + GX * (g & 1) + GX * ((g >> 1) & 1); };
   static_assert(G * GH * GW == W4_NT, "32 tiles per workgroup");
   constexpr int CK = W4_CK, BM = W4_BM, NT = W4_THREADS;
   constexpr int PHG = 4 * GH + 2, PCG = 4 * GW + 2;                 // patch of one group (valid elements)
-  static_assert(PW % 4 == 0 && PW > PCG && GS % 4 == 0 && GS >= PHG * PW, "patch strides");
-  constexpr int PS = G * GS;                                         // floats per channel
+  static_assert(PW % 4 == 0 && PW > PCG && GS % 4 == 0 && GX % 4 == 0 && GS >= PHG * PW, "patch strides");
+  constexpr int PS = G * GS + (G > 1 ? GX : 0) + (G > 2 ? GX : 0);   // floats per channel
   constexpr int P_FLOATS = CK * PS, V_FLOATS = W4_V_FLOATS;
   constexpr int NPOS = G * PHG * PCG, NSLOT = (NPOS + NT - 1) / NT;  // patch positions, positions per thread
   constexpr int DEAD = PCG;                                          // a word of row 0 that no transform reads (PW > PCG)
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
     }
     // BYTE offset from the source's base (the channel offset is scalar): element offsets < 2^30, host check
     p_off[sl] = inimg ? 4u * (unsigned)((long long)n * a.C0 * HW + (long long)fy * a.W + fx) : 0xffffffffu;   // C1 == C0 when there is a source 1
-    const int word = g * GS + r * PW + col;
+    const int word = goff(g) + r * PW + col;
     if constexpr (RAW) {
       p_lds[sl] = valid ? word : DEAD;           // an element outside the image loads as 0: stored like any other
     } else {
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
   int t_src, t_dst;
   {
     const int g = li / (GH * GW), ty = (li % (GH * GW)) / GW, tx = li % GW;
-    t_src = (2 * tp + lk) * PS + g * GS + (4 * ty + thalf) * PW + 4 * tx;
+    t_src = (2 * tp + lk) * PS + goff(g) + (4 * ty + thalf) * PW + 4 * tx;
     t_dst = (18 * thalf * CK + 2 * tp + lk) * W4_NT + li;               // V[(18 half + m)][channel][tile], m * 256 apart
   }
   f32x4 ra[5];
@@ -522,9 +525,9 @@ template <bool RAW, bool SUB, bool FULL>
 static void w4_launch_cfg(const W4Args& a, int cfg, dim3 grid, hipStream_t st) {
   // <G, GH, GW, PW, GS>: row strides chosen so that the b128 row reads of the transform spread over the 64 banks
   switch (cfg) {
-    case 0: hipLaunchKernelGGL((wino4_kernel<1, 4, 8, 40, 18 * 40, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((wino4_kernel<2, 4, 4, 20, 384, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
-    default: hipLaunchKernelGGL((wino4_kernel<8, 2, 2, 12, 10 * 12 + 8, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
+    case 0: hipLaunchKernelGGL((wino4_kernel<1, 4, 8, 40, 18 * 40, 0, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((wino4_kernel<2, 4, 4, 20, 384, 0, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL((wino4_kernel<8, 2, 2, 12, 120, 8, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
   }
 }
 
