@@ -616,6 +616,11 @@ int c3_fwd(const avsep_conv_desc* d, const float* wp, const float* bias, float* 
 int c3_dgrad(const avsep_conv_desc* d, const float* wp, const float* dy, float* dx, hipStream_t st);
 bool w3_applicable(const avsep_conv_desc* d);
 // wgrad_wino.hip: Winograd form of the 3x3 / stride 1 weight gradient, fp32
+// wgrad_wino4.hip: Winograd F(4x4, 3x3) weight gradient (asked before the F(2x2) form)
+bool x4_applicable(const avsep_conv_desc* d);
+size_t x4_workspace_floats(const avsep_conv_desc* d);
+int x4_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
+void x4_variant(const avsep_conv_desc* d, char* buf, size_t cap);
 bool ww_applicable(const avsep_conv_desc* d);
 size_t ww_workspace_floats(const avsep_conv_desc* d);
 int ww_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st);
@@ -951,6 +956,7 @@ extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {
   if (smallco_applicable(d)) return smallco_wgrad_workspace_floats(d) * sizeof(float);
   if (head_applicable(d)) return head_wgrad_workspace_floats(d) * sizeof(float);
   if (wbn_applicable(d)) return wbn_workspace_floats(d) * sizeof(float) + (size_t)2 * d->Cout * sizeof(double);
+  if (x4_applicable(d)) return x4_workspace_floats(d) * sizeof(float);
   if (ww_applicable(d)) return ww_workspace_floats(d) * sizeof(float);
   if (w4d_applicable(d)) return w4d_workspace_floats(d) * sizeof(float);
   if (w3_applicable(d)) return w3_workspace_floats(d) * sizeof(float);
@@ -976,8 +982,9 @@ extern "C" int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, flo
     double* acc = reinterpret_cast<double*>((float*)workspace + wbn_workspace_floats(d));   // behind the slabs (8-byte aligned: slab sizes are multiples of 64*64)
     return b16_channel_sum(dy, d->N, d->Cout, d->Ho * d->Wo, acc, dbias, (hipStream_t)stream);
   }
-  if (ww_applicable(d) || w4d_applicable(d) || w3_applicable(d) || scw_applicable(d)) {
-    int rc3 = ww_applicable(d) ? ww_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
+  if (x4_applicable(d) || ww_applicable(d) || w4d_applicable(d) || w3_applicable(d) || scw_applicable(d)) {
+    int rc3 = x4_applicable(d) ? x4_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
+              : ww_applicable(d) ? ww_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : w4d_applicable(d) ? w4d_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
               : w3_applicable(d) ? w3_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream)
                                  : scw_wgrad(d, dy, dw, (float*)workspace, (hipStream_t)stream);
@@ -1042,6 +1049,7 @@ extern "C" const char* avsep_conv_kernel_name(const avsep_conv_desc* d, int32_t 
   if (smallco_applicable(d)) return "smallco_wgrad";
   if (head_applicable(d)) return "head_wgrad_kernel";
   if (wbn_applicable(d)) return "wgradb_kernel";
+  if (x4_applicable(d)) return "winow4_kernel";
   if (ww_applicable(d)) return "winow_kernel";
   if (w4d_applicable(d)) return "wgrad4d_kernel";
   if (w3_applicable(d)) return "wgrad3x3_kernel";
@@ -1061,6 +1069,7 @@ extern "C" int avsep_conv_kernel_variant(const avsep_conv_desc* d, int32_t mode,
   if (!strcmp(fam, "convbf_kernel")) bf_variant(d, mode, tail, sizeof(tail));
   else if (!strcmp(fam, "wgradb_kernel")) wbn_variant(d, tail, sizeof(tail));
   else if (!strcmp(fam, "wino4_kernel")) w4_variant(d, mode, tail, sizeof(tail));
+  else if (!strcmp(fam, "winow4_kernel")) x4_variant(d, tail, sizeof(tail));
   else if (!strcmp(fam, "conv3x3_kernel")) {
     if (c3_applicable(d, mode)) c3_variant(d, mode, tail, sizeof(tail));
     else if (c4_applicable(d, mode)) c4_variant(d, mode, tail, sizeof(tail));

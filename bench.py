@@ -459,7 +459,7 @@ def add_traffic(roof, prec, B, config=3):
 
 
 # F(2x2, 3x3): 16 products per 2x2 tile instead of 36; F(4x4, 3x3): 36 per 4x4 tile instead of 144
-WINOGRAD_EXECUTED = {"wino_kernel": 4.0 / 9.0, "winow_kernel": 4.0 / 9.0, "wino4_kernel": 1.0 / 4.0}
+WINOGRAD_EXECUTED = {"wino_kernel": 4.0 / 9.0, "winow_kernel": 4.0 / 9.0, "wino4_kernel": 1.0 / 4.0, "winow4_kernel": 1.0 / 4.0}
 
 
 def roofline_of(kernels, prec, step_ms, B_total_per_gpu):

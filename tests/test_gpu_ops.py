@@ -94,6 +94,9 @@ CONV_CASES = [
     (72, 72, 18, 30, 72, 3, 1, 1, 1),      # H, W = 2 mod 4 on the 2x2-tile groups
     (260, 72, 14, 14, 72, 3, 1, 2, 2),     # dilation 2: the four 7x7 parity sub-images, one 2x2-tile group each (ResNet layer4)
     (80, 72, 28, 28, 72, 3, 1, 2, 2),      # dilation 2 at 28x28: 14x14 sub-images on the 4x4-tile groups
+    # wgrad_wino4.hip: Winograd F(4x4, 3x3) weight gradient (Cin % 32 == 0, maps that tile by 8x16 or 8x8 regions, >= 128 workgroups)
+    (48, 96, 32, 48, 80, 3, 1, 1, 1),      # one 8x16 region per K-tile, three input-channel blocks, ragged second output-channel tile
+    (26, 64, 24, 40, 72, 3, 1, 1, 1),      # two 8x8 regions per K-tile (W % 16 != 0), K-tiles that span two images, 49 splits
 ]
 
 
@@ -114,6 +117,8 @@ for _c in _rows_after((64, 64, 32, 32, 80, 3, 1, 1, 1), 4):
     EXPECT_MASK[_c] = ("winograd4",)
 for _c in _rows_after((40, 72, 32, 64, 80, 3, 1, 1, 1), 8):
     EXPECT_FAMILY[_c] = {"fwd": "wino4_kernel", "dgrad": "wino4_kernel"}
+EXPECT_FAMILY[(48, 96, 32, 48, 80, 3, 1, 1, 1)] = {"fwd": "wino4_kernel", "dgrad": "wino4_kernel", "wgrad": "winow4_kernel"}
+EXPECT_FAMILY[(26, 64, 24, 40, 72, 3, 1, 1, 1)] = {"wgrad": "winow4_kernel"}
 for _c in _rows_after((64, 64, 32, 32, 80, 4, 2, 1, 1), 3):
     EXPECT_FAMILY[_c] = {"wgrad": "wgrad4d_kernel"}
 for _c in _rows_after((3, 3, 32, 64, 72, 7, 2, 3, 1), 3) + [(2, 1, 32, 48, 24, 4, 2, 1, 1)]:
@@ -462,11 +467,19 @@ def test_b16_relu_up2x_and_stem_tail(dev, N, C0, C1, H, W):
     assert K.is_b16(s2d16) and torch.equal(K.to_f32(s2d16), s2d32.to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("N,family", [(32, "wino_kernel"), (64, "wino4_kernel")])
-def test_conv_virtual_input_winograd(dev, N, family):
-    """the same folded two-source input (C0 == C1) through the Winograd kernels' staging (conv_wino.hip at 128 workgroups,
-    conv_wino4.hip from 192), with the BatchNorm sums of the result."""
+@pytest.mark.parametrize("N,family,wfamily", [(32, "wino_kernel", "winow_kernel"), (64, "wino4_kernel", "winow4_kernel")])
+def test_conv_virtual_input_winograd(dev, N, family, wfamily):
+    """the same folded two-source input (C0 == C1) through the Winograd kernels' staging (conv_wino.hip / wgrad_wino.hip with
+    the F(4x4) kernels masked out, conv_wino4.hip / wgrad_wino4.hip otherwise), with the BatchNorm sums of the result."""
     K = _pkg().kernels
+    K.set_algo_mask(*(("winograd4",) if family == "wino_kernel" else ()))
+    try:
+        _virtual_input_winograd_case(dev, K, N, family, wfamily)
+    finally:
+        K.set_algo_mask()
+
+
+def _virtual_input_winograd_case(dev, K, N, family, wfamily):
     g = torch.Generator().manual_seed(11)
     C0, C1, Cout, H, W = 64, 64, 72, 32, 32
     x0, x1 = torch.randn(N, C0, H, W, generator=g), torch.randn(N, C1, H, W, generator=g)
@@ -482,7 +495,7 @@ def test_conv_virtual_input_winograd(dev, N, family):
     y_ref = y_ref.detach()
     t = lambda z: z.to(dev)
     cv = K.Conv(t(x0), Cout, 3, 1, 1, x1=t(x1), sc0=t(sc0), sh0=t(sh0), act0=2, sc1=t(sc1), sh1=t(sh1), act1=1)
-    assert cv.kernel_name("fwd", True) == family and cv.kernel_name("wgrad") == "winow_kernel"
+    assert cv.kernel_name("fwd", True) == family and cv.kernel_name("wgrad") == wfamily
     assert_close(cv.wgrad(t(dy))[0], wr.grad, 2e-5, "wgrad")
     st = K.zeros_stats(Cout, cv.like)
     assert_close(cv.fwd(cv.pack(t(w), 0), None, st), y_ref, 2e-5, "fwd")
