@@ -126,17 +126,18 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict
 // groups tile the four parity sub-images of a dilation-2 conv (a dilated 'same' conv is four independent undilated convs
 // over the pixels of equal row / column parity); FULL: H and W are multiples of 4 (whole tiles, 16-byte row stores) —
 // otherwise the last tile row / column of a (sub-)image is partial: its inputs load as zeros, its outputs are masked.
-// GX: extra words on the odd groups and on the groups with bit 1 set (g*GS + GX*(g&1) + GX*((g>>1)&1)): with eight 2x2-tile
-// groups no uniform group stride spreads the row reads of a 16-lane b128 access over all 64 banks (4-way conflicts measured).
+// GX: extra words in front of every second group and twice as many in front of every fourth (g*GS + GX*(g>>1) + 2*GX*(g>>2)):
+// with eight 2x2-tile groups no uniform group stride spreads the row reads of a 16-lane b128 access over all 64 banks (4-way
+// conflicts measured with a uniform stride of 128 words).
 template <int G, int GH, int GW, int PW, int GS, int GX, bool RAW, bool SUB, bool FULL>
 __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
   static_assert(!(SUB && FULL), "sub-image stores are strided");
-  auto goff = [](int g) __attribute__((always_inline)) { return g * GS + GX * (g & 1) + GX * ((g >> 1) & 1); };
+  auto goff = [](int g) __attribute__((always_inline)) { return g * GS + GX * (g >> 1) + 2 * GX * (g >> 2); };
   static_assert(G * GH * GW == W4_NT, "32 tiles per workgroup");
   constexpr int CK = W4_CK, BM = W4_BM, NT = W4_THREADS;
   constexpr int PHG = 4 * GH + 2, PCG = 4 * GW + 2;                 // patch of one group (valid elements)
   static_assert(PW % 4 == 0 && PW > PCG && GS % 4 == 0 && GX % 4 == 0 && GS >= PHG * PW, "patch strides");
-  constexpr int PS = G * GS + (G > 1 ? GX : 0) + (G > 2 ? GX : 0);   // floats per channel
+  constexpr int PS = G * GS + GX * ((G - 1) >> 1) + 2 * GX * ((G - 1) >> 2);   // floats per channel (= goff(G - 1) + GS)
   constexpr int P_FLOATS = CK * PS, V_FLOATS = W4_V_FLOATS;
   constexpr int NPOS = G * PHG * PCG, NSLOT = (NPOS + NT - 1) / NT;  // patch positions, positions per thread
   constexpr int DEAD = PCG;                                          // a word of row 0 that no transform reads (PW > PCG)
@@ -527,7 +528,7 @@ static void w4_launch_cfg(const W4Args& a, int cfg, dim3 grid, hipStream_t st) {
   switch (cfg) {
     case 0: hipLaunchKernelGGL((wino4_kernel<1, 4, 8, 40, 18 * 40, 0, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
     case 1: hipLaunchKernelGGL((wino4_kernel<2, 4, 4, 20, 384, 0, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
-    default: hipLaunchKernelGGL((wino4_kernel<8, 2, 2, 12, 120, 8, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL((wino4_kernel<8, 2, 2, 12, 120, 16, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
   }
 }
 
