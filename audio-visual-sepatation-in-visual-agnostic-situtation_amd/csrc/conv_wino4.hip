@@ -221,22 +221,24 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
   // ---- stage G / S: NSLOT * CK pieces per K-tile ----
   constexpr int NPC = NSLOT * CK;
   float praw[NPC];
-  auto g_issue = [&](int kt_, int pc) __attribute__((always_inline)) {
+  auto g_issue_to = [&](float* dst, int kt_, int pc) __attribute__((always_inline)) {
     const int kt = __builtin_amdgcn_readfirstlane(kt_);
     const int sl = pc / CK, cc = pc % CK;
     const bool src1 = kt >= kt_switch;
     const unsigned soff = (unsigned)((src1 ? kt - kt_switch : kt) * CK + cc) * 4u * (unsigned)HW;
-    praw[pc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src1 ? rs_x1 : rs_x0, (int)p_off[sl], (int)soff, 0));
+    dst[pc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src1 ? rs_x1 : rs_x0, (int)p_off[sl], (int)soff, 0));
   };
-  auto s_store = [&](int kt, int buf, int pc) __attribute__((always_inline)) {
+  auto g_issue = [&](int kt_, int pc) __attribute__((always_inline)) { g_issue_to(praw, kt_, pc); };
+  auto s_store_from = [&](const float* src, int kt, int buf, int pc) __attribute__((always_inline)) {
     const int sl = pc / CK, cc = pc % CK;
-    float v = praw[pc];
+    float v = src[pc];
     if constexpr (!RAW) {
       const f32x2 sa = *reinterpret_cast<const f32x2*>(aff + 2 * (kt * CK + cc));
       v = act_by_slope(fmaf(v, sa[0], sa[1]), kt >= kt_switch ? slope1 : slope0);
     }
     (Pb + buf * P_FLOATS + cc * PS)[p_lds[sl]] = v;
   };
+  auto s_store = [&](int kt, int buf, int pc) __attribute__((always_inline)) { s_store_from(praw, kt, buf, pc); };
 
   // ---- stage T: thread (half = wave & 1, channel = 2 * (wave >> 1) + lk, tile = li) ----
   int t_src, t_dst;
@@ -334,15 +336,24 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
   static_assert(NPC <= 36, "one S / G piece per MFMA slot");
 
   auto run = [&](auto half_) __attribute__((always_inline)) {
-    // prologue: G(0) S(0) | T(0), G(1) S(1) | then the loop's first trip needs V(0), P(1), praw = G(2), areg = A(0)
+    // prologue: G(0) G(1) S(0) S(1) | T(0) | then the loop's first trip needs V(0), P(1), praw = G(2), areg = A(0).
+    // The patches of K-tiles 0 and 1 are loaded together (the second set of registers is free: no accumulator lives yet):
+    // one memory round trip less in front of the first MFMA.
+    {
+      float praw1[NPC];
 #pragma unroll
-    for (int pc = 0; pc < NPC; ++pc) g_issue(0, pc);
+      for (int pc = 0; pc < NPC; ++pc) g_issue_to(praw, 0, pc);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) a_issue(0, c);
+      for (int pc = 0; pc < NPC; ++pc) g_issue_to(praw1, min(1, nK - 1), pc);
 #pragma unroll
-    for (int pc = 0; pc < NPC; ++pc) s_store(0, 0, pc);
+      for (int c = 0; c < 9; ++c) a_issue(0, c);
 #pragma unroll
-    for (int pc = 0; pc < NPC; ++pc) g_issue(min(1, nK - 1), pc);
+      for (int pc = 0; pc < NPC; ++pc) s_store_from(praw, 0, 0, pc);
+#pragma unroll
+      for (int pc = 0; pc < NPC; ++pc) g_issue_to(praw, min(2, nK - 1), pc);
+#pragma unroll
+      for (int pc = 0; pc < NPC; ++pc) s_store_from(praw1, min(1, nK - 1), 1, pc);
+    }
     lds_barrier();
 #pragma unroll
     for (int k = 0; k < 10; ++k) t_read(0, k);
@@ -350,10 +361,6 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
     for (int c = 0; c < 6; ++c) t_stage1(half_, c);
 #pragma unroll
     for (int i = 0; i < 3; ++i) t_stage2(0, i);
-#pragma unroll
-    for (int pc = 0; pc < NPC; ++pc) s_store(min(1, nK - 1), 1, pc);
-#pragma unroll
-    for (int pc = 0; pc < NPC; ++pc) g_issue(min(2, nK - 1), pc);
     lds_barrier();
     ktile(0, std::integral_constant<int, 0>{}, std::true_type{}, half_);
     if (nK > 1) ktile(1, std::integral_constant<int, 1>{}, std::false_type{}, half_);
