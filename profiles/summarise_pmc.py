@@ -29,7 +29,7 @@ def per_kernel(directory):
 def family(name):
     if "convbf_res_kernel" in name:          # the resident-weights form is reported under its family (avsep_conv_kernel_name: convbf_kernel)
         return "convbf_kernel"
-    for key in ("winow_kernel", "wino_kernel", "convbf_kernel", "wgradb_reduce_kernel", "wgradb_kernel", "wgradbf_kernel", "wgrad4bf_kernel", "wgrad4d_kernel", "smallci_wgrad_kernel",
+    for key in ("winow4_kernel", "wino4_kernel", "winow_kernel", "wino_kernel", "convbf_kernel", "wgradb_reduce_kernel", "wgradb_kernel", "wgradbf_kernel", "wgrad4bf_kernel", "wgrad4d_kernel", "smallci_wgrad_kernel",
                 "conv3x3_kernel", "wgrad3x3_kernel", "head_fwd_kernel", "head_wgrad_kernel", "affine_act_kernel", "maxpool_fwd4_kernel",
                 "head_dgrad_kernel", "smallco_fwd", "smallco_wgrad", "smallci_dgrad", "relu_up2x_fwd",
                 "relu_up2x_bwd", "bn_bwd_apply_kernel", "affine_act_bwd_kernel", "sgd_kernel", "w3_reduce_kernel"):
@@ -73,7 +73,7 @@ def main():
     dst = sys.argv[6] if len(sys.argv) > 6 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
-    for k in ("wino_kernel", "winow_kernel", "conv3x3_kernel", "convbf_kernel", "wgradbf_kernel"):
+    for k in ("wino4_kernel", "winow4_kernel", "wino_kernel", "winow_kernel", "conv3x3_kernel", "convbf_kernel", "wgradb_kernel"):
         if k in out["kernels"]:
             print(k, json.dumps(out["kernels"][k]))
 
