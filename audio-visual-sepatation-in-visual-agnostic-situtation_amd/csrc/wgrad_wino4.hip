@@ -67,7 +67,12 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   float* const Ps = Vs + X4_V_FLOATS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lk = lane >> 5;
-  const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
+  // 1-D grid, XCD-aware: the gridM * gridC workgroups of one K-split read the same pixels (dY is shared by the gridC input-
+  // channel blocks, the input patch by the gridM output-channel blocks); under round-robin dispatch they would land on eight
+  // different XCDs and every L2 would fetch those pixels again — consecutive LOGICAL ids share an XCD instead
+  const int t_ = xcd_remap(blockIdx.x, gridDim.x), per_split = a.gridM * a.gridC;
+  const int split = t_ / per_split, lin_ = t_ % per_split;
+  const int mt = lin_ % a.gridM, ct = lin_ / a.gridM;
   const int m0 = mt * BCO, c0 = ct * BCI;
   const int HW = a.H * a.W;
   const bool src1 = c0 >= a.C0;                 // the 32-channel input block lies in one source
@@ -464,7 +469,7 @@ int x4_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
   a.dy = dy; a.out = ws;
   const bool raw = !d->scale0 && !d->scale1 && d->act0 == AVSEP_ACT_NONE && (a.C1 == 0 || d->act1 == AVSEP_ACT_NONE);
-  dim3 grid((unsigned)(p.gridM * p.gridC), (unsigned)p.splits);
+  dim3 grid((unsigned)(p.gridM * p.gridC * p.splits));
   // <G, RH, RW, PW, GS, PS>
   if (p.cfg == 0) {
     if (raw) hipLaunchKernelGGL((winow4_kernel<1, 2, 4, 20, 200, 204, true>), grid, dim3(X4_THREADS), 0, st, a);

@@ -11,8 +11,8 @@
  *     dense fp32 NCHW unless stated; the caller owns all buffers incl. workspaces;
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous;
  *   - return value: 0 = ok, negative = error (avsep_strerror()).
- *   - the library keeps no mutable global state and is re-entrant per stream; the only process state is a set of
- *     AVSEP_* environment switches (A/B and tuning overrides), each read ONCE into a function-local static.
+ *   - the library keeps no mutable global state, reads no environment variable and is re-entrant per stream; what steers
+ *     the dispatch of a convolution call (A/B and tuning overrides) travels in its descriptor (avsep_conv_desc.algo / .tune).
  */
 #ifndef AVSEP_H
 #define AVSEP_H

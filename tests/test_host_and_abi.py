@@ -30,6 +30,21 @@ def test_library_exports_every_declared_symbol():
     assert L.avsep_strerror(-1).startswith(b"invalid argument")
 
 
+def test_library_reads_no_environment_variable():
+    """include/avsep.h: "reads no environment variable".  The shared library must not even import getenv / secure_getenv /
+    environ: every dispatch override travels in avsep_conv_desc.algo / .tune (the host layer reads AVSEP_ALGO_NO in Python),
+    and the descriptor carries both fields."""
+    import subprocess
+    P = _pkg()
+    out = subprocess.run(["nm", "-D", "--undefined-only", P.lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    bad = [l for l in out.splitlines() if re.search(r"\b(secure_)?getenv\b|\benviron\b", l)]
+    assert not bad, bad
+    names = [n for n, _ in P.lib.ConvDesc._fields_]
+    assert names[22:24] == ["algo", "tune"] and P.lib.ALGO_NO["winograd4"] == 64
+    K = P.kernels
+    assert K.set_algo_mask("winograd", "flat") == 5 and K.set_algo_mask() == 0
+
+
 def test_every_entry_point_rejects_null_and_zero_arguments():
     """Error behaviour at the boundary: an int-returning entry point handed null pointers, empty descriptors and zero sizes
     returns AVSEP_ERR_ARG before anything is launched (this runs without a GPU)."""
