@@ -74,7 +74,11 @@ __global__ __launch_bounds__(WW_THREADS) void winow_kernel(WwArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
   const int wi = wave & 3, wcb = wave >> 2;
-  const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
+  // 1-D grid, XCD-aware (round 5): the gridM * gridC workgroups of one K-split read the same pixels; consecutive LOGICAL ids
+  // share an XCD, so those pixels are fetched into one L2 instead of eight (wgrad_wino4.hip: -10 % on the 256 -> 64 layer)
+  const int t_ = xcd_remap(blockIdx.x, gridDim.x), per_split_ = a.gridM * a.gridC;
+  const int split = t_ / per_split_, lin_ = t_ % per_split_;
+  const int mt = lin_ % a.gridM, ct = lin_ / a.gridM;
   const int m0 = mt * B, c0 = ct * B;
   const int iHW = a.H * a.W;
   // the 64-channel input block lies in one source
@@ -401,7 +405,11 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad4d_kernel(W4dArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
   const int wi = wave & 3, wcb = wave >> 2;
-  const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
+  // 1-D grid, XCD-aware (round 5): the gridM * gridC workgroups of one K-split read the same pixels; consecutive LOGICAL ids
+  // share an XCD, so those pixels are fetched into one L2 instead of eight (wgrad_wino4.hip: -10 % on the 256 -> 64 layer)
+  const int t_ = xcd_remap(blockIdx.x, gridDim.x), per_split_ = a.gridM * a.gridC;
+  const int split = t_ / per_split_, lin_ = t_ % per_split_;
+  const int mt = lin_ % a.gridM, ct = lin_ / a.gridM;
   const int m0 = mt * B, c0 = ct * B;
   const long long HW = (long long)a.H * a.W, HWo = (long long)a.Ho * a.Wo;
   const int iHW = a.H * a.W, iHWo = a.Ho * a.Wo;
@@ -667,7 +675,7 @@ int ww_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
   a.dy = dy; a.out = ws;
   const bool raw = !d->scale0 && !d->scale1 && d->act0 == AVSEP_ACT_NONE && (a.C1 == 0 || d->act1 == AVSEP_ACT_NONE);
-  dim3 grid((unsigned)(p.gridM * p.gridC), (unsigned)p.splits);
+  dim3 grid((unsigned)(p.gridM * p.gridC * p.splits));
   const bool sub = d->dil == 2;
   if (sub && raw) ww_launch_cfg<true, true>(a, p.cfg, grid, st);
   else if (sub) ww_launch_cfg<true, false>(a, p.cfg, grid, st);
@@ -729,7 +737,7 @@ int w4d_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, h
   a.gridM = p.gridM; a.gridC = p.gridC; a.act0 = d->act0;
   a.x0 = d->x0; a.sc0 = d->scale0; a.sh0 = d->shift0; a.dy = dy; a.out = ws;
   const bool raw = !d->scale0 && d->act0 == AVSEP_ACT_NONE;
-  dim3 grid((unsigned)(p.gridM * p.gridC), (unsigned)p.splits);
+  dim3 grid((unsigned)(p.gridM * p.gridC * p.splits));
 #define W4D_LAUNCH(G_, GH_, GW_)                                                                               \
   do {                                                                                                       \
     if (raw) hipLaunchKernelGGL((wgrad4d_kernel<G_, GH_, GW_, true>), grid, dim3(WW_THREADS), 0, st, a);      \
