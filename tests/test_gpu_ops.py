@@ -94,9 +94,9 @@ CONV_CASES = [
     (72, 72, 18, 30, 72, 3, 1, 1, 1),      # H, W = 2 mod 4 on the 2x2-tile groups
     (260, 72, 14, 14, 72, 3, 1, 2, 2),     # dilation 2: the four 7x7 parity sub-images, one 2x2-tile group each (ResNet layer4)
     (80, 72, 28, 28, 72, 3, 1, 2, 2),      # dilation 2 at 28x28: 14x14 sub-images on the 4x4-tile groups
-    # wgrad_wino4.hip: Winograd F(4x4, 3x3) weight gradient (Cin % 32 == 0, maps that tile by 8x16 or 8x8 regions, >= 128 workgroups)
-    (48, 96, 32, 48, 80, 3, 1, 1, 1),      # one 8x16 region per K-tile, three input-channel blocks, ragged second output-channel tile
-    (26, 64, 24, 40, 72, 3, 1, 1, 1),      # two 8x8 regions per K-tile (W % 16 != 0), K-tiles that span two images, 49 splits
+    # wgrad_wino4.hip: Winograd F(4x4, 3x3) weight gradient (Cin % 32 == 0, maps that tile by 8x8 regions, >= 128 workgroups)
+    (48, 96, 32, 48, 80, 3, 1, 1, 1),      # three input-channel blocks, ragged second output-channel tile, 14 regions per split
+    (26, 64, 24, 40, 72, 3, 1, 1, 1),      # 3 x 5 regions per image, 7 regions per split (splits cross images), odd step counts
 ]
 
 
