@@ -339,7 +339,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_kernel(W3Args a) {
   float (*As)[BM * LDA] = reinterpret_cast<float (*)[BM * LDA]>(smem + 2 * W3_CC * PS);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
-  const int mt = blockIdx.x % a.gridM, ct = blockIdx.x / a.gridM, split = blockIdx.y;
+  // 1-D grid, XCD-aware (round 5): the workgroups of one K-split read the same pixels and share an L2
+  const int t_ = xcd_remap(blockIdx.x, gridDim.x), per_split_ = a.gridM * a.gridC;
+  const int split = t_ / per_split_, lin_ = t_ % per_split_;
+  const int mt = lin_ % a.gridM, ct = lin_ / a.gridM;
   const int m0 = mt * BM, c0 = ct * W3_CC;
   const int tiles_img = a.tilesX * a.tilesY, tiles_all = tiles_img * a.N;
   const int t_begin = split * a.tiles_per_split, t_end = min(tiles_all, t_begin + a.tiles_per_split);
@@ -593,7 +596,7 @@ int w3_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
   a.dy = dy; a.out = p.splits > 1 ? ws : dw; a.tapmajor = p.splits > 1;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.gridM = p.gridM; a.gridC = p.gridC; a.tiles_per_split = p.tps;
-  dim3 grid(p.gridM * p.gridC, p.splits);
+  dim3 grid(p.gridM * p.gridC * p.splits);
 #define W3_LAUNCH(TH_, TW_, UP_, DIL_, A2_)                                                                            \
   do {                                                                                                                 \
     if (d->Cout <= 64) hipLaunchKernelGGL((wgrad3x3_kernel<TH_, TW_, UP_, 64, DIL_, A2_>), grid, dim3(512), 0, st, a);  \

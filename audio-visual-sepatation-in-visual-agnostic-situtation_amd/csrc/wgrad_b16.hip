@@ -35,7 +35,7 @@ struct WbArgs {
   const float* sh;
   int act;
   int N, Cin, H, W, Cout, Ho, Wo, pad;
-  int tilesX, tilesY, chunks, per_split, gridCi;
+  int tilesX, tilesY, chunks, per_split, gridCi, gridCo;
   float* out;
   long long slab;
   int CoutP, CinP;
@@ -74,7 +74,11 @@ __global__ __launch_bounds__(KH * KW > 1 ? 512 : 256) void wgradb_kernel(WbArgs 
   unsigned char* const Ys = smem + 4 * XPL;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
-  const int cot = blockIdx.x / a.gridCi, cit = blockIdx.x % a.gridCi;
+  // 1-D grid, XCD-aware (round 5): the gco * gci workgroups of one K-split read the same pixels; consecutive LOGICAL ids
+  // share an XCD, so those pixels reach one L2 instead of eight
+  const int t_ = xcd_remap(blockIdx.x, gridDim.x), per_split_ = a.gridCo * a.gridCi;
+  const int zsplit = t_ / per_split_, lin_ = t_ % per_split_;
+  const int cot = lin_ / a.gridCi, cit = lin_ % a.gridCi;
   const int CBi = a.Cin >> 4, CBo = a.Cout >> 4;
   const float slope = act_slope(a.act);
   const bool has_aff = !RAW && a.sc != nullptr;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(KH * KW > 1 ? 512 : 256) void wgradb_kernel(WbArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const int c_beg = blockIdx.z * a.per_split, c_end = min(a.chunks, c_beg + a.per_split);
+  const int c_beg = zsplit * a.per_split, c_end = min(a.chunks, c_beg + a.per_split);
   if (c_beg < c_end) issue(c_beg);
   for (int c = c_beg; c < c_end; ++c) {
     __syncthreads();                         // every wave is done reading the previous chunk
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(KH * KW > 1 ? 512 : 256) void wgradb_kernel(WbArgs 
   }
 
   // ---- partial slab [tap][CoutP][CinP]: C/D map col = lane & 31 (ci), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (co) ----------
-  float* const op = a.out + (long long)blockIdx.z * a.slab;
+  float* const op = a.out + (long long)zsplit * a.slab;
   const int li = lane & 31, lk = lane >> 5;
   const int ci = cit * 64 + wn * 32 + li;
 #pragma unroll
@@ -412,7 +416,7 @@ void wbn_variant(const avsep_conv_desc* d, char* buf, size_t cap) {
 
 template <int KH, int KW, int S, int DIL>
 static int wbn_launch(WbArgs& a, const WbPlan& p, bool raw, hipStream_t st) {
-  dim3 grid(p.gco * p.gci, 1, p.splits);
+  dim3 grid(p.gco * p.gci * p.splits);
   constexpr int THW = KH * KW == 16 ? 2 : S == 2 ? 4 : 8, THN = KH * KW == 16 ? 4 : S == 2 ? 8 : 16;
 #define WB_L(TH_, TW_)                                                                                                    \
   do {                                                                                                                    \
@@ -431,7 +435,7 @@ int wbn_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, h
   WbArgs a{};
   a.x = (const u32x4*)d->x0; a.dy = (const u32x4*)dy; a.sc = d->scale0; a.sh = d->shift0; a.act = d->act0;
   a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Ho = d->Ho; a.Wo = d->Wo; a.pad = d->pad;
-  a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.chunks = p.chunks; a.per_split = p.per_split; a.gridCi = p.gci;
+  a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.chunks = p.chunks; a.per_split = p.per_split; a.gridCi = p.gci; a.gridCo = p.gco;
   a.out = ws; a.CoutP = p.CoutP; a.CinP = p.CinP;
   a.slab = (long long)d->KH * d->KW * p.CoutP * p.CinP;
   const bool raw = d->scale0 == nullptr && d->act0 == AVSEP_ACT_NONE;
