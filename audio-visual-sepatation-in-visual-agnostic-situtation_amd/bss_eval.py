@@ -42,7 +42,10 @@ def _solve(R, D, B, S, E, flen, mode):
         srcs = list(range(S)) if mode == 0 else [s % S]
         G = _gram(R, b, srcs, flen).cpu()
         rhs = (D[b].reshape(E, S * flen).t() if mode == 0 else D[b, s % S, s % S].reshape(flen, 1)).cpu()
-        C[s] = torch.linalg.lstsq(G, rhs).solution.to(C.device)
+        # driver gelsd = numpy.linalg.lstsq's (what mir_eval falls back to).  torch's CPU default, gelsy, returned wrong
+        # minimum-norm solutions for this exactly rank-deficient system on some calls (errors of 0.2-0.9 in the filters on a
+        # 128-thread host, 1e-16 on others: scratch probe of round 5); gelsd / gelss / an eigendecomposition agree to 3e-15
+        C[s] = torch.linalg.lstsq(G, rhs.contiguous(), driver="gelsd").solution.to(C.device)
     return C
 
 
