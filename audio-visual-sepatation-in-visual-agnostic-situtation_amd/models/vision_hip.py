@@ -15,8 +15,6 @@ Backward mirrors it with the BatchNorm backward folded as dy = p*dz + q*y + r (s
 modules in ``net.features`` / ``net.fc`` stay the parameter and running-statistics holders, so checkpoints and the
 optimizer see the same tensors whichever backend runs.
 """
-import os
-
 import torch
 
 from .. import kernels as K
@@ -123,18 +121,17 @@ def stem_forward(f, x, training):
     return S, z
 
 
-FOLD_BN1_F32 = os.environ.get("AVSEP_FOLD_BN1_F32", "0") != "0"      # experiment switch (round 5): fold bn1 + ReLU into conv2's staging in fp32 too
-
-
 def block_forward(blk, z, training):
     """One BasicBlock on a materialised post-ReLU input z -> (saved record, z')."""
     R = {"mod": blk, "z": z}
     R["cv1"], R["y1"], R["bn1"] = _conv_bn(z, blk.conv1, blk.bn1, training)
-    if K.get_precision() == "f32" and not FOLD_BN1_F32:
+    if K.get_precision() == "f32":
         # fp32: relu(bn1(y1)) is written out once (one elementwise pass) and conv2 reads it as a plain tensor.  Folding the
         # affine + ReLU into conv2's staging costs vector instructions in its forward AND its weight gradient, and the f32
         # MFMA does not overlap them (SQ: 8-11 VALU per MFMA against 4.5-5.5 for the plain-input instantiations of the
         # Winograd kernels): 109.9 -> 109.0 ms per step.  With bf16 operands the fold is free (47.2 vs 47.7 ms): kept there.
+        # (Round 5, with the F(4x4) kernels: folding costs them +9-11 % per call and saves this pass — same-box A/B of the
+        # whole step 78.1 / 79.4 ms materialised against 78.6 / 78.7 folded: a wash, the materialised form stays.)
         a1 = K.affine_act(R["y1"], R["bn1"][0], R["bn1"][1], None, ACT_RELU)
         R["cv2"], R["y2"], R["bn2"] = _conv_bn(a1, blk.conv2, blk.bn2, training)
     else:
