@@ -35,7 +35,8 @@ constexpr int X4_THREADS = 512;
 
 struct X4Args {
   int N, C0, C1, Cin, H, W, Cout;
-  int ryn, rxn;                                 // 8x8 regions per image along y / x
+  int ryn, rxn;                                 // 8x8 regions per image (per parity sub-map) along y / x
+  int dil, Hs, Ws;                              // GEN: dilation (1 | 2) and the size of a parity sub-map (H / dil, W / dil)
   int nkt, kps;                                 // regions in total / per split
   int gridM, gridC, act0, act1;
   const float *x0, *x1, *sc0, *sh0, *sc1, *sh1;
@@ -50,7 +51,12 @@ constexpr int X4P_PW = 12, X4P_PS = 124;        // patch 10 x 10 in rows of 12; 
 constexpr int X4P_P_FLOATS = X4_BCI * X4P_PS;   // 3968
 constexpr int X4P_KPS_MAX = 512;                // regions of one split (origin records in LDS)
 
-template <bool RAW>
+// GEN: maps the 8x8 regions do not divide (28x28, 14x14) and dilation 2 (= four parity sub-maps of H/2 x W/2, each a
+// dilation-1 problem on pixels 2 apart).  A region's record carries a third word, the VALID rows | columns of its 10x10
+// patch as bit masks; every patch piece and every dY element tests its own (row bit | column bit) against it and loads
+// through the out-of-range offset (= 0) when it is outside the map.  GEN 1: dilation 1 and W even — dY in 8-byte pairs
+// (a pair is inside or outside together); GEN 2: anything else, dY element by element.
+template <bool RAW, int GEN>
 __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   constexpr int NT = X4_THREADS, BCO = X4_BCO, BCI = X4_BCI, PW = X4P_PW, PS = X4P_PS, YCO = X4P_YCO;
   constexpr int NIS = BCI * 64 / NT;            // interior pieces per thread: 4
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   constexpr int BUF = X4P_Y_FLOATS + X4P_V_FLOATS + X4P_P_FLOATS;
   static_assert(2 * BUF >= 36 * 16 * 32, "epilogue exchange fits");
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
-  __shared__ unsigned gtab[X4P_KPS_MAX][2];     // per region: {byte offset of its origin in x | border bits, byte offset in dy}
+  __shared__ unsigned gtab[X4P_KPS_MAX][GEN ? 3 : 2];   // per region: {byte offset of its origin in x | border bits, byte offset in dy, GEN: valid rows | columns << 10}
   __shared__ f32x2 aff[BCI];
   auto Yb = [&](int b) __attribute__((always_inline)) { return smem + b * BUF; };
   auto Vb = [&](int b) __attribute__((always_inline)) { return smem + b * BUF + X4P_Y_FLOATS; };
@@ -76,8 +82,22 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   const float slope = act_slope(src1 ? a.act1 : a.act0);
   const int kt0 = split * a.kps, nk = min(a.kps, a.nkt - kt0);
 
+  const int D = GEN ? a.dil : 1;
   {
     const int per = a.ryn * a.rxn;
+    if constexpr (GEN) {
+      const int pper = D * D * per;
+      for (int k = tid; k < nk; k += NT) {
+        const int reg = kt0 + k, img = reg / pper, rem = reg % pper, par = rem / per;
+        const int ry = (rem % per) / a.rxn, rx = rem % a.rxn, py = par / D, px = par % D;
+        const int y0 = ry * 8, x0 = rx * 8, pix = (D * y0 + py) * a.W + D * x0 + px;
+        const int vr9 = min(9, a.Hs - y0), vc9 = min(9, a.Ws - x0);       // last valid patch row / column
+        const unsigned rm = ((2u << vr9) - 1u) & ~(y0 == 0 ? 1u : 0u), cm = ((2u << vc9) - 1u) & ~(x0 == 0 ? 1u : 0u);
+        gtab[k][0] = 4u * (unsigned)((img * Cs + cs0) * HW + pix);
+        gtab[k][1] = 4u * (unsigned)((img * a.Cout + m0) * HW + pix);
+        gtab[k][2] = rm | (cm << 10);
+      }
+    } else
     for (int k = tid; k < nk; k += NT) {
       const int reg = kt0 + k, img = reg / per, ry = (reg % per) / a.rxn, rx = reg % a.rxn;
       const int y0 = ry * 8, x0 = rx * 8;
@@ -98,12 +118,13 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
 
   // ---- patch pieces: interior element e = tid + 512 sl -> channel (tid >> 6) + 8 sl, pixel tid & 63 (one lane offset, one
   //      LDS word); halo ring element e -> channel e / 36, ring position e % 36 ----
-  unsigned i_off;
+  unsigned i_off, i_pm;                         // (GEN) i_pm / h_cls: the piece's row bit | column bit << 10
   int i_lds;
   {
     const int ci = tid >> 6, pos = tid & 63, iy = pos >> 3, ix = pos & 7;
-    i_off = 4u * (unsigned)(ci * HW + (iy + 1) * a.W + ix + 1);
+    i_off = 4u * (unsigned)(ci * HW + D * ((iy + 1) * a.W + ix + 1));
     i_lds = ci * PS + (iy + 1) * PW + ix + 1;
+    i_pm = (1u << (iy + 1)) | (1u << (10 + ix + 1));
   }
   unsigned h_off[NHS], h_cls[NHS];
   int h_lds[NHS], h_ci[NHS];
@@ -115,24 +136,32 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
     if (hh < 10) { r = 0; col = hh; }
     else if (hh < 20) { r = 9; col = hh - 10; }
     else { const int k = hh - 20; r = 1 + (k & 7); col = (k >> 3) ? 9 : 0; }
-    h_off[sl] = 4u * (unsigned)(ci * HW + r * a.W + col);
+    h_off[sl] = 4u * (unsigned)(ci * HW + D * (r * a.W + col));
     h_lds[sl] = e < BCI * NH ? ci * PS + r * PW + col : -1;
-    h_cls[sl] = e < BCI * NH ? (unsigned)((r == 0) | ((r == 9) << 1) | ((col == 0) << 2) | ((col == 9) << 3)) : 0x10u;
+    if constexpr (GEN) h_cls[sl] = e < BCI * NH ? (1u << r) | (1u << (10 + col)) : 1u << 20;
+    else h_cls[sl] = e < BCI * NH ? (unsigned)((r == 0) | ((r == 9) << 1) | ((col == 0) << 2) | ((col == 9) << 3)) : 0x10u;
     h_ci[sl] = ci;
   }
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xs - (a.W + 1)), 0, 0xfffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xs - D * (a.W + 1)), 0, 0xfffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, 0xfffffff0, 0x00020000);
 
   float iraw[NIS], hraw[NHS];
-  bool hinv[NHS];
-  auto g_interior = [&](unsigned xrec, int sl) __attribute__((always_inline)) {
-    const unsigned so = (xrec & ~31u) + (unsigned)sl * 32u * (unsigned)HW;                      // + 8 channels per slot
-    iraw[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)i_off, (int)so, 0));
+  bool hinv[NHS], iinv[NIS];
+  auto g_interior = [&](unsigned xrec, unsigned srec, int sl) __attribute__((always_inline)) {
+    if constexpr (GEN) {
+      const bool inv = (i_pm & srec) != i_pm;
+      const unsigned off = inv ? 0xffffffffu : i_off;
+      iraw[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, (int)(xrec + (unsigned)sl * 32u * (unsigned)HW), 0));
+      iinv[sl] = inv;
+    } else {
+      const unsigned so = (xrec & ~31u) + (unsigned)sl * 32u * (unsigned)HW;                    // + 8 channels per slot
+      iraw[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)i_off, (int)so, 0));
+    }
   };
-  auto g_halo = [&](unsigned xrec, int sl) __attribute__((always_inline)) {
-    const bool inv = (h_cls[sl] & ((xrec & 15u) | 0x10u)) != 0u;
+  auto g_halo = [&](unsigned xrec, unsigned srec, int sl) __attribute__((always_inline)) {
+    const bool inv = GEN ? (h_cls[sl] & srec) != h_cls[sl] : (h_cls[sl] & ((xrec & 15u) | 0x10u)) != 0u;
     const unsigned off = inv ? 0xffffffffu : h_off[sl];
-    hraw[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, (int)(xrec & ~31u), 0));
+    hraw[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, (int)(GEN ? xrec : xrec & ~31u), 0));
     hinv[sl] = inv;
   };
   auto s_interior = [&](int b, int sl) __attribute__((always_inline)) {
@@ -140,6 +169,7 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
     if constexpr (!RAW) {
       const f32x2 sa = aff[(tid >> 6) + 8 * sl];
       v = act_by_slope(fmaf(v, sa[0], sa[1]), slope);
+      if constexpr (GEN) v = iinv[sl] ? 0.f : v;
     }
     Pb(b)[i_lds + sl * 8 * PS] = v;
   };
@@ -154,17 +184,53 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   };
   auto xrec_of = [&](int k) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)gtab[k][0]); };
   auto yrec_of = [&](int k) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)gtab[k][1]); };
+  auto srec_of = [&](int k) __attribute__((always_inline)) { return GEN ? (unsigned)__builtin_amdgcn_readfirstlane((int)gtab[k][GEN ? 2 : 0]) : 0u; };
 
   // ---- dY role (waves 0-3): output channel tid >> 2, tile tid & 3 = (ty, tx) ----
   const bool yrole = wave < 4;
   const int y_co = (tid >> 2) & 63, y_tile = tid & 3;
-  const unsigned y_off = (m0 + y_co < a.Cout) ? 4u * (unsigned)(y_co * HW + 4 * (y_tile >> 1) * a.W + 4 * (y_tile & 1)) : 0xffffffffu;
+  const unsigned y_off = (m0 + y_co < a.Cout) ? 4u * (unsigned)(y_co * HW + D * (4 * (y_tile >> 1) * a.W + 4 * (y_tile & 1))) : 0xffffffffu;
+  const int y_rsh = 4 * (y_tile >> 1) + 1, y_csh = 10 + 4 * (y_tile & 1) + 1;   // (GEN) the tile's rows / columns in the region's masks
   const int y_dst = y_tile * YCO + y_co;        // Yh4[xi][tile][co]: + xi * 4 * 72
   f32x4 dyr[4];
-  auto y_issue = [&](unsigned yrec) __attribute__((always_inline)) {
+  auto y_issue = [&](unsigned yrec, unsigned srec) __attribute__((always_inline)) {
+    if constexpr (GEN == 1) {
+      // pair (r, p) = columns 2p, 2p + 1 of row r: valid when row bit r and column bit 2p of the tile are
+      const unsigned rsel = (srec >> y_rsh) & 15u, csel = (srec >> y_csh) & 15u, psel = (csel & 1u) | ((csel >> 1) & 2u);
+      unsigned m8 = 0u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      dyr[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y_off, (int)(yrec + (unsigned)(r * 4) * (unsigned)a.W), 0));
+      for (int r = 0; r < 4; ++r) m8 |= (0u - ((rsel >> r) & 1u)) & (psel << (2 * r));
+      const unsigned nm = ~m8;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const unsigned t = (unsigned)((int)(nm << (31 - (2 * r + pp))) >> 31);               // all ones when invalid
+          const f32x2 v2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_dy, (int)(y_off | t),
+                                                                                          (int)(yrec + 4u * (unsigned)(r * a.W + 2 * pp)), 0));
+          dyr[r][2 * pp] = v2[0];
+          dyr[r][2 * pp + 1] = v2[1];
+        }
+    } else if constexpr (GEN == 2) {
+      // element (r, c) is valid when row bit r and column bit c of the tile are: nm = ~(16 bits, row-major)
+      const unsigned rsel = (srec >> y_rsh) & 15u, csel = (srec >> y_csh) & 15u;
+      unsigned m16 = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m16 |= (0u - ((rsel >> r) & 1u)) & (csel << (4 * r));
+      const unsigned nm = ~m16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned t = (unsigned)((int)(nm << (31 - (4 * r + c))) >> 31);            // all ones when invalid
+          dyr[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, (int)(y_off | t),
+                                                                                     (int)(yrec + 4u * (unsigned)D * (unsigned)(r * a.W + c)), 0));
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dyr[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)y_off, (int)(yrec + (unsigned)(r * 4) * (unsigned)a.W), 0));
+    }
   };
 #define X4_A6(Y0, Y1, Y2, Y3, O0, O1, O2, O3, O4, O5)                        \
   do {                                                                       \
@@ -257,8 +323,8 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   auto step = [&](int j, auto buf_, auto role_) __attribute__((always_inline)) {
     constexpr int buf = decltype(buf_)::value;
     constexpr int ROLE = decltype(role_)::value;            // 0: dY transform, 1 / 2: input transform half 0 / 1
-    const unsigned xr3 = xrec_of(min(j + 3, nk - 1));
-    const unsigned yr2 = ROLE == 0 ? yrec_of(min(j + 2, nk - 1)) : 0u;
+    const unsigned xr3 = xrec_of(min(j + 3, nk - 1)), sr3 = srec_of(min(j + 3, nk - 1));
+    const unsigned yr2 = ROLE == 0 ? yrec_of(min(j + 2, nk - 1)) : 0u, sy2 = ROLE == 0 ? srec_of(min(j + 2, nk - 1)) : 0u;
     const float* Yr = Yb(buf) + a_lane;
     const float* Vr = Vb(buf) + b_lane;
     float av[18], bv[18];
@@ -277,14 +343,14 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
       }
       if (m < NIS) {
         s_interior(buf, m);
-        g_interior(xr3, m);
+        g_interior(xr3, sr3, m);
       } else if (m < NIS + NHS) {
         s_halo(buf, m - NIS);
-        g_halo(xr3, m - NIS);
+        g_halo(xr3, sr3, m - NIS);
       }
       if constexpr (ROLE == 0) {
         if (m < 4) y_stage1(m);
-        if (m == 4) y_issue(yr2);
+        if (m == 4) y_issue(yr2, sy2);
         if (m >= 5 && m < 17 && ((m - 5) & 1) == 0) y_stage2(buf ^ 1, (m - 5) >> 1);
       } else {
         if (m < 5) { v_read(buf ^ 1, 2 * m); v_read(buf ^ 1, 2 * m + 1); }
@@ -301,25 +367,26 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
     // prologue: patches of regions 0 and 1 -> LDS, pieces of region 2 and the dY rows of region 0 (then 1) in flight, T(0)
     {
       const unsigned x0r = xrec_of(0), x1r = xrec_of(min(1, nk - 1)), x2r = xrec_of(min(2, nk - 1));
+      const unsigned s0r = srec_of(0), s1r = srec_of(min(1, nk - 1)), s2r = srec_of(min(2, nk - 1));
 #pragma unroll
-      for (int sl = 0; sl < NIS; ++sl) g_interior(x0r, sl);
+      for (int sl = 0; sl < NIS; ++sl) g_interior(x0r, s0r, sl);
 #pragma unroll
-      for (int sl = 0; sl < NHS; ++sl) g_halo(x0r, sl);
-      if constexpr (ROLE == 0) y_issue(yrec_of(0));
+      for (int sl = 0; sl < NHS; ++sl) g_halo(x0r, s0r, sl);
+      if constexpr (ROLE == 0) y_issue(yrec_of(0), s0r);
 #pragma unroll
-      for (int sl = 0; sl < NIS; ++sl) { s_interior(0, sl); g_interior(x1r, sl); }
+      for (int sl = 0; sl < NIS; ++sl) { s_interior(0, sl); g_interior(x1r, s1r, sl); }
 #pragma unroll
-      for (int sl = 0; sl < NHS; ++sl) { s_halo(0, sl); g_halo(x1r, sl); }
+      for (int sl = 0; sl < NHS; ++sl) { s_halo(0, sl); g_halo(x1r, s1r, sl); }
 #pragma unroll
-      for (int sl = 0; sl < NIS; ++sl) { s_interior(1, sl); g_interior(x2r, sl); }
+      for (int sl = 0; sl < NIS; ++sl) { s_interior(1, sl); g_interior(x2r, s2r, sl); }
 #pragma unroll
-      for (int sl = 0; sl < NHS; ++sl) { s_halo(1, sl); g_halo(x2r, sl); }
+      for (int sl = 0; sl < NHS; ++sl) { s_halo(1, sl); g_halo(x2r, s2r, sl); }
     }
     lds_barrier();
     if constexpr (ROLE == 0) {
 #pragma unroll
       for (int b_ = 0; b_ < 4; ++b_) y_stage1(b_);
-      y_issue(yrec_of(min(1, nk - 1)));
+      y_issue(yrec_of(min(1, nk - 1)), srec_of(min(1, nk - 1)));
 #pragma unroll
       for (int i = 0; i < 6; ++i) y_stage2(0, i);
     } else {
@@ -394,13 +461,20 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
 // ---------------------------------------------------------------------------
 int w3_reduce(const float* ws, float* dw, long long P, int splits, hipStream_t st);      // conv3x3.hip
 
-struct X4Plan { int ryn, rxn, nkt, kps, splits, gridM, gridC; };
+struct X4Plan { int ryn, rxn, nkt, kps, splits, gridM, gridC, dil, Hs, Ws, gen; };
+constexpr double X4_MIN_FILL = 0.7;             // pixels of the map / pixels of its 8x8 regions: below it the F(2x2) form wins
 static bool x4_plan(const avsep_conv_desc* d, X4Plan* out) {
   X4Plan p{};
-  if ((d->H & 7) || (d->W & 7)) return false;
-  p.ryn = d->H / 8;
-  p.rxn = d->W / 8;
-  p.nkt = d->N * p.ryn * p.rxn;
+  p.dil = d->dil;
+  if (p.dil != 1 && p.dil != 2) return false;
+  if (d->H % p.dil || d->W % p.dil) return false;
+  p.Hs = d->H / p.dil;
+  p.Ws = d->W / p.dil;
+  p.ryn = cdiv(p.Hs, 8);
+  p.rxn = cdiv(p.Ws, 8);
+  p.gen = (p.dil != 1 || (d->W & 1)) ? 2 : ((p.Hs & 7) || (p.Ws & 7)) ? 1 : 0;
+  if ((double)p.Hs * p.Ws < X4_MIN_FILL * 64.0 * p.ryn * p.rxn) return false;
+  p.nkt = d->N * p.dil * p.dil * p.ryn * p.rxn;
   p.gridM = cdiv(d->Cout, X4_BCO);
   p.gridC = cdiv(d->Cin, X4_BCI);
   // one workgroup per CU (512 threads x 256 registers, 156 KB of LDS): ONE round of workgroups, as in wgrad_wino.hip
@@ -416,7 +490,7 @@ static bool x4_plan(const avsep_conv_desc* d, X4Plan* out) {
 
 bool x4_applicable(const avsep_conv_desc* d) {
   if ((d->algo & (AVSEP_ALGO_NO_WINOGRAD | AVSEP_ALGO_NO_WINOGRAD_WGRAD | AVSEP_ALGO_NO_WINOGRAD4)) || d->prec != AVSEP_PREC_F32) return false;
-  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1) || d->up2x) return false;
+  if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil) || d->up2x) return false;
   const int C1 = d->Cin - d->C0;
   if (d->Cin % X4_BCI || d->C0 % X4_BCI || d->Cout < 48 || (C1 != 0 && C1 != d->C0)) return false;
   if ((long long)d->N * (d->C0 > d->Cout ? d->C0 : d->Cout) * d->H * d->W >= 0x3fffffffLL) return false;   // 32-bit BYTE offsets
@@ -436,7 +510,7 @@ void x4_variant(const avsep_conv_desc* d, char* buf, size_t cap) {
   X4Plan p;
   const avsep_conv_desc e = plan_desc(d);
   if (!x4_plan(&e, &p)) { snprintf(buf, cap, "?"); return; }
-  snprintf(buf, cap, "8x8,split%d", p.splits);
+  snprintf(buf, cap, "8x8%s,split%d", p.gen ? (p.dil == 2 ? "g,dil2" : "g") : "", p.splits);
 }
 
 int x4_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st) {
@@ -444,14 +518,22 @@ int x4_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   if (!x4_plan(d, &p)) return AVSEP_ERR_ARG;
   X4Args a{};
   a.N = d->N; a.C0 = d->C0; a.C1 = d->Cin - d->C0; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
-  a.ryn = p.ryn; a.rxn = p.rxn; a.nkt = p.nkt; a.kps = p.kps; a.gridM = p.gridM; a.gridC = p.gridC;
+  a.ryn = p.ryn; a.rxn = p.rxn; a.dil = p.dil; a.Hs = p.Hs; a.Ws = p.Ws; a.nkt = p.nkt; a.kps = p.kps; a.gridM = p.gridM; a.gridC = p.gridC;
   a.act0 = d->act0; a.act1 = d->act1;
   a.x0 = d->x0; a.x1 = d->x1; a.sc0 = d->scale0; a.sh0 = d->shift0; a.sc1 = d->scale1; a.sh1 = d->shift1;
   a.dy = dy; a.out = ws;
   const bool raw = !d->scale0 && !d->scale1 && d->act0 == AVSEP_ACT_NONE && (a.C1 == 0 || d->act1 == AVSEP_ACT_NONE);
   dim3 grid((unsigned)(p.gridM * p.gridC * p.splits));
-  if (raw) hipLaunchKernelGGL((winow4_kernel<true>), grid, dim3(X4_THREADS), 0, st, a);
-  else hipLaunchKernelGGL((winow4_kernel<false>), grid, dim3(X4_THREADS), 0, st, a);
+  if (p.gen == 2) {
+    if (raw) hipLaunchKernelGGL((winow4_kernel<true, 2>), grid, dim3(X4_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((winow4_kernel<false, 2>), grid, dim3(X4_THREADS), 0, st, a);
+  } else if (p.gen == 1) {
+    if (raw) hipLaunchKernelGGL((winow4_kernel<true, 1>), grid, dim3(X4_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((winow4_kernel<false, 1>), grid, dim3(X4_THREADS), 0, st, a);
+  } else {
+    if (raw) hipLaunchKernelGGL((winow4_kernel<true, 0>), grid, dim3(X4_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((winow4_kernel<false, 0>), grid, dim3(X4_THREADS), 0, st, a);
+  }
   AVSEP_LAUNCH_CHECK();
   return w3_reduce(ws, dw, (long long)d->Cout * d->Cin, p.splits, st);
 }

@@ -867,7 +867,7 @@ def test_benched_dispatch_full_size_step_vs_oracle(dev, prec, err_tol):
     print("families:", {k: len(v) for k, v in fams.items()})
     # the families profiles/r02_layers_*.txt lists for the batch-64 step
     if prec == "f32":
-        for must in ("wino4_kernel", "winow4_kernel", "wino_kernel", "winow_kernel", "wgrad4d_kernel", "conv3x3_kernel", "head_fwd_kernel", "head_dgrad_kernel",
+        for must in ("wino4_kernel", "winow4_kernel", "wino_kernel", "wgrad4d_kernel", "conv3x3_kernel", "head_fwd_kernel", "head_dgrad_kernel",
                      "head_wgrad_kernel"):
             assert must in fams, (must, sorted(fams))
         # every 3x3/s1 conv with >= 64 input channels on an even map >= 8x8 is a Winograd launch, in all three modes

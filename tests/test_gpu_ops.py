@@ -94,9 +94,15 @@ CONV_CASES = [
     (72, 72, 18, 30, 72, 3, 1, 1, 1),      # H, W = 2 mod 4 on the 2x2-tile groups
     (260, 72, 14, 14, 72, 3, 1, 2, 2),     # dilation 2: the four 7x7 parity sub-images, one 2x2-tile group each (ResNet layer4)
     (80, 72, 28, 28, 72, 3, 1, 2, 2),      # dilation 2 at 28x28: 14x14 sub-images on the 4x4-tile groups
-    # wgrad_wino4.hip: Winograd F(4x4, 3x3) weight gradient (Cin % 32 == 0, maps that tile by 8x8 regions, >= 128 workgroups)
+    # wgrad_wino4.hip: Winograd F(4x4, 3x3) weight gradient (Cin % 32 == 0, 8x8 regions >= 70 % full, >= 128 workgroups)
     (48, 96, 32, 48, 80, 3, 1, 1, 1),      # three input-channel blocks, ragged second output-channel tile, 14 regions per split
     (26, 64, 24, 40, 72, 3, 1, 1, 1),      # 3 x 5 regions per image, 7 regions per split (splits cross images), odd step counts
+    # ... the masked form: maps the 8x8 regions do not divide, and dilation 2 (parity sub-maps)
+    (200, 64, 14, 14, 72, 3, 1, 1, 1),     # 14x14 (ResNet layer3): 2 x 2 regions, the second 6 pixels wide, partial dY tiles
+    (40, 64, 28, 28, 72, 3, 1, 1, 1),      # 28x28 (ResNet layer2): the fourth region row / column is half a region
+    (260, 64, 14, 14, 72, 3, 1, 2, 2),     # dilation 2 (ResNet layer4): one 7x7 region per parity sub-map, pixels 2 apart
+    (72, 64, 20, 36, 72, 3, 1, 1, 1),      # H != W, both ragged (3 x 5 regions per image)
+    (36, 64, 24, 32, 72, 3, 1, 2, 2),      # dilation 2 over 12x16 sub-maps: two region rows, the second half valid
 ]
 
 
@@ -119,6 +125,8 @@ for _c in _rows_after((40, 72, 32, 64, 80, 3, 1, 1, 1), 8):
     EXPECT_FAMILY[_c] = {"fwd": "wino4_kernel", "dgrad": "wino4_kernel"}
 EXPECT_FAMILY[(48, 96, 32, 48, 80, 3, 1, 1, 1)] = {"fwd": "wino4_kernel", "dgrad": "wino4_kernel", "wgrad": "winow4_kernel"}
 EXPECT_FAMILY[(26, 64, 24, 40, 72, 3, 1, 1, 1)] = {"wgrad": "winow4_kernel"}
+for _c in _rows_after((200, 64, 14, 14, 72, 3, 1, 1, 1), 5):
+    EXPECT_FAMILY[_c] = {"wgrad": "winow4_kernel"}
 for _c in _rows_after((64, 64, 32, 32, 80, 4, 2, 1, 1), 3):
     EXPECT_FAMILY[_c] = {"wgrad": "wgrad4d_kernel"}
 for _c in _rows_after((3, 3, 32, 64, 72, 7, 2, 3, 1), 3) + [(2, 1, 32, 48, 24, 4, 2, 1, 1)]:
@@ -542,7 +550,7 @@ def _dilated_folded_case(dev, K, family):
     y_ref.backward(dy)
     t = lambda z: z.to(dev)
     cv = K.Conv(t(x), Cout, 3, 1, 2, 2, sc0=t(sc), sh0=t(sh), act0=1)
-    assert (cv.kernel_name("fwd", True), cv.kernel_name("dgrad"), cv.kernel_name("wgrad")) == (family, family, "winow_kernel")
+    assert (cv.kernel_name("fwd", True), cv.kernel_name("dgrad"), cv.kernel_name("wgrad")) == (family, family, "winow_kernel" if family == "wino_kernel" else "winow4_kernel")
     st = K.zeros_stats(Cout, cv.like)
     yd = y_ref.detach()
     assert_close(cv.fwd(cv.pack(t(w.detach()), 0), None, st), yd, 2e-5, "fwd")

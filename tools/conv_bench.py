@@ -20,6 +20,7 @@ SHAPES = [
     (192, 128, 28, 28, 128, 3, 1, 1, 1),
     (192, 256, 14, 14, 256, 3, 1, 1, 1),
     (192, 512, 14, 14, 512, 3, 1, 2, 2),
+    (192, 256, 14, 14, 512, 3, 1, 1, 1),
 ]
 LEFTOVERS = [    # the shapes profiles/r02_layers_f32.txt lists on the im2col kernel
     (192, 3, 224, 224, 64, 7, 2, 3, 1), (64, 1, 256, 256, 64, 4, 2, 1, 1),
