@@ -55,12 +55,19 @@ constexpr int X4P_KPS_MAX = 512;                // regions of one split (origin 
 // dilation-1 problem on pixels 2 apart).  A region's record carries a third word, the VALID rows | columns of its 10x10
 // patch as bit masks; every patch piece and every dY element tests its own (row bit | column bit) against it and loads
 // through the out-of-range offset (= 0) when it is outside the map.  GEN 1: dilation 1 and W even — dY in 8-byte pairs
-// (a pair is inside or outside together); GEN 2: anything else, dY element by element.
+// (a pair is inside or outside together); GEN 2: odd W, dY element by element; GEN 3: dilation 2 and W even, the
+// two x parities of a sub-map row TOGETHER in one region: its four tiles are (tile row ty, x parity px), the patch is 10
+// sub-rows x 12 CONSECUTIVE columns of the map (the two parities' 6-column patches interleaved, de-interleaved by the LDS
+// store addresses) and a lane pair (px = 0 | 1) loads the 8 consecutive dY values of a tile row as two 8-byte pairs each
+// and swaps the odd / even ones through the DPP crossbar — a quarter of the cache-line lookups of GEN 2, which bound it.
 template <bool RAW, int GEN>
 __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   constexpr int NT = X4_THREADS, BCO = X4_BCO, BCI = X4_BCI, PW = X4P_PW, PS = X4P_PS, YCO = X4P_YCO;
-  constexpr int NIS = BCI * 64 / NT;            // interior pieces per thread: 4
-  constexpr int NH = 36, NHS = (BCI * NH + NT - 1) / NT;     // halo ring: 36 positions per channel, 3 pieces per thread
+  // interior pieces per thread: 4; halo ring: 36 positions per channel, 3 pieces per thread.  GEN 3: the 120 positions of
+  // 4 channels on threads 0-479, 8 pieces per thread (channel 4 sl + tid / 120), all of them masked
+  constexpr int NIS = GEN == 3 ? 8 : BCI * 64 / NT;
+  constexpr int NH = 36, NHS = GEN == 3 ? 0 : (BCI * NH + NT - 1) / NT, NHA = NHS ? NHS : 1;
+  constexpr int ISL = GEN == 3 ? 4 : 8;         // channels between the interior pieces of a thread
   constexpr int BUF = X4P_Y_FLOATS + X4P_V_FLOATS + X4P_P_FLOATS;
   static_assert(2 * BUF >= 36 * 16 * 32, "epilogue exchange fits");
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
@@ -85,7 +92,19 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   const int D = GEN ? a.dil : 1;
   {
     const int per = a.ryn * a.rxn;
-    if constexpr (GEN) {
+    if constexpr (GEN == 3) {
+      const int pper = 2 * per;
+      for (int k = tid; k < nk; k += NT) {
+        const int reg = kt0 + k, img = reg / pper, rem = reg % pper, py = rem / per;
+        const int ry = (rem % per) / a.rxn, rx = rem % a.rxn;
+        const int y0 = ry * 8, x0 = rx * 8, pix = (2 * y0 + py) * a.W + x0;
+        const int vr9 = min(9, a.Hs - y0), qmax = min(11, a.W - x0 + 1);   // last valid patch row / column (column q = map column x0 - 2 + q)
+        const unsigned rm = ((2u << vr9) - 1u) & ~(y0 == 0 ? 1u : 0u), cm = ((2u << qmax) - 1u) & ~(x0 == 0 ? 3u : 0u);
+        gtab[k][0] = 4u * (unsigned)((img * Cs + cs0) * HW + pix);
+        gtab[k][1] = 4u * (unsigned)((img * a.Cout + m0) * HW + pix);
+        gtab[k][2] = rm | (cm << 10);
+      }
+    } else if constexpr (GEN) {
       const int pper = D * D * per;
       for (int k = tid; k < nk; k += NT) {
         const int reg = kt0 + k, img = reg / pper, rem = reg % pper, par = rem / per;
@@ -119,15 +138,24 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   // ---- patch pieces: interior element e = tid + 512 sl -> channel (tid >> 6) + 8 sl, pixel tid & 63 (one lane offset, one
   //      LDS word); halo ring element e -> channel e / 36, ring position e % 36 ----
   unsigned i_off, i_pm;                         // (GEN) i_pm / h_cls: the piece's row bit | column bit << 10
-  int i_lds;
-  {
+  int i_lds, i_ci = tid >> 6;
+  if constexpr (GEN == 3) {
+    const int ci = tid / 120, rq = tid % 120, r = rq / 12, q = rq % 12, px = q & 1, sc = q >> 1;
+    const bool on = tid < 480;
+    i_ci = on ? ci : 3;
+    i_off = on ? 4u * (unsigned)(ci * HW + 2 * r * a.W + q) : 0xffffffffu;
+    i_pm = on ? (1u << r) | (1u << (10 + q)) : 1u << 22;
+    // parity 0: sub-columns 0-5 at words 0-5 of the row; parity 1: 0-3 at words 8-11, 4-5 at words 6-7 (16-byte row reads);
+    // the idle threads write the 4 pad words behind a channel's patch
+    i_lds = on ? ci * PS + r * PW + (px ? (sc < 4 ? 8 + sc : 2 + sc) : sc) : (tid & 3) * PS + 120 + ((tid >> 2) & 3);
+  } else {
     const int ci = tid >> 6, pos = tid & 63, iy = pos >> 3, ix = pos & 7;
     i_off = 4u * (unsigned)(ci * HW + D * ((iy + 1) * a.W + ix + 1));
     i_lds = ci * PS + (iy + 1) * PW + ix + 1;
     i_pm = (1u << (iy + 1)) | (1u << (10 + ix + 1));
   }
-  unsigned h_off[NHS], h_cls[NHS];
-  int h_lds[NHS], h_ci[NHS];
+  unsigned h_off[NHA], h_cls[NHA];
+  int h_lds[NHA], h_ci[NHA];
 #pragma unroll
   for (int sl = 0; sl < NHS; ++sl) {
     const int e = tid + NT * sl, ec = min(e, BCI * NH - 1);
@@ -142,16 +170,16 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
     else h_cls[sl] = e < BCI * NH ? (unsigned)((r == 0) | ((r == 9) << 1) | ((col == 0) << 2) | ((col == 9) << 3)) : 0x10u;
     h_ci[sl] = ci;
   }
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xs - D * (a.W + 1)), 0, 0xfffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xs - (GEN == 3 ? 2 * a.W + 2 : D * (a.W + 1))), 0, 0xfffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, 0xfffffff0, 0x00020000);
 
-  float iraw[NIS], hraw[NHS];
-  bool hinv[NHS], iinv[NIS];
+  float iraw[NIS], hraw[NHA];
+  bool hinv[NHA], iinv[NIS];
   auto g_interior = [&](unsigned xrec, unsigned srec, int sl) __attribute__((always_inline)) {
     if constexpr (GEN) {
       const bool inv = (i_pm & srec) != i_pm;
       const unsigned off = inv ? 0xffffffffu : i_off;
-      iraw[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, (int)(xrec + (unsigned)sl * 32u * (unsigned)HW), 0));
+      iraw[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, (int)(xrec + (unsigned)sl * (4u * ISL) * (unsigned)HW), 0));
       iinv[sl] = inv;
     } else {
       const unsigned so = (xrec & ~31u) + (unsigned)sl * 32u * (unsigned)HW;                    // + 8 channels per slot
@@ -167,11 +195,11 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   auto s_interior = [&](int b, int sl) __attribute__((always_inline)) {
     float v = iraw[sl];
     if constexpr (!RAW) {
-      const f32x2 sa = aff[(tid >> 6) + 8 * sl];
+      const f32x2 sa = aff[i_ci + ISL * sl];
       v = act_by_slope(fmaf(v, sa[0], sa[1]), slope);
       if constexpr (GEN) v = iinv[sl] ? 0.f : v;
     }
-    Pb(b)[i_lds + sl * 8 * PS] = v;
+    Pb(b)[i_lds + sl * ISL * PS] = v;
   };
   auto s_halo = [&](int b, int sl) __attribute__((always_inline)) {
     float v = hraw[sl];
@@ -189,12 +217,15 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   // ---- dY role (waves 0-3): output channel tid >> 2, tile tid & 3 = (ty, tx) ----
   const bool yrole = wave < 4;
   const int y_co = (tid >> 2) & 63, y_tile = tid & 3;
-  const unsigned y_off = (m0 + y_co < a.Cout) ? 4u * (unsigned)(y_co * HW + D * (4 * (y_tile >> 1) * a.W + 4 * (y_tile & 1))) : 0xffffffffu;
-  const int y_rsh = 4 * (y_tile >> 1) + 1, y_csh = 10 + 4 * (y_tile & 1) + 1;   // (GEN) the tile's rows / columns in the region's masks
+  const unsigned y_off = (m0 + y_co < a.Cout) ? 4u * (unsigned)(y_co * HW + (GEN == 3 ? 8 * (y_tile >> 1) * a.W + 4 * (y_tile & 1)
+                                                                                      : D * (4 * (y_tile >> 1) * a.W + 4 * (y_tile & 1)))) : 0xffffffffu;
+  // (GEN) the tile's rows / columns in the region's masks (GEN 3: the lane's 4 consecutive map columns, patch columns 2 + 4 px ...)
+  const int y_rsh = 4 * (y_tile >> 1) + 1, y_csh = 10 + 4 * (y_tile & 1) + (GEN == 3 ? 2 : 1);
+  const bool y_px = y_tile & 1;
   const int y_dst = y_tile * YCO + y_co;        // Yh4[xi][tile][co]: + xi * 4 * 72
   f32x4 dyr[4];
   auto y_issue = [&](unsigned yrec, unsigned srec) __attribute__((always_inline)) {
-    if constexpr (GEN == 1) {
+    if constexpr (GEN == 1 || GEN == 3) {
       // pair (r, p) = columns 2p, 2p + 1 of row r: valid when row bit r and column bit 2p of the tile are
       const unsigned rsel = (srec >> y_rsh) & 15u, csel = (srec >> y_csh) & 15u, psel = (csel & 1u) | ((csel >> 1) & 2u);
       unsigned m8 = 0u;
@@ -207,7 +238,7 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
         for (int pp = 0; pp < 2; ++pp) {
           const unsigned t = (unsigned)((int)(nm << (31 - (2 * r + pp))) >> 31);               // all ones when invalid
           const f32x2 v2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_dy, (int)(y_off | t),
-                                                                                          (int)(yrec + 4u * (unsigned)(r * a.W + 2 * pp)), 0));
+                                                                                          (int)(yrec + 4u * (unsigned)((GEN == 3 ? 2 : 1) * r * a.W + 2 * pp)), 0));
           dyr[r][2 * pp] = v2[0];
           dyr[r][2 * pp + 1] = v2[1];
         }
@@ -244,6 +275,19 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
     O5 = Y3;                                                                 \
   } while (0)
   float yt[6][4];
+  // GEN 3: the lane pair holds map columns 0-3 | 4-7 of the tile row; parity 0 wants columns 0 2 4 6, parity 1 columns 1 3 5 7
+  auto y_swap = [&]() __attribute__((always_inline)) {
+    if constexpr (GEN == 3) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float k0 = y_px ? dyr[r][1] : dyr[r][0], k1 = y_px ? dyr[r][3] : dyr[r][2];
+        const float g0 = y_px ? dyr[r][0] : dyr[r][1], g1 = y_px ? dyr[r][2] : dyr[r][3];
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, g0), 0xB1, 0xf, 0xf, false));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, g1), 0xB1, 0xf, 0xf, false));
+        dyr[r] = f32x4{y_px ? r0 : k0, y_px ? r1 : k1, y_px ? k0 : r0, y_px ? k1 : r1};
+      }
+    }
+  };
   auto y_stage1 = [&](int b_) __attribute__((always_inline)) {              // column b_ of dY: 8 instructions
     X4_A6(dyr[0][b_], dyr[1][b_], dyr[2][b_], dyr[3][b_], yt[0][b_], yt[1][b_], yt[2][b_], yt[3][b_], yt[4][b_], yt[5][b_]);
   };
@@ -262,10 +306,11 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
 
   // ---- input role (waves 4-7): input channel li, tile 2 * ((wave - 4) >> 1) + lk, half = wave & 1 ----
   const int thalf = wave & 1;
-  int v_src, v_dst;
+  int v_src, v_dst, v_hi = 4;                   // (v_hi: sub-columns 4-5 of the tile's patch rows, relative to v_src)
+  if constexpr (GEN == 3) v_hi = lk ? -2 : 4;
   {
     const int tile = 2 * ((wave >> 1) & 1) + lk, ty = tile >> 1, tx = tile & 1;
-    v_src = li * PS + (4 * ty + thalf) * PW + 4 * tx;
+    v_src = li * PS + (4 * ty + thalf) * PW + (GEN == 3 ? 8 : 4) * tx;
     v_dst = (18 * thalf * 4 + tile) * BCI + li;               // V4[18 half + m][tile][ci]: + m * 128
   }
   f32x4 ra[5];
@@ -273,7 +318,7 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   float tt[3][6];
   auto v_read = [&](int b, int k) __attribute__((always_inline)) {          // k = 0..9: row k/2, columns 0-3 / 4-5
     const float* pp = Pb(b) + v_src + (k >> 1) * PW;
-    if (k & 1) rb[k >> 1] = *reinterpret_cast<const f32x2*>(pp + 4);
+    if (k & 1) rb[k >> 1] = *reinterpret_cast<const f32x2*>(pp + v_hi);
     else ra[k >> 1] = *reinterpret_cast<const f32x4*>(pp);
   };
   auto v_stage1 = [&](auto half_, int c) __attribute__((always_inline)) {
@@ -349,6 +394,7 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
         g_halo(xr3, sr3, m - NIS);
       }
       if constexpr (ROLE == 0) {
+        if (m == 0) y_swap();
         if (m < 4) y_stage1(m);
         if (m == 4) y_issue(yr2, sy2);
         if (m >= 5 && m < 17 && ((m - 5) & 1) == 0) y_stage2(buf ^ 1, (m - 5) >> 1);
@@ -384,6 +430,7 @@ __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
     }
     lds_barrier();
     if constexpr (ROLE == 0) {
+      y_swap();
 #pragma unroll
       for (int b_ = 0; b_ < 4; ++b_) y_stage1(b_);
       y_issue(yrec_of(min(1, nk - 1)), srec_of(min(1, nk - 1)));
@@ -471,10 +518,12 @@ static bool x4_plan(const avsep_conv_desc* d, X4Plan* out) {
   p.Hs = d->H / p.dil;
   p.Ws = d->W / p.dil;
   p.ryn = cdiv(p.Hs, 8);
-  p.rxn = cdiv(p.Ws, 8);
-  p.gen = (p.dil != 1 || (d->W & 1)) ? 2 : ((p.Hs & 7) || (p.Ws & 7)) ? 1 : 0;
-  if ((double)p.Hs * p.Ws < X4_MIN_FILL * 64.0 * p.ryn * p.rxn) return false;
-  p.nkt = d->N * p.dil * p.dil * p.ryn * p.rxn;
+  p.gen = (d->W & 1) ? 2 : p.dil == 2 ? 3 : ((p.Hs & 7) || (p.Ws & 7)) ? 1 : 0;
+  // (gen 3: a region is 8 sub-map rows x 8 MAP columns, both x parities)
+  p.rxn = cdiv(p.gen == 3 ? d->W : p.Ws, 8);
+  const int nsub = p.gen == 3 ? 2 : p.dil * p.dil;
+  if ((double)d->H * d->W < X4_MIN_FILL * 64.0 * p.ryn * p.rxn * nsub) return false;
+  p.nkt = d->N * nsub * p.ryn * p.rxn;
   p.gridM = cdiv(d->Cout, X4_BCO);
   p.gridC = cdiv(d->Cin, X4_BCI);
   // one workgroup per CU (512 threads x 256 registers, 156 KB of LDS): ONE round of workgroups, as in wgrad_wino.hip
@@ -510,7 +559,7 @@ void x4_variant(const avsep_conv_desc* d, char* buf, size_t cap) {
   X4Plan p;
   const avsep_conv_desc e = plan_desc(d);
   if (!x4_plan(&e, &p)) { snprintf(buf, cap, "?"); return; }
-  snprintf(buf, cap, "8x8%s,split%d", p.gen ? (p.dil == 2 ? "g,dil2" : "g") : "", p.splits);
+  snprintf(buf, cap, "8x8%s,split%d", p.gen == 3 ? "p,dil2" : p.gen == 2 ? "e" : p.gen == 1 ? "g" : "", p.splits);
 }
 
 int x4_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hipStream_t st) {
@@ -524,7 +573,10 @@ int x4_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* ws, hi
   a.dy = dy; a.out = ws;
   const bool raw = !d->scale0 && !d->scale1 && d->act0 == AVSEP_ACT_NONE && (a.C1 == 0 || d->act1 == AVSEP_ACT_NONE);
   dim3 grid((unsigned)(p.gridM * p.gridC * p.splits));
-  if (p.gen == 2) {
+  if (p.gen == 3) {
+    if (raw) hipLaunchKernelGGL((winow4_kernel<true, 3>), grid, dim3(X4_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((winow4_kernel<false, 3>), grid, dim3(X4_THREADS), 0, st, a);
+  } else if (p.gen == 2) {
     if (raw) hipLaunchKernelGGL((winow4_kernel<true, 2>), grid, dim3(X4_THREADS), 0, st, a);
     else hipLaunchKernelGGL((winow4_kernel<false, 2>), grid, dim3(X4_THREADS), 0, st, a);
   } else if (p.gen == 1) {

@@ -103,6 +103,8 @@ CONV_CASES = [
     (260, 64, 14, 14, 72, 3, 1, 2, 2),     # dilation 2 (ResNet layer4): one 7x7 region per parity sub-map, pixels 2 apart
     (72, 64, 20, 36, 72, 3, 1, 1, 1),      # H != W, both ragged (3 x 5 regions per image)
     (36, 64, 24, 32, 72, 3, 1, 2, 2),      # dilation 2 over 12x16 sub-maps: two region rows, the second half valid
+    (40, 64, 28, 28, 72, 3, 1, 2, 2),      # dilation 2 at 28x28: 2 x 4 paired-parity regions per sub-map row parity, both ragged
+    (60, 64, 20, 29, 72, 3, 1, 1, 1),      # odd W: dY element by element
 ]
 
 
@@ -125,7 +127,7 @@ for _c in _rows_after((40, 72, 32, 64, 80, 3, 1, 1, 1), 8):
     EXPECT_FAMILY[_c] = {"fwd": "wino4_kernel", "dgrad": "wino4_kernel"}
 EXPECT_FAMILY[(48, 96, 32, 48, 80, 3, 1, 1, 1)] = {"fwd": "wino4_kernel", "dgrad": "wino4_kernel", "wgrad": "winow4_kernel"}
 EXPECT_FAMILY[(26, 64, 24, 40, 72, 3, 1, 1, 1)] = {"wgrad": "winow4_kernel"}
-for _c in _rows_after((200, 64, 14, 14, 72, 3, 1, 1, 1), 5):
+for _c in _rows_after((200, 64, 14, 14, 72, 3, 1, 1, 1), 7):
     EXPECT_FAMILY[_c] = {"wgrad": "winow4_kernel"}
 for _c in _rows_after((64, 64, 32, 32, 80, 4, 2, 1, 1), 3):
     EXPECT_FAMILY[_c] = {"wgrad": "wgrad4d_kernel"}
