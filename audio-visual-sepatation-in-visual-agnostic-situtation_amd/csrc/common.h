@@ -47,6 +47,7 @@ __device__ __forceinline__ float act_slope(int act) {
   return act == AVSEP_ACT_RELU ? 0.f : (act == AVSEP_ACT_LRELU02 ? 0.2f : 1.f);
 }
 __device__ __forceinline__ float act_by_slope(float v, float slope) { return fmaxf(v, v * slope); }
+static inline float act_slope_host(int act) { return act == AVSEP_ACT_RELU ? 0.f : (act == AVSEP_ACT_LRELU02 ? 0.2f : 1.f); }
 // derivative of act at pre-activation value v
 __device__ __forceinline__ float act_grad(float v, int act) {
   if (act == AVSEP_ACT_RELU) return v > 0.f ? 1.f : 0.f;

@@ -601,7 +601,7 @@ bool w4_applicable(const avsep_conv_desc* d, int mode);
 size_t w4_packed_floats(const avsep_conv_desc* d, int mode);
 int w4_pack(const avsep_conv_desc* d, const float* w, float* packed, int mode, hipStream_t st);
 int w4_fwd(const avsep_conv_desc* d, const float* up, const float* bias, float* y, double* stats, hipStream_t st);
-int w4_dgrad(const avsep_conv_desc* d, const float* up, const float* dy, float* dx, hipStream_t st);
+int w4_dgrad(const avsep_conv_desc* d, const float* up, const float* dy, float* dx, const avsep_act_bwd* e, hipStream_t st);
 void w4_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap);
 bool wn_applicable(const avsep_conv_desc* d, int mode);
 size_t wn_packed_floats(const avsep_conv_desc* d, int mode);
@@ -890,7 +890,7 @@ extern "C" int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packe
   if (!w_packed_dgrad || !dy || !dx) return AVSEP_ERR_ARG;
   if (smallci_applicable(d)) return smallci_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (bf_applicable(d, 1)) return bf_dgrad(d, w_packed_dgrad, dy, dx, workspace, workspace_bytes, (hipStream_t)stream);
-  if (w4_applicable(d, 1)) return w4_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
+  if (w4_applicable(d, 1)) return w4_dgrad(d, w_packed_dgrad, dy, dx, nullptr, (hipStream_t)stream);
   if (wn_applicable(d, 1)) return wn_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c3_applicable(d, 1)) return c3_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
   if (c4_applicable(d, 1)) return c4_dgrad(d, w_packed_dgrad, dy, dx, (hipStream_t)stream);
@@ -949,6 +949,30 @@ static WgradPlan wgrad_plan(const avsep_conv_desc* d) {
   p.chunk = (int)chunk;
   p.splits = (int)((P + chunk - 1) / chunk);
   return p;
+}
+
+// the data gradient through the activation in front of the conv's input (include/avsep.h): in the F(4x4) Winograd kernel's
+// epilogue, else as the two launches it stands for
+static bool dgrad_act_fused(const avsep_conv_desc* d) {
+  return !smallci_applicable(d) && !bf_applicable(d, 1) && w4_applicable(d, 1);
+}
+extern "C" int32_t avsep_conv2d_dgrad_act_fused(const avsep_conv_desc* d) { return (!check_desc(d) && dgrad_act_fused(d)) ? 1 : 0; }
+extern "C" int avsep_conv2d_dgrad_act(const avsep_conv_desc* d, const float* w_packed_dgrad, const float* dy,
+                                      const avsep_act_bwd* e, float* dx, void* workspace, size_t workspace_bytes,
+                                      avsep_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!w_packed_dgrad || !dy || !dx || !e || !e->y) return AVSEP_ERR_ARG;
+  if (d->dxfmt != AVSEP_FMT_F32) return AVSEP_ERR_ARG;
+  if ((e->scale == nullptr) != (e->shift == nullptr) || (e->res_scale == nullptr) != (e->res_shift == nullptr) ||
+      (e->res_scale && !e->residual) || (e->bstats && (!e->mean || !e->invstd)))
+    return AVSEP_ERR_ARG;
+  if (e->act != AVSEP_ACT_NONE && e->act != AVSEP_ACT_RELU && e->act != AVSEP_ACT_LRELU02) return AVSEP_ERR_ARG;
+  if (dgrad_act_fused(d)) return w4_dgrad(d, w_packed_dgrad, dy, dx, e, (hipStream_t)stream);
+  rc = avsep_conv2d_dgrad(d, w_packed_dgrad, dy, dx, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  return avsep_affine_act_bwd(dx, e->dz2, e->y, e->scale, e->shift, e->residual, e->res_scale, e->res_shift, e->add, e->mean,
+                              e->invstd, e->act, d->N, d->Cin, d->H * d->W, dx, e->bstats, stream);
 }
 
 extern "C" size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d) {

@@ -44,6 +44,15 @@ constexpr int W4_AFF_MAX = 2048;      // channels of the folded affine rows kept
 constexpr int W4_U_FLOATS = W4_CK * W4_BM * 36;     // transformed weights of one (K-tile, M-tile): 73,728 bytes
 constexpr int W4_V_FLOATS = 36 * W4_CK * W4_NT;     // transformed input of one K-tile
 
+// Data gradient through the activation of the tensor the convolution read (avsep_conv2d_dgrad_act): the epilogue is
+// avsep_affine_act_bwd on the values it holds in registers,
+//     g = act'(sc*y + sh [+ rs*res + rh]) * (dx [+ dz2]) [+ add],   stats += (sum g, sum g * (y - mean) * invstd),
+// with y, res, dz2, add laid out like dx.  y == nullptr: the plain data gradient.
+struct W4Epi {
+  const float *y, *sc, *sh, *res, *rs, *rh, *dz2, *add, *mean, *inv;
+  float slope;
+};
+
 struct W4Args {
   int N, C0, C1, Cin, H, W, Cout;   // Cin = C0 + C1
   int Hq, Wq;                       // the (sub-)image the tiles live in: H x W, or H/2 x W/2 per parity class (dilation 2)
@@ -53,7 +62,8 @@ struct W4Args {
   const float* up;                  // [K-tile][M-tile][cb][q][chunk 9][lk 2][li 32][4]
   float* out;
   const float* bias;
-  double* stats;
+  double* stats;                    // forward: (sum y, sum y^2) per output channel; with e.y: the sums of the line above
+  W4Epi e;
 };
 
 // U = G g G^T (6x6) of every (input channel, output channel) pair, in the order the MFMA waves load it: wave (cb, q),
@@ -387,6 +397,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
   else obase = (long long)img * a.Cout * HW + (long long)oy * a.W + ox;
   constexpr int XS = SUB ? 2 : 1;
   const bool want_stats = a.stats != nullptr;
+  const bool epi = a.e.y != nullptr;
 #pragma unroll
   for (int cbp = 0; cbp < 2; ++cbp) {
 #pragma unroll
@@ -409,8 +420,25 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
           W4_AT4(z[(0 * 6 + j) * 512], z[(1 * 6 + j) * 512], z[(2 * 6 + j) * 512], z[(3 * 6 + j) * 512], z[(4 * 6 + j) * 512],
                  z[(5 * 6 + j) * 512], r_[0][j], r_[1][j], r_[2][j], r_[3][j]);
         const float bias = (a.bias && rok) ? a.bias[row] : 0.f;
-        float* o = a.out + obase + (long long)row * HW;
+        const long long ooff = obase + (long long)row * HW;
+        float* o = a.out + ooff;
         float s = 0.f, q = 0.f;
+        float esc = 1.f, esh = 0.f, ers = 1.f, erh = 0.f, emu = 0.f, eis = 1.f;
+        if (epi && rok) {
+          if (a.e.sc) { esc = a.e.sc[row]; esh = a.e.sh[row]; }
+          if (a.e.rs) { ers = a.e.rs[row]; erh = a.e.rh[row]; }
+          if (a.e.mean) { emu = a.e.mean[row]; eis = a.e.inv[row]; }
+        }
+        // one element through the activation gradient; returns g and adds to the two sums
+        auto through = [&](float v, float yk, float rk, float d2, float ak) __attribute__((always_inline)) {
+          float pre = fmaf(yk, esc, esh);
+          if (a.e.res) pre += fmaf(rk, ers, erh);
+          float g = (pre > 0.f ? 1.f : a.e.slope) * (a.e.dz2 ? v + d2 : v);
+          if (a.e.add) g += ak;
+          s += g;
+          q += g * (yk - emu) * eis;
+          return g;
+        };
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           f32x4 y;
@@ -418,9 +446,21 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
           y += bias;
           if constexpr (FULL) {
             if (rok && tok) {
-              *reinterpret_cast<f32x4*>(o + (long long)i * a.W) = y;
-              s += (y[0] + y[1]) + (y[2] + y[3]);
-              q += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+              if (epi) {
+                const long long eo = ooff + (long long)i * a.W;
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(a.e.y + eo);
+                const f32x4 rv = a.e.res ? *reinterpret_cast<const f32x4*>(a.e.res + eo) : zero4;
+                const f32x4 dv = a.e.dz2 ? *reinterpret_cast<const f32x4*>(a.e.dz2 + eo) : zero4;
+                const f32x4 av = a.e.add ? *reinterpret_cast<const f32x4*>(a.e.add + eo) : zero4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = through(y[j], yv[j], rv[j], dv[j], av[j]);
+                *reinterpret_cast<f32x4*>(o + (long long)i * a.W) = y;
+              } else {
+                *reinterpret_cast<f32x4*>(o + (long long)i * a.W) = y;
+                s += (y[0] + y[1]) + (y[2] + y[3]);
+                q += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+              }
             }
           } else {
             if (rok && tok && oy + i < a.Hq) {
@@ -428,9 +468,15 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
 #pragma unroll
               for (int j = 0; j < 4; ++j)
                 if (ox + j < a.Wq) {
-                  orow[XS * j] = y[j];
-                  s += y[j];
-                  q += y[j] * y[j];
+                  if (epi) {
+                    const long long eo = ooff + (long long)(XS * i) * a.W + XS * j;
+                    orow[XS * j] = through(y[j], a.e.y[eo], a.e.res ? a.e.res[eo] : 0.f, a.e.dz2 ? a.e.dz2[eo] : 0.f,
+                                           a.e.add ? a.e.add[eo] : 0.f);
+                  } else {
+                    orow[XS * j] = y[j];
+                    s += y[j];
+                    q += y[j] * y[j];
+                  }
                 }
             }
           }
@@ -569,9 +615,14 @@ int w4_fwd(const avsep_conv_desc* d, const float* up, const float* bias, float* 
 }
 
 // dX[N,Cin,H,W] = conv3x3(dY[N,Cout,H,W], flipped / transposed weights)
-int w4_dgrad(const avsep_conv_desc* d, const float* up, const float* dy, float* dx, hipStream_t st) {
+int w4_dgrad(const avsep_conv_desc* d, const float* up, const float* dy, float* dx, const avsep_act_bwd* e, hipStream_t st) {
   W4Args a{};
   a.N = d->N; a.C0 = d->Cout; a.C1 = 0; a.Cin = d->Cout; a.H = d->H; a.W = d->W; a.Cout = d->Cin;
   a.x0 = dy; a.up = up; a.out = dx;
+  if (e) {
+    a.e = W4Epi{e->y, e->scale, e->shift, e->residual, e->res_scale, e->res_shift, e->dz2, e->add, e->mean, e->invstd,
+                act_slope_host(e->act)};
+    a.stats = e->bstats;
+  }
   return w4_launch(a, d, 1, true, st);
 }

@@ -389,6 +389,29 @@ class Conv:
         call("avsep_conv2d_dgrad", self.ref, ptr(w_packed_d), ptr(dy), ptr(dx), ptr(ws), nbytes)
         return dx
 
+    def dgrad_act_fused(self):
+        """True when dgrad_act runs as ONE kernel (the activation gradient in the data-gradient kernel's epilogue)."""
+        self.d.dxfmt = FMT_F32
+        return bool(lib.load().avsep_conv2d_dgrad_act_fused(self.ref))
+
+    def dgrad_act(self, w_packed_d, dy, y, scale, shift, mean, invstd, act, bstats, residual=None, res_scale=None,
+                  res_shift=None, dz2=None, add=None):
+        """act'(scale*y + shift [+ res_scale*residual + res_shift]) * (dgrad(dy) [+ dz2]) [+ add] and its BatchNorm-backward
+        sums: avsep_conv2d_dgrad_act (fp32 tensors; the data gradient is never written unmasked)."""
+        need, _ = self.io_formats(1)
+        dy = as_fmt(dy, need)
+        self.d.dyfmt = need
+        self.d.dxfmt = FMT_F32
+        dx = _f32((self.N, self.Cin, self.H, self.W), self.like)
+        for t in (y, residual, dz2, add):
+            if t is not None and (is_b16(t) or tuple(t.shape) != tuple(dx.shape) or not t.is_contiguous()):
+                raise lib.AvsepError("dgrad_act operands must be dense fp32 tensors of dx's shape")
+        e = lib.ActBwd(ptr(y), ptr(scale), ptr(shift), ptr(residual), ptr(res_scale), ptr(res_shift), ptr(dz2), ptr(add),
+                       ptr(mean), ptr(invstd), ptr(bstats), int(act))
+        ws, nbytes = self._ws("avsep_conv2d_dgrad_workspace_bytes")
+        call("avsep_conv2d_dgrad_act", self.ref, ptr(w_packed_d), ptr(dy), C.byref(e), ptr(dx), ptr(ws), nbytes)
+        return dx
+
     def kernel_name(self, mode, with_stats=True):
         """Kernel family the library dispatches this call to (mode: "fwd" | "dgrad" | "wgrad")."""
         ref = self.ref

@@ -30,6 +30,12 @@ class ConvDesc(C.Structure):
                [(n, C.c_void_p) for n in "x0 x1 scale0 shift0 scale1 shift1".split()]
 
 
+class ActBwd(C.Structure):
+    """avsep_act_bwd (include/avsep.h): the operands of avsep_affine_act_bwd for avsep_conv2d_dgrad_act."""
+    _fields_ = [(n, C.c_void_p) for n in "y scale shift residual res_scale res_shift dz2 add mean invstd bstats".split()] + \
+               [("act", C.c_int32)]
+
+
 class CatDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in "N C0 C1 H W bcast0 bcast1".split()] + \
                [(n, C.c_void_p) for n in "x0 x1 scale0 shift0 scale1 shift1".split()]
@@ -50,6 +56,8 @@ SIGNATURES = {
     "avsep_conv2d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _Z, _P]),
     "avsep_conv2d_dgrad_workspace_bytes": (_Z, [_CD]),
     "avsep_conv2d_dgrad": (C.c_int, [_CD, _P, _P, _P, _P, _Z, _P]),
+    "avsep_conv2d_dgrad_act_fused": (C.c_int32, [_CD]),
+    "avsep_conv2d_dgrad_act": (C.c_int, [_CD, _P, _P, C.POINTER(ActBwd), _P, _P, _Z, _P]),
     "avsep_conv2d_head_applicable": (C.c_int32, [_CD]),
     "avsep_conv_kernel_name": (C.c_char_p, [_CD, _I, _I]),
     "avsep_conv_kernel_variant": (C.c_int, [_CD, _I, _I, C.c_char_p, _Z]),

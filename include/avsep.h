@@ -130,6 +130,35 @@ int avsep_conv2d_fwd(const avsep_conv_desc* d, const float* w_packed, const floa
 size_t avsep_conv2d_dgrad_workspace_bytes(const avsep_conv_desc* d);
 int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packed_dgrad, const float* dy,
                        float* dx, void* workspace, size_t workspace_bytes, avsep_stream_t stream);
+/* The data gradient taken THROUGH the activation (and BatchNorm / residual add) in front of the convolution's input, in the
+ * producing kernel's epilogue: the backward of `relu(bn1(y1))` between the two convs of a ResNet BasicBlock and of the block
+ * tail `relu(bn2(y2) + residual)` (vision_net.py:84-109 through torchvision's BasicBlock; main.py:557-569 runs it as
+ * autograd's ReluBackward + NativeBatchNormBackward between the two ConvolutionBackward nodes).  The operands are those of
+ * avsep_affine_act_bwd below with dz = the data gradient:
+ *     dx = act'(scale*y + shift [+ res_scale*residual + res_shift]) * (dgrad(dy) [+ dz2]) [+ add]
+ *     bstats += (sum dx, sum dx * (y - mean) * invstd)                                  per channel of dx, fp64
+ * y, residual, dz2, add: [N,Cin,H,W] fp32 like dx; the per-channel rows [Cin].  Exactly avsep_conv2d_dgrad followed by
+ * avsep_affine_act_bwd in place on dx — which is what the call runs for the kernel families without the epilogue
+ * (avsep_conv2d_dgrad_act_fused(d) == 0); with it the gradient is never written unmasked and never re-read.
+ * fp32 dx only (d->dxfmt == AVSEP_FMT_F32).  workspace as avsep_conv2d_dgrad. */
+typedef struct avsep_act_bwd {
+  const float* y;              /* the BatchNorm input whose activation the gradient passes            (required) */
+  const float* scale;          /* folded BatchNorm rows of y (NULL: identity)                                     */
+  const float* shift;
+  const float* residual;       /* added to scale*y + shift before the activation (NULL: none)                     */
+  const float* res_scale;      /* folded BatchNorm rows of the residual (NULL: plain add)                         */
+  const float* res_shift;
+  const float* dz2;            /* a second gradient branch reaching the same activation output (NULL: none)       */
+  const float* add;            /* added after the activation gradient (NULL: none)                                */
+  const float* mean;           /* batch statistics of y: required with bstats                                     */
+  const float* invstd;
+  double* bstats;              /* [2*Cin], accumulated (NULL: no sums)                                            */
+  int32_t act;                 /* AVSEP_ACT_*                                                                     */
+} avsep_act_bwd;
+int32_t avsep_conv2d_dgrad_act_fused(const avsep_conv_desc* d);   /* 1: one kernel; 0: the two launches */
+int avsep_conv2d_dgrad_act(const avsep_conv_desc* d, const float* w_packed_dgrad, const float* dy,
+                           const avsep_act_bwd* e, float* dx, void* workspace, size_t workspace_bytes,
+                           avsep_stream_t stream);
 /* dw OIHW; dbias optional ([Cout]).  workspace from avsep_conv2d_wgrad_workspace_bytes(). */
 size_t avsep_conv2d_wgrad_workspace_bytes(const avsep_conv_desc* d);
 int avsep_conv2d_wgrad(const avsep_conv_desc* d, const float* dy, float* dw, float* dbias,

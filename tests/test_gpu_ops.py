@@ -561,6 +561,59 @@ def _dilated_folded_case(dev, K, family):
     assert_close(cv.wgrad(t(dy))[0], w.grad, 2e-5, "wgrad")
 
 
+@pytest.mark.parametrize("N,C,H,W,dil,fused", [(40, 72, 56, 56, 1, True),     # 16-byte stores (W % 4 == 0)
+                                                  (400, 72, 14, 14, 1, True),    # masked scalar stores, partial tiles
+                                                  (260, 72, 14, 14, 2, True),    # parity sub-images (stride-2 stores)
+                                                  (72, 72, 20, 36, 1, True),     # ragged group grid
+                                                  (2, 24, 10, 12, 1, False)])    # a family without the epilogue: two launches
+def test_conv_dgrad_through_activation(dev, N, C, H, W, dil, fused):
+    """avsep_conv2d_dgrad_act: act'(sc*y + sh [+ rs*res + rh]) * (dgrad(dy) [+ dz2]) [+ add] and the BatchNorm-backward sums,
+    in the F(4x4) data-gradient kernel's epilogue (`fused`) or as the two launches it stands for — the ReLU'/BatchNorm-sum
+    passes of a ResNet BasicBlock (vision_net.py:84-109; torchvision BasicBlock.forward)."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(31)
+    Cout = 72
+    w = torch.randn(Cout, C, 3, 3, generator=g) * 0.05
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    x = torch.zeros(N, C, H, W).requires_grad_(True)
+    F.conv2d(x, w, None, 1, dil, dil).backward(dy)
+    dxr = x.grad.double()
+    t = lambda z: None if z is None else z.to(dev)
+    cv = K.Conv(t(x.detach()), Cout, 3, 1, dil, dil)
+    assert cv.dgrad_act_fused() == fused
+    assert cv.kernel_name("dgrad") == ("wino4_kernel" if fused else cv.kernel_name("dgrad"))
+    wp = cv.pack(t(w), 1)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rs, rh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    mean, invstd = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    res, dz2, add = (torch.randn(N, C, H, W, generator=g) for _ in range(3))
+    v = lambda r: r.view(1, -1, 1, 1).double()
+    # pre-activations at least 1e-2 away from zero, then y from them: both sides take the same branch everywhere
+    pre = torch.randn(N, C, H, W, generator=g).double()
+    pre = torch.where(pre.abs() < 1e-2, torch.full_like(pre, 1e-2), pre)
+    for act, slope, use_res, use_rs, use_dz2, use_add in ((1, 0.0, True, True, True, False), (1, 0.0, True, False, True, True),
+                                                          (2, 0.2, False, False, False, False), (0, 1.0, False, False, False, True)):
+        rterm = (v(rs) * res.double() + v(rh) if use_rs else res.double()) if use_res else 0.0
+        y = ((pre - v(sh) - rterm) / v(sc)).float()
+        gfac = torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, slope))
+        gref = gfac * (dxr + (dz2.double() if use_dz2 else 0.0)) + (add.double() if use_add else 0.0)
+        sref = torch.cat([gref.sum((0, 2, 3)), (gref * (y.double() - v(mean)) * v(invstd)).sum((0, 2, 3))])
+        bst = K.zeros_stats(C, cv.like)
+        out = cv.dgrad_act(wp, t(dy), t(y), t(sc), t(sh), t(mean), t(invstd), act, bst, residual=t(res) if use_res else None,
+                           res_scale=t(rs) if use_rs else None, res_shift=t(rh) if use_rs else None,
+                           dz2=t(dz2) if use_dz2 else None, add=t(add) if use_add else None)
+        tag = f"act {act} res {use_res}/{use_rs} dz2 {use_dz2} add {use_add}"
+        assert_close(out, gref, 2e-5, "dgrad_act " + tag)
+        assert_close(bst, sref, 2e-5, "dgrad_act sums " + tag)
+        # the two launches the call stands for
+        bst2 = K.zeros_stats(C, cv.like)
+        two = K.affine_act_bwd_(cv.dgrad(wp, t(dy), out_b16=False), t(y), t(sc), t(sh), t(res) if use_res else None,
+                                t(add) if use_add else None, t(mean), t(invstd), act, bst2, res_scale=t(rs) if use_rs else None,
+                                res_shift=t(rh) if use_rs else None, dz2=t(dz2) if use_dz2 else None)
+        assert_close(out, two, 2e-6, "dgrad_act against dgrad + affine_act_bwd " + tag)
+        assert_close(bst, bst2, 2e-6, "dgrad_act sums against dgrad + affine_act_bwd " + tag)
+
+
 @pytest.mark.parametrize("up2x,H,W", [(False, 9, 7), (True, 9, 7), (False, 10, 36), (True, 10, 18), (True, 6, 10)])
 def test_conv_virtual_input(dev, up2x, H, W):
     """two-source concat + per-channel affine + LeakyReLU/ReLU (+ bilinear x2) folded into the gather;

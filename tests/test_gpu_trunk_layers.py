@@ -123,7 +123,7 @@ def test_basic_block_layer_parity(dev, arch, dilate, li, bi, B, H):
 
     R, out = VH.block_forward(blk, z.to(dev), True)
     grads = _grads(VH, blk)
-    dz, dz2 = VH.block_backward(R, cot.to(dev).clone(), grads)
+    dz, dz2, _ = VH.block_backward(R, cot.to(dev).clone(), grads)
     dz = dz + dz2          # (conv branch, identity / downsample branch): the consumer's first pass sums them
     tag = f"{arch}{dilate} features[{li}][{bi}]"
     assert_close(out, out64, TOL, tag + ": output")
@@ -138,6 +138,70 @@ def test_basic_block_layer_parity(dev, arch, dilate, li, bi, B, H):
             assert_close(b, ob[k], TOL, f"{tag}: buffer {k}")
         else:
             assert int(b) == int(ob[k]) == 1, k
+
+
+# (dilate_scale, features index, batch, input size, all F(4x4) data gradients fused?): both blocks of a layer in a chain, the
+# way trunk_backward runs them in fp32: relu'(bn1(y1)) in conv2's data-gradient epilogue, and the tail relu'(bn2(y2) + z) of
+# the FIRST block (+ the identity-branch add) in the epilogue of the second block's conv1 data gradient
+# (avsep_conv2d_dgrad_act).  The descriptors are PLANNED for the bench's batch, which takes them to the F(4x4) Winograd
+# kernels that carry the epilogue (asserted), and run at a batch small enough for the branch margins; the single-block test
+# above runs the same calls unplanned, in the two-launch form inside the library.
+LAYERS = [(16, 4, 1, 56, True), (16, 5, 1, 56, True), (16, 6, 2, 28, True), (16, 7, 3, 14, True)]
+CHAIN_PLAN_SCALE = 96      # the launch decisions of a batch this many times larger (kernels.plan_batch_scale): the bench's
+
+
+@pytest.mark.parametrize("dilate,li,B,H,want_fused", LAYERS)
+def test_layer_chain_with_fused_activation_gradients(dev, dilate, li, B, H, want_fused):
+    from avsep_amd.models import vision_hip as VH
+    K = _pkg().kernels
+    gen = torch.Generator().manual_seed(1000 + li)
+    onet, net = _pair("dilated", dilate, gen)
+    olayer = onet.features[li]
+    cin = olayer[0].conv1.in_channels
+    z = F.relu(torch.randn(B, cin, H, H, generator=gen))
+    o64 = copy.deepcopy(olayer).double().train()
+    stats0 = {k: v.clone() for k, v in o64.state_dict().items() if "running_" in k or "num_batches" in k}
+    zz = z.double()
+    for ob in o64:                                              # branch margins, block after block
+        with torch.no_grad():
+            pre1 = ob.bn1(ob.conv1(zz))
+        sh1 = _nudge(pre1, ob.bn1.bias)
+        with torch.no_grad():
+            a = F.relu(pre1 + sh1.view(1, -1, 1, 1))
+            idt = zz if ob.downsample is None else ob.downsample(zz)
+            pre2 = ob.bn2(ob.conv2(a)) + idt
+        sh2 = _nudge(pre2, ob.bn2.bias)
+        zz = F.relu(pre2 + sh2.view(1, -1, 1, 1))
+    o64.load_state_dict({**o64.state_dict(), **stats0})
+    sd = {k: (v.float() if v.dtype.is_floating_point else v.clone()) for k, v in o64.state_dict().items()}
+    layer = net.features[li]
+    layer.load_state_dict(sd)
+    layer = layer.to(dev).train()
+    zin = z.double().requires_grad_(True)
+    out64 = o64(zin)
+    cot = torch.randn(out64.shape, generator=gen)
+    (out64 * cot.double()).sum().backward()
+
+    K.plan_batch_scale = CHAIN_PLAN_SCALE
+    try:
+        R0, z1 = VH.block_forward(layer[0], z.to(dev), True)
+        R1, out = VH.block_forward(layer[1], z1, True)
+        if want_fused:
+            assert R0["cv2"].dgrad_act_fused() and R1["cv2"].dgrad_act_fused() and R1["cv1"].dgrad_act_fused()
+        grads = _grads(VH, layer)
+        g, g2, pre = VH.block_backward(R1, cot.to(dev).clone(), grads, None, prev=R0)
+        assert g2 is None and pre is not None                   # the first block's tail came out of conv1's data gradient
+        dz, dz2, _ = VH.block_backward(R0, g, grads, None, prev=None, pre=pre)
+        dz = dz + dz2
+    finally:
+        K.plan_batch_scale = 1
+    tag = f"dilated{dilate} features[{li}]"
+    assert_close(out, out64, TOL, tag + ": output")
+    assert_close(dz, zin.grad, TOL, tag + ": dz")
+    og = dict(o64.named_parameters())
+    for k, p in layer.named_parameters():
+        assert p in grads, k
+        assert_close(grads[p], og[k].grad, TOL, f"{tag}: grad {k}")
 
 
 def _pool_margin(act):

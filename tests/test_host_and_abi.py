@@ -53,7 +53,7 @@ def test_every_entry_point_rejects_null_and_zero_arguments():
     L = P.lib.load()
     probed = 0
     for name, (res, args) in sorted(P.lib.SIGNATURES.items()):
-        if res is not C.c_int or not args or name in ("avsep_strerror", "avsep_conv2d_head_applicable"):
+        if res is not C.c_int or not args or name in ("avsep_strerror", "avsep_conv2d_head_applicable", "avsep_conv2d_dgrad_act_fused"):
             continue
         vals = []
         for a in args:
@@ -73,6 +73,7 @@ def test_every_entry_point_rejects_null_and_zero_arguments():
         probed += 1
     assert probed >= 55
     assert L.avsep_conv2d_head_applicable(C.byref(P.lib.ConvDesc())) == 0
+    assert L.avsep_conv2d_dgrad_act_fused(C.byref(P.lib.ConvDesc())) == 0
     assert L.avsep_conv_packed_floats(C.byref(P.lib.ConvDesc()), 0) == 0
 
 
