@@ -79,7 +79,7 @@ class KernelTimer:
 
     def __init__(self, K):
         self.K, self.rec, self.on = K, [], False
-        for name in ("fwd", "dgrad", "wgrad", "dgrad_up2x"):
+        for name in ("fwd", "dgrad", "wgrad", "dgrad_up2x", "dgrad_act"):
             self._wrap_conv(name)
         for name in ("fwd", "bwd"):
             self._wrap_cat(name)
@@ -98,7 +98,7 @@ class KernelTimer:
         def wrapped(cv, *a, **kw):
             if not timer.on:
                 return orig(cv, *a, **kw)
-            mode = "dgrad" if name == "dgrad_up2x" else name
+            mode = "dgrad" if name in ("dgrad_up2x", "dgrad_act") else name
             with_stats = bool(len(a) > 2 and a[2] is not None) or kw.get("stats") is not None
             family = "head_dgrad_kernel" if name == "dgrad_up2x" else cv.kernel_name(mode, with_stats)
             flops = 2.0 * cv.N * cv.Ho * cv.Wo * cv.Cout * cv.Cin * cv.KH * cv.KW
@@ -112,6 +112,11 @@ class KernelTimer:
                 nbytes = 4.0 * ((2 * lo if mode == "dgrad" else lo) + cv.N * cv.Cout * cv.Ho * cv.Wo + wts)
             else:   # each of the three operands (input, output / cotangent, weights) touched once
                 nbytes = eb * (cv.N * cv.Cin * cv.H * cv.W + cv.N * cv.Cout * cv.Ho * cv.Wo) + 4.0 * wts
+            if name == "dgrad_act":
+                # the activation gradient in the epilogue (or, for a family without it, as the second launch the call stands
+                # for, booked on the conv's family): y, and residual / dz2 / add when given, are read once more
+                extra = 1 + sum(kw.get(k) is not None for k in ("residual", "dz2", "add"))
+                nbytes += 4.0 * extra * cv.N * cv.Cin * cv.H * cv.W
             layer = (cv.N, cv.Cin, cv.H, cv.W, cv.Cout, cv.KH, cv.d.stride, cv.d.pad, cv.d.dil, cv.d.up2x)
             return timer._time(orig, (cv,) + a, kw, family, mode, flops, nbytes, layer)
         setattr(self.K.Conv, name, wrapped)
