@@ -139,7 +139,8 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict
 // GX: extra words in front of every second group and twice as many in front of every fourth (g*GS + GX*(g>>1) + 2*GX*(g>>2)):
 // with eight 2x2-tile groups no uniform group stride spreads the row reads of a 16-lane b128 access over all 64 banks (4-way
 // conflicts measured with a uniform stride of 128 words).
-template <int G, int GH, int GW, int PW, int GS, int GX, bool RAW, bool SUB, bool FULL>
+// EPI: the instantiations that carry the activation-gradient epilogue (W4Epi; data gradients only, so RAW)
+template <int G, int GH, int GW, int PW, int GS, int GX, bool RAW, bool SUB, bool FULL, bool EPI = false>
 __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
   static_assert(!(SUB && FULL), "sub-image stores are strided");
   auto goff = [](int g) __attribute__((always_inline)) { return g * GS + GX * (g >> 1) + 2 * GX * (g >> 2); };
@@ -397,11 +398,29 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
   else obase = (long long)img * a.Cout * HW + (long long)oy * a.W + ox;
   constexpr int XS = SUB ? 2 : 1;
   const bool want_stats = a.stats != nullptr;
-  const bool epi = a.e.y != nullptr;
+  constexpr bool epi = EPI;
 #pragma unroll
   for (int cbp = 0; cbp < 2; ++cbp) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      // (EPI) y at this thread's 4x4 outputs: in flight across the exchange below (the other operands are loaded where they
+      // are used: 16 more registers each, and the accumulators are still live)
+      f32x4 pyv[4];
+      if constexpr (EPI) {
+        const int prow = m0 + cbp * 32 + 16 * h + ec;
+        const float* py = a.e.y + obase + (long long)prow * HW;
+        const bool pok = prow < a.Cout && tok;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (FULL) {
+            pyv[i] = pok ? *reinterpret_cast<const f32x4*>(py + (long long)i * a.W) : f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              pyv[i][j] = (pok && oy + i < a.Hq && ox + j < a.Wq) ? py[(long long)(XS * i) * a.W + XS * j] : 0.f;
+          }
+        }
+      }
       if (wcb == cbp) {
 #pragma unroll
         for (int e = 0; e < 9; ++e)
@@ -449,7 +468,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
               if (epi) {
                 const long long eo = ooff + (long long)i * a.W;
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(a.e.y + eo);
+                const f32x4 yv = pyv[i];
                 const f32x4 rv = a.e.res ? *reinterpret_cast<const f32x4*>(a.e.res + eo) : zero4;
                 const f32x4 dv = a.e.dz2 ? *reinterpret_cast<const f32x4*>(a.e.dz2 + eo) : zero4;
                 const f32x4 av = a.e.add ? *reinterpret_cast<const f32x4*>(a.e.add + eo) : zero4;
@@ -470,7 +489,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
                 if (ox + j < a.Wq) {
                   if (epi) {
                     const long long eo = ooff + (long long)(XS * i) * a.W + XS * j;
-                    orow[XS * j] = through(y[j], a.e.y[eo], a.e.res ? a.e.res[eo] : 0.f, a.e.dz2 ? a.e.dz2[eo] : 0.f,
+                    orow[XS * j] = through(y[j], pyv[i][j], a.e.res ? a.e.res[eo] : 0.f, a.e.dz2 ? a.e.dz2[eo] : 0.f,
                                            a.e.add ? a.e.add[eo] : 0.f);
                   } else {
                     orow[XS * j] = y[j];
@@ -575,13 +594,13 @@ void w4_variant(const avsep_conv_desc* d, int mode, char* buf, size_t cap) {
   snprintf(buf, cap, "%dx%dx%d%s", k.g, k.gh, k.gw, d->dil == 2 ? ",sub" : "");
 }
 
-template <bool RAW, bool SUB, bool FULL>
+template <bool RAW, bool SUB, bool FULL, bool EPI = false>
 static void w4_launch_cfg(const W4Args& a, int cfg, dim3 grid, hipStream_t st) {
   // <G, GH, GW, PW, GS>: row strides chosen so that the b128 row reads of the transform spread over the 64 banks
   switch (cfg) {
-    case 0: hipLaunchKernelGGL((wino4_kernel<1, 4, 8, 40, 18 * 40, 0, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((wino4_kernel<2, 4, 4, 20, 384, 0, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
-    default: hipLaunchKernelGGL((wino4_kernel<8, 2, 2, 12, 120, 16, RAW, SUB, FULL>), grid, dim3(W4_THREADS), 0, st, a); break;
+    case 0: hipLaunchKernelGGL((wino4_kernel<1, 4, 8, 40, 18 * 40, 0, RAW, SUB, FULL, EPI>), grid, dim3(W4_THREADS), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((wino4_kernel<2, 4, 4, 20, 384, 0, RAW, SUB, FULL, EPI>), grid, dim3(W4_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL((wino4_kernel<8, 2, 2, 12, 120, 16, RAW, SUB, FULL, EPI>), grid, dim3(W4_THREADS), 0, st, a); break;
   }
 }
 
@@ -590,7 +609,11 @@ static int w4_launch(W4Args& a, const avsep_conv_desc* d, int mode, bool raw, hi
   a.Hq = p.Hq; a.Wq = p.Wq; a.gyn = p.gyn; a.gxn = p.gxn; a.ngroups = p.ngroups; a.gridM = p.gridM;
   dim3 grid((unsigned)((long long)p.ptiles * p.gridM));
   const bool sub = d->dil == 2, full = !sub && !(d->H & 3) && !(d->W & 3);
-  if (sub) {
+  if (a.e.y) {                                     // (data gradient: raw input)
+    if (sub) w4_launch_cfg<true, true, false, true>(a, p.cfg, grid, st);
+    else if (full) w4_launch_cfg<true, false, true, true>(a, p.cfg, grid, st);
+    else w4_launch_cfg<true, false, false, true>(a, p.cfg, grid, st);
+  } else if (sub) {
     if (raw) w4_launch_cfg<true, true, false>(a, p.cfg, grid, st);
     else w4_launch_cfg<false, true, false>(a, p.cfg, grid, st);
   } else if (full) {

@@ -174,57 +174,45 @@ def fc_backward(fc, cvf, dout, grads):
     return cvf.dgrad(cvf.pack(_w(fc), 1), dout)
 
 
-def block_backward(R, g, grads, g2=None, prev=None, pre=None):
+def block_backward(R, g, grads, g2=None):
     """dL/dz' = g (+ g2), consumed in place -> dL/dz as ONE tensor (downsample blocks) or as the pair (conv branch,
     identity branch): the pair is summed by the consumer's first elementwise pass instead of by a launch of its own.
-    Parameter gradients are accumulated into `grads`.  Returns (g, g2, pre) for the block in front.
+    Parameter gradients are accumulated into `grads`.
 
-    fp32: the two ReLU'/BatchNorm-sum passes of a block run in the EPILOGUE of the data-gradient kernel that produces their
-    operand (avsep_conv2d_dgrad_act): relu'(bn1(y1)) in conv2's, and the tail relu'(bn2(y2) + residual) of the block in
-    front (`prev`, its record) in this block's conv1's, together with the identity-branch add.  The block in front then
-    receives its dL/d(pre-ReLU sum) as g and the statistics buffer that goes with it as `pre`."""
+    fp32: the ReLU' / BatchNorm-sum pass over conv2's data gradient runs in the EPILOGUE of that kernel
+    (avsep_conv2d_dgrad_act): dL/da1 is never written unmasked.  The block TAIL relu'(bn2(y2) + residual) stays a pass of its
+    own: in the next block's conv1 epilogue its three extra operand reads cost more than the pass (one workgroup per CU,
+    nothing overlaps the epilogue's memory latency): +4-8 % per call on the 28x28 / 14x14 maps against -1 % for this one
+    (`tools/conv_bench.py dgrad --act-epilogue bn1|tail`)."""
     blk = R["mod"]
     ds = blk.downsample is not None
     bnd = R.get("bnd")
-    fused = K.get_precision() == "f32" and not K.is_b16(R["y1"]) and not K.is_b16(R["y2"])
-    if pre is not None:                                             # this block's tail was taken by the block behind
-        pqr2 = _bn_back(grads, blk.bn2, R["bn2"], pre, K.per_channel(R["y2"]))
-    else:
-        g, pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
-                                rs=bnd[0] if ds else None, rh=bnd[1] if ds else None, g2=g2)   # g = dL/d(pre-ReLU sum)
+    g, pqr2 = _relu_bn_back(grads, g, R["y2"], R["bn2"], blk.bn2, res=R["yd"] if ds else R["z"],
+                            rs=bnd[0] if ds else None, rh=bnd[1] if ds else None, g2=g2)   # g = dL/d(pre-ReLU sum)
     dy2 = K.bn_bwd_apply_(g, R["y2"], pqr2, fresh=True)
     grads.wgrad(R["cv2"], blk.conv2.weight, dy2)
-    if fused:
+    if K.get_precision() == "f32" and not K.is_b16(R["y1"]):
         bn1 = R["bn1"]
         bst1 = K.zeros_stats(K.channels(R["y1"]), R["y1"])
         da = R["cv2"].dgrad_act(R["cv2"].pack(_w(blk.conv2), 1), dy2, R["y1"], bn1[0], bn1[1], bn1[2], bn1[3], ACT_RELU, bst1)
         pqr1 = _bn_back(grads, blk.bn1, bn1, bst1, K.per_channel(R["y1"]))
+        del dy2
     else:
         da = R["cv2"].dgrad(R["cv2"].pack(_w(blk.conv2), 1), dy2)
-    del dy2
-    if not fused:
+        del dy2
         da, pqr1 = _relu_bn_back(grads, da, R["y1"], R["bn1"], blk.bn1)
     da = K.bn_bwd_apply_(da, R["y1"], pqr1)                         # da = dL/dy1
     grads.wgrad(R["cv1"], blk.conv1.weight, da)
-    gid = g                                                         # the identity branch's share of dL/dz
+    dz = R["cv1"].dgrad(R["cv1"].pack(_w(blk.conv1), 1), da)
+    del da
     if ds:
         bst = K.zeros_stats(K.channels(g), g)                       # BNd statistics of g (values of g unchanged)
         g = K.affine_act_bwd_(g, R["yd"], None, None, None, None, bnd[2], bnd[3], ACT_NONE, bst, stats_only=True)
         pqrd = _bn_back(grads, blk.downsample[1], bnd, bst, K.per_channel(g))
         g = K.bn_bwd_apply_(g, R["yd"], pqrd)                       # g = dL/dyd
         grads.wgrad(R["cvd"], blk.downsample[0].weight, g)
-        gid = R["cvd"].dgrad(R["cvd"].pack(_w(blk.downsample[0]), 1), g)
-    if fused and prev is not None and not K.is_b16(prev["y2"]):
-        pm = prev["mod"]
-        pds, pbnd, pbn2 = pm.downsample is not None, prev.get("bnd"), prev["bn2"]
-        bstp = K.zeros_stats(K.channels(prev["y2"]), prev["y2"])
-        gt = R["cv1"].dgrad_act(R["cv1"].pack(_w(blk.conv1), 1), da, prev["y2"], pbn2[0], pbn2[1], pbn2[2], pbn2[3], ACT_RELU,
-                                bstp, residual=prev["yd"] if pds else prev["z"], res_scale=pbnd[0] if pds else None,
-                                res_shift=pbnd[1] if pds else None, dz2=K.to_f32(gid))
-        return gt, None, bstp
-    dz = R["cv1"].dgrad(R["cv1"].pack(_w(blk.conv1), 1), da)
-    del da
-    return dz, gid, None
+        return dz, R["cvd"].dgrad(R["cvd"].pack(_w(blk.downsample[0]), 1), g)
+    return dz, g
 
 
 def stem_backward(f, S, g, grads, g2=None):
@@ -251,10 +239,9 @@ def stem_backward(f, S, g, grads, g2=None):
 
 def trunk_backward(net, S, dout, grads):
     g = fc_backward(net.fc, S["cvf"], dout, grads)                  # dL/dz of the last block
-    g2 = pre = None
-    blocks = S["blocks"]
-    for k in range(len(blocks) - 1, -1, -1):
-        g, g2, pre = block_backward(blocks[k], g, grads, g2, prev=blocks[k - 1] if k > 0 else None, pre=pre)
+    g2 = None
+    for R in reversed(S["blocks"]):
+        g, g2 = block_backward(R, g, grads, g2)
     stem_backward(net.features, S, g, grads, g2)
 
 

@@ -140,7 +140,11 @@ int avsep_conv2d_dgrad(const avsep_conv_desc* d, const float* w_packed_dgrad, co
  * y, residual, dz2, add: [N,Cin,H,W] fp32 like dx; the per-channel rows [Cin].  Exactly avsep_conv2d_dgrad followed by
  * avsep_affine_act_bwd in place on dx — which is what the call runs for the kernel families without the epilogue
  * (avsep_conv2d_dgrad_act_fused(d) == 0); with it the gradient is never written unmasked and never re-read.
- * fp32 dx only (d->dxfmt == AVSEP_FMT_F32).  workspace as avsep_conv2d_dgrad. */
+ * fp32 dx only (d->dxfmt == AVSEP_FMT_F32).  workspace as avsep_conv2d_dgrad.
+ * Measured (MI355X, tools/conv_bench.py dgrad --act-epilogue): with y alone (the bn1 form) the call costs what the data
+ * gradient alone did on the 14x14 ... 56x56 trunk maps and saves the pass (the host layer uses it there); every further
+ * operand (residual, dz2, add) is a read the epilogue cannot hide: slower than the two launches below 32x32 maps,
+ * 5-15 % faster on 64x64 and 128x128 ones. */
 typedef struct avsep_act_bwd {
   const float* y;              /* the BatchNorm input whose activation the gradient passes            (required) */
   const float* scale;          /* folded BatchNorm rows of y (NULL: identity)                                     */

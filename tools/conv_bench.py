@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--tune", type=lambda v: int(v, 0), default=0, help="avsep_conv_desc.tune (include/avsep.h): bits 0-3 Winograd "
                     "group shape + 1, bits 4-7 Winograd weight-gradient group shape + 1, bits 8-23 its target workgroup count")
     ap.add_argument("--algo-no", default="", help="comma list of kernel families the calls must not use (lib.ALGO_NO)")
+    ap.add_argument("--act-epilogue", default="", choices=["", "bn1", "tail"], help="dgrad only: time avsep_conv2d_dgrad_act (bn1: through "
+                    "relu(bn(y)); tail: through relu(bn(y) + residual) with a second gradient branch) against dgrad + affine_act_bwd")
     o = ap.parse_args()
     K = P.kernels
     K.conv_tune = o.tune
@@ -58,6 +60,28 @@ def main():
         dy = torch.randn(N, Cout, cv.Ho, cv.Wo, device=dev)
         wp = cv.pack(w, 1 if o.mode == "dgrad" else 0)
         run = {"fwd": lambda: cv.fwd(wp, None, st), "dgrad": lambda: cv.dgrad(wp, dy), "wgrad": lambda: cv.wgrad(dy)}[o.mode]
+        if o.act_epilogue and o.mode == "dgrad":
+            C = Cin
+            yb, res, dz2 = (torch.randn(N, C, H, W, device=dev) for _ in range(3))
+            sc, sh, mu, isd = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev), torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5
+            bst = K.zeros_stats(C, x)
+            tail = o.act_epilogue == "tail"
+            kw2 = dict(residual=res, dz2=dz2) if tail else {}
+            fused = lambda: cv.dgrad_act(wp, dy, yb, sc, sh, mu, isd, 1, bst, **kw2)
+            two = lambda: K.affine_act_bwd_(cv.dgrad(wp, dy), yb, sc, sh, res if tail else None, None, mu, isd, 1, bst, dz2=dz2 if tail else None)
+            for tag, fn in (("dgrad_act", fused), ("two launches", two)):
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(o.reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                print("%-40s %-14s %-12s fused=%d %8.3f ms" % ((N, Cin, H, W, Cout, k, s, p, d), tag, o.act_epilogue, cv.dgrad_act_fused(),
+                                                             e0.elapsed_time(e1) / o.reps))
+            continue
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
