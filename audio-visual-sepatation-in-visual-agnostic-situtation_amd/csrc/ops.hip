@@ -1108,27 +1108,33 @@ extern "C" int avsep_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int32
 // with w'[co][(dy*2+dx)*C + c][a][b] = w[co][c][2a + dy - 1][2b + dx - 1] (zero where kh, kw leave 0..6): every tap of
 // the 7x7 kernel appears exactly once.  Cp = 4*C rounded up to 16 gives the halo-patch kernels (f32 and bf16) a
 // 16-channel K-tile instead of the im2col gather over 3 channels (38 TFLOP/s).
+// One (n, phase channel q) plane per blockIdx.y: per-plane constants in scalar registers and 32-bit index arithmetic (the flat
+// form spent four 64-bit divisions per element: 165 us per call for 270 MB at 192 frames).
 __global__ __launch_bounds__(256) void space_to_depth2_kernel(const float* __restrict__ x, int C, int Cp, int H, int W,
-                                                              long long total, float* __restrict__ xs) {
-  const int Hs = H / 2 + 3, Ws = W / 2 + 3;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int j = (int)(i % Ws), r = (int)((i / Ws) % Hs), q = (int)((i / ((long long)Ws * Hs)) % Cp);
-    const long long n = i / ((long long)Ws * Hs * Cp);
-    float v = 0.f;
-    const int ii = r - 2, jj = j - 2;
-    if (q < 4 * C && ii >= 0 && ii < H / 2 && jj >= 0 && jj < W / 2) {
-      const int c = q % C, dy = (q / C) >> 1, dx = (q / C) & 1;
-      v = x[((n * C + c) * H + 2 * ii + dy) * W + 2 * jj + dx];
+                                                              int planes, float* __restrict__ xs) {
+  const int Hs = H / 2 + 3, Ws = W / 2 + 3, Hh = H / 2, Wh = W / 2;
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int q = plane % Cp, n = plane / Cp;
+    float* const op = xs + (long long)plane * Hs * Ws;
+    const bool live = q < 4 * C;
+    const int c = q % C, dy = (q / C) >> 1, dx = (q / C) & 1;
+    const float* const xp = x + ((long long)(n * C + (live ? c : 0)) * H + dy) * W + dx;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Hs * Ws; i += gridDim.x * 256) {
+      const int r = i / Ws, j = i - r * Ws, ii = r - 2, jj = j - 2;
+      float v = 0.f;
+      if (live && (unsigned)ii < (unsigned)Hh && (unsigned)jj < (unsigned)Wh) v = xp[2 * ii * W + 2 * jj];
+      op[i] = v;
     }
-    xs[i] = v;
   }
 }
 extern "C" int avsep_space_to_depth2(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp, float* xs,
                                      avsep_stream_t stream) {
   if (!x || !xs || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cp < 4 * C) return AVSEP_ERR_ARG;
-  const long long total = (long long)N * Cp * (H / 2 + 3) * (W / 2 + 3);
-  hipLaunchKernelGGL(space_to_depth2_kernel, dim3((int)min((total + 255) / 256, (long long)262144)), dim3(256), 0,
-                     (hipStream_t)stream, x, C, Cp, H, W, total, xs);
+  if ((long long)N * Cp > 0x7fffffffLL || (long long)H * W > 0x3fffffffLL) return AVSEP_ERR_ARG;
+  const int per = (H / 2 + 3) * (W / 2 + 3), gx = (per + 255) / 256 < 16 ? (per + 255) / 256 : 16;
+  const int planes = N * Cp;
+  hipLaunchKernelGGL(space_to_depth2_kernel, dim3(gx, planes < 65535 ? planes : 65535), dim3(256), 0, (hipStream_t)stream, x, C, Cp,
+                     H, W, planes, xs);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
 }
@@ -1205,6 +1211,46 @@ __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_apply_kernel(const fl
     *reinterpret_cast<f32x2*>(dp + self) = f32x2{fmaf(cp, s0, fmaf(cq, yv[0], cr)), fmaf(cp, s1, fmaf(cq, yv[1], cr))};
   }
 }
+// W % 4 == 0: a thread owns the pixel quad (h, 4j .. 4j+3) — window columns 2j (pixels 0, 1), 2j+1 (pixels 1, 2, 3) and 2j+2
+// (pixel 3): 16-byte loads and stores of y / dy (the pair form moves 1.5 GB per call at 3.3 TB/s on the stem's 112x112 maps)
+__global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_apply4_kernel(const float* __restrict__ g, const int* __restrict__ idx,
+                                                                         const float* __restrict__ y, const float* __restrict__ scale,
+                                                                         const float* __restrict__ shift, const float* __restrict__ pqr,
+                                                                         int C, int H, int W, int Ho, int Wo, float* __restrict__ dy) {
+  const int nc = blockIdx.y, c = nc % C, Wq = W >> 2;
+  const float sc = scale[c], sh = shift[c], cp = pqr[c], cq = pqr[C + c], cr = pqr[2 * C + c];
+  const float* yp = y + (long long)nc * H * W;
+  float* dp = dy + (long long)nc * H * W;
+  const float* gp = g + (long long)nc * Ho * Wo;
+  const int* ip = idx + (long long)nc * Ho * Wo;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * Wq; i += gridDim.x * 256) {
+    const int h = i / Wq, j = i - h * Wq, self = h * W + 4 * j;
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(yp + self);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ho0 = h >> 1, nho = (h & 1) && ho0 + 1 < Ho ? 2 : 1;
+    const bool third = 2 * j + 2 < Wo;
+    for (int a = 0; a < nho; ++a) {
+      const int o = (ho0 + a) * Wo + 2 * j;                        // (Wo = W / 2: columns 2j and 2j + 1 exist)
+      const int i0 = ip[o], i1 = ip[o + 1];
+      const float g0 = gp[o], g1 = gp[o + 1];
+      if (i0 == self) s[0] += g0;
+      if (i0 == self + 1) s[1] += g0;
+      if (i1 == self + 1) s[1] += g1;
+      if (i1 == self + 2) s[2] += g1;
+      if (i1 == self + 3) s[3] += g1;
+      if (third) {
+        if (ip[o + 2] == self + 3) s[3] += gp[o + 2];
+      }
+    }
+    f32x4 out;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sk = fmaf(yv[k], sc, sh) > 0.f ? s[k] : 0.f;
+      out[k] = fmaf(cp, sk, fmaf(cq, yv[k], cr));
+    }
+    *reinterpret_cast<f32x4*>(dp + self) = out;
+  }
+}
 // odd widths: one pixel per thread
 __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_apply1_kernel(const float* __restrict__ g, const int* __restrict__ idx,
                                                                          const float* __restrict__ y, const float* __restrict__ scale,
@@ -1245,7 +1291,11 @@ extern "C" int avsep_maxpool_bn_relu_bwd_apply(const float* g, const int32_t* id
   if (!g || !idx || !y || !scale || !shift || !pqr || !dy || N <= 0 || C <= 0 || H <= 0 || W <= 0) return AVSEP_ERR_ARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * C * H * W;
-  if ((W & 1) == 0 && (long long)N * C <= 65535 && (long long)H * W < 0x7fffffffLL) {
+  if ((W & 3) == 0 && (long long)N * C <= 65535 && (long long)H * W < 0x7fffffffLL) {
+    const int per = H * (W / 4), gx = (per + 255) / 256 < 64 ? (per + 255) / 256 : 64;
+    hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply4_kernel, dim3(gx, N * C), dim3(256), 0, (hipStream_t)stream, g, idx, y, scale,
+                       shift, pqr, C, H, W, Ho, Wo, dy);
+  } else if ((W & 1) == 0 && (long long)N * C <= 65535 && (long long)H * W < 0x7fffffffLL) {
     const int per = H * (W / 2), gx = (per + 255) / 256 < 64 ? (per + 255) / 256 : 64;
     hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply_kernel, dim3(gx, N * C), dim3(256), 0, (hipStream_t)stream, g, idx, y, scale,
                        shift, pqr, C, H, W, Ho, Wo, dy);

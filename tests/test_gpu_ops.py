@@ -561,6 +561,31 @@ def _dilated_folded_case(dev, K, family):
     assert_close(cv.wgrad(t(dy))[0], w.grad, 2e-5, "wgrad")
 
 
+@pytest.mark.parametrize("H,W", [(12, 16), (10, 14), (9, 11), (64, 112)])   # pixel quads / pixel pairs / single pixels / the stem's width
+def test_stem_tail_backward_apply(dev, H, W):
+    """max-pool 3x3/s2 backward + ReLU mask + folded BatchNorm backward in one pass over the stem's conv output
+    (vision_net.py:111-117 children 1-3, backward): the three kernel forms of avsep_maxpool_bn_relu_bwd_apply."""
+    K = _pkg().kernels
+    g = torch.Generator().manual_seed(41)
+    N, C = 3, 5
+    y = torch.randn(N, C, H, W, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    a = F.relu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    z_ref, ind = F.max_pool2d(a, 3, 2, 1, return_indices=True)
+    t = lambda v: v.to(dev)
+    rows = torch.stack([sc, sh, torch.zeros(C), torch.ones(C)]).to(dev)
+    z, idx = K.maxpool3x3s2(t(y), rows[0], rows[1], 1)
+    assert_close(z, z_ref, 1e-6, "maxpool forward")
+    assert torch.equal(idx.cpu().long()[z_ref > 0], ind[z_ref > 0])          # (an all-zero window has no unique winner)
+    gp = torch.randn(z_ref.shape, generator=g)
+    pqr = torch.randn(3, C, generator=g)
+    da = torch.zeros(N, C, H * W).scatter_add_(2, ind.reshape(N, C, -1), (gp * (z_ref > 0)).reshape(N, C, -1)).reshape(N, C, H, W)
+    v = lambda k: pqr[k].view(1, -1, 1, 1)
+    dy_ref = v(0) * (da * (a > 0)) + v(1) * y + v(2)
+    dy = K.maxpool_bn_relu_bwd_apply(t(gp), idx, t(y), rows, t(pqr))
+    assert_close(dy, dy_ref, 1e-6, "stem-tail backward apply")
+
+
 @pytest.mark.parametrize("N,C,H,W,dil,fused", [(40, 72, 56, 56, 1, True),     # 16-byte stores (W % 4 == 0)
                                                   (400, 72, 14, 14, 1, True),    # masked scalar stores, partial tiles
                                                   (260, 72, 14, 14, 2, True),    # parity sub-images (stride-2 stores)
