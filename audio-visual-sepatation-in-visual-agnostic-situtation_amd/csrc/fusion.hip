@@ -286,8 +286,12 @@ __global__ __launch_bounds__(256) void fusion_av_bwd_kernel(FusArgs a, const flo
   // gradient to the audio vectors -> scattered to the arg-max position of the global max-pool.  A wave owns channel d: its
   // lanes sweep the HW positions of v_c[d] (coalesced; a thread per (k, d) walked its own row, 64 cache lines per load
   // instruction: 2/3 of the kernel's 220 us) and reduce both audio blocks' sums at once.
+  // (The kernel was one workgroup per sample: 64 of 256 CUs at batch 64, 290 us per call, and two thirds of that in the two
+  //  channel sweeps below.  gridDim.y workgroups share a sample now: each recomputes the maps — the other parts' reads of v
+  //  hit the L2 — and sweeps its own slice [dlo, dhi) of the Dc channels.)
+  const int dlo = (int)((long long)Dc * blockIdx.y / gridDim.y), dhi = (int)((long long)Dc * (blockIdx.y + 1) / gridDim.y), dn = dhi - dlo;
   float* s_ga = s_S + 8;                 // [D]
-  for (int d = wave; d < Dc; d += 4) {
+  for (int d = dlo + wave; d < dhi; d += 4) {
     float g0 = 0.f, g1 = 0.f;
     for (int c = 0; c < 2; ++c) {
       const float* vp = (c == 0 ? a.v0 : a.v1) + ((long long)b * Dc + d) * HW;
@@ -311,8 +315,8 @@ __global__ __launch_bounds__(256) void fusion_av_bwd_kernel(FusArgs a, const flo
     if (lane == 0) { s_ga[d] = g0; s_ga[Dc + d] = g1; }
   }
   __syncthreads();
-  for (int i = tid; i < D; i += 256) {
-    int k = i / Dc;
+  for (int e = tid; e < 2 * dn; e += 256) {
+    const int k = e / dn, i = k * Dc + dlo + e % dn;
     float g = s_ga[i];
     if (a.att == 0) {
       float na = s_na[k], nac = fmaxf(na, FUS_EPS);
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void fusion_av_bwd_kernel(FusArgs a, const flo
     const float* E1 = s_E + (1 * 2 + c) * HW;
     const float* at = s_m + ((c ^ best) * 2 + c) * HW;
     const int where = s_arg[(c ^ best) * 2 + c];
-    for (int i = tid; i < Dc * HW; i += 256) {
+    for (int i = dlo * HW + tid; i < dhi * HW; i += 256) {
       int d = i / HW, hw = i % HW;
       float g;
       if (a.att == 1) {
@@ -406,7 +410,9 @@ extern "C" int avsep_fusion_av_bwd(const float* x, const float* v0, const float*
   FusArgs a{x, v0, v1, B, Dc, FT, HW, kind, att};
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)fusion_av_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(fusion_av_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, a, a_pool, pool_idx, sel_idx, best,
+  int parts = B >= 256 ? 1 : (B >= 128 ? 2 : 4);        // channel slices per sample: fill the chip at the bench's batch
+  if (parts > Dc) parts = Dc;
+  hipLaunchKernelGGL(fusion_av_bwd_kernel, dim3(B, parts), dim3(256), smem, (hipStream_t)stream, a, a_pool, pool_idx, sel_idx, best,
                      dfeat, dmaps, dmatch, dmatch_scale, dx_accum, dv0, dv1);
   AVSEP_LAUNCH_CHECK();
   return AVSEP_OK;
