@@ -933,9 +933,10 @@ def test_sdr_on_synthetic_val_trains_in_both_precisions(dev):
     evaluated on a held-out seeded set with the reference's evaluate() protocol (main.py:421-503).  The model must LEARN in both
     precisions — training loss down by >= 8 % (measured 13-28 %), validation SDR up by >= 4 dB from the untrained masks
     (measured +7 ... +20 dB; the thresholded masks of a 300-step model make the metric itself noisy) — and bf16 must track fp32:
-    final training losses within 25 % (measured <= 10.6 %: a 15-step window of random batches), validation SDR within 7 dB (the
-    SAME fp32 configuration ends 2-4 dB apart between runs at this length, profiles/r05_sdr_on_synthetic_val_*.json; a bf16 path
-    that does not train shows up as no SDR gain and no loss decrease, far outside every one of these margins)."""
+    final training losses within 25 % (measured <= 10.6 %: a 15-step window of random batches), validation SDR within 9 dB (the
+    SAME fp32 command has ended up to 6.2 dB apart between runs at this length — audio-only +3.9 ... +10.1 dB over seven runs,
+    DESIGN.md 8d, profiles/r05_sdr_on_synthetic_val_*.json; a bf16 path that does not train shows up as no SDR gain (>= 14 dB
+    short) and no loss decrease, far outside every one of these margins)."""
     import os
     import sys
     P = _pkg()
@@ -956,7 +957,7 @@ def test_sdr_on_synthetic_val_trains_in_both_precisions(dev):
         a, b = r["f32"]["train_loss_" + k]["last"], r["bf16"]["train_loss_" + k]["last"]
         assert abs(a - b) <= 0.25 * a, (k, a, b)
     for k in ("val_av", "val_ao"):
-        assert abs(r["bf16_minus_f32_after"][k]["sdr"]) <= 7.0, r["bf16_minus_f32_after"]
+        assert abs(r["bf16_minus_f32_after"][k]["sdr"]) <= 9.0, r["bf16_minus_f32_after"]
 
 
 def test_eval_path_vs_oracle(dev):
