@@ -262,6 +262,12 @@ def test_pack_scope_and_plan_batch_are_scoped():
         assert K._pack_cache == {"x": 1}
     assert K._pack_cache is None
     assert P.lib.ConvDesc().plan_n == 0 and ctypes.sizeof(P.lib.ConvDesc) == 24 * 4 + 6 * 8
+    # avsep_act_bwd: eleven pointers in the header's order, then the int32 activation code (padded to the pointer size)
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "avsep.h")).read()
+    body = hdr[hdr.index("typedef struct avsep_act_bwd {"):hdr.index("} avsep_act_bwd;")]
+    names = re.findall(r"(?:const float\*|double\*|int32_t)\s+(\w+);", body)
+    assert names == [n for n, _ in P.lib.ActBwd._fields_], names
+    assert ctypes.sizeof(P.lib.ActBwd) == 11 * 8 + 8
 
 
 def test_flat_sgd_state_dict_is_layout_independent_and_reads_older_blobs():
