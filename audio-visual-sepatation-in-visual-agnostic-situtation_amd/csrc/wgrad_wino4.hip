@@ -59,7 +59,8 @@ constexpr int X4P_KPS_MAX = 512;                // regions of one split (origin 
 // two x parities of a sub-map row TOGETHER in one region: its four tiles are (tile row ty, x parity px), the patch is 10
 // sub-rows x 12 CONSECUTIVE columns of the map (the two parities' 6-column patches interleaved, de-interleaved by the LDS
 // store addresses) and a lane pair (px = 0 | 1) loads the 8 consecutive dY values of a tile row as two 8-byte pairs each
-// and swaps the odd / even ones through the DPP crossbar — a quarter of the cache-line lookups of GEN 2, which bound it.
+// and swaps the odd / even ones through the DPP crossbar — half the cache-line lookups of GEN 2, which bound it, and patch
+// rows that are contiguous in memory.
 template <bool RAW, int GEN>
 __global__ __launch_bounds__(X4_THREADS) void winow4_kernel(X4Args a) {
   constexpr int NT = X4_THREADS, BCO = X4_BCO, BCI = X4_BCI, PW = X4P_PW, PS = X4P_PS, YCO = X4P_YCO;
