@@ -28,7 +28,8 @@
 // in flight are register loads.
 // Epilogue: Y = A^T M A.  The 36 positions of an output tile sit in four waves, so M goes through LDS in four passes
 // (channel block x accumulator-row half: 36 x 16 x 32 floats = the two V buffers), then every thread transforms one
-// (channel, tile): 100 vector instructions, four 16-byte row stores, BatchNorm sums.
+// (channel, tile): 100 vector instructions, four 16-byte row stores, BatchNorm sums.  The data gradient can be taken through
+// the activation in front of the conv's input there (EPI instantiations, W4Epi below: avsep_conv2d_dgrad_act).
 #include <stdlib.h>
 #include <type_traits>
 
