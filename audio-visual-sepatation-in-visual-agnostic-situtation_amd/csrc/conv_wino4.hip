@@ -429,7 +429,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
           for (int rr = 0; rr < 8; ++rr)
             Zs[((9 * wq + e) * 16 + (rr & 3) + 8 * (rr >> 2) + 4 * lk) * 32 + li] = acc[e][8 * h + rr];
       }
-      __syncthreads();
+      lds_barrier();           // LDS only: the 16-byte stores of the previous pass stay in flight (a __syncthreads() waits for them)
       {
         const int lrow = cbp * 32 + 16 * h + ec, row = m0 + lrow;
         const bool rok = row < a.Cout;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_kernel(W4Args a) {
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
   }
   if (want_stats) {
